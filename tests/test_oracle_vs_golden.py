@@ -1,0 +1,236 @@
+"""Pins the numpy oracle (oracle/dsrl_oracle.py) to the vectors captured from the imported reference
+(tests/golden/make_golden.py).  CPU only; no reference import happens here."""
+import numpy as np
+import pytest
+
+import gen
+import oracle as O
+
+F64 = np.float64
+
+
+def close(a, b, rtol=2e-4, atol=None, name=''):
+    a = np.asarray(a, F64); b = np.asarray(b, F64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    if atol is None:
+        atol = rtol * max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b).max() if a.size else 0.0
+    assert np.all(np.isnan(a) == np.isnan(b)), name
+    assert not (err > atol + 0 * rtol), f'{name}: max err {err:.3e} > {atol:.3e} (ref max {np.abs(b).max():.3e})'
+
+
+# ------------------------------------------------------------------------------------------ FA loss
+FA_CASES = ['rand', 'c3', 'big', 'signed', 'relu_like', 'same', 'near_degenerate']
+
+
+@pytest.mark.parametrize('case', FA_CASES)
+def test_fa_forward(golden, case):
+    g = golden('fa_loss')
+    f1, f2 = g[f'{case}.fm1'].astype(F64), g[f'{case}.fm2'].astype(F64)
+    close(O.fa_loss(f1, f2), g[f'{case}.mean'], 2e-5, name='mean')
+    close(O.fa_loss(f1, f2, reduction='sum'), g[f'{case}.sum'], 2e-5, name='sum')
+    none = O.fa_loss(f1, f2, reduction='none')
+    assert tuple(none.shape) == tuple(g[f'{case}.none_shape'])
+    close(gen.strided_sample(none), g[f'{case}.none_sample'], 1e-4, name='none')
+
+
+@pytest.mark.parametrize('case', ['rand', 'c3', 'big', 'signed', 'relu_like', 'same'])
+def test_fa_backward(golden, case):
+    g = golden('fa_loss')
+    f1, f2 = g[f'{case}.fm1'].astype(F64), g[f'{case}.fm2'].astype(F64)
+    g1, g2 = O.fa_loss_bwd(f1, f2)
+    # the gradient holds sums of sign(S1_i - S2_j): a near-tie flipped by fp32 rounding moves it by 2/(BCn^2)
+    close(g1, g[f'{case}.g1'], 2e-3, name='g1')
+    close(g2, g[f'{case}.g2'], 2e-3, name='g2')
+
+
+def test_fa_backward_near_degenerate(golden):
+    g = golden('fa_loss')
+    f1, f2 = g['near_degenerate.fm1'].astype(F64), g['near_degenerate.fm2'].astype(F64)
+    g1, g2 = O.fa_loss_bwd(f1, f2)
+    close(g1, g['near_degenerate.g1'], 2e-2, name='g1')       # d sigma_1 is ill-conditioned at sigma_1 ~ sigma_2
+    close(g2, g['near_degenerate.g2'], 2e-3, name='g2')
+
+
+def test_fa_zero_sample_is_nan(golden):
+    g = golden('fa_loss')
+    assert np.isnan(g['zero_sample.mean'])
+    assert np.isnan(O.fa_loss(g['zero_sample.fm1'].astype(F64), g['zero_sample.fm2'].astype(F64)))
+
+
+def test_fa_shape_checks():
+    with pytest.raises(AssertionError):
+        O.fa_loss(np.zeros((2, 1, 8)), np.zeros((2, 1, 8)))
+    with pytest.raises(AssertionError):
+        O.fa_loss(np.zeros((2, 1, 8, 8)), np.zeros((2, 1, 8, 16)))
+
+
+# --------------------------------------------------------------------------------------- micro ops
+CONVS = ['conv_d6', 'conv_d12', 'conv_d18', 'conv_1x1', 'conv_3x3', 'conv_s8', 'conv_s2', 'conv_7x7s2', 'conv_1x1s2', 'conv_d2']
+
+
+@pytest.mark.parametrize('name', CONVS)
+def test_conv(golden, name):
+    g = golden('ops_micro')
+    stride, pad, dil = [int(v) for v in g[f'{name}.cfg']]
+    x, w = g[f'{name}.x'].astype(F64), g[f'{name}.w'].astype(F64)
+    b = g[f'{name}.b'].astype(F64) if f'{name}.b' in g else None
+    close(O.conv2d(x, w, b, stride, pad, dil), g[f'{name}.y'], name='y')
+    dx, dw, db = O.conv2d_bwd(x, w, g[f'{name}.dy'].astype(F64), stride, pad, dil, b is not None)
+    close(dx, g[f'{name}.dx'], name='dx'); close(dw, g[f'{name}.dw'], name='dw')
+    if b is not None:
+        close(db, g[f'{name}.db'], name='db')
+
+
+def test_convT(golden):
+    g = golden('ops_micro')
+    x, w, b = (g[f'convT.{k}'].astype(F64) for k in 'xwb')
+    close(O.conv_transpose2d_k2s2(x, w, b), g['convT.y'])
+    dx, dw, db = O.conv_transpose2d_k2s2_bwd(x, w, g['convT.dy'].astype(F64), True)
+    close(dx, g['convT.dx']); close(dw, g['convT.dw']); close(db, g['convT.db'])
+
+
+@pytest.mark.parametrize('name', ['up2', 'up4', 'up_bcast', 'up_odd'])
+def test_bilinear(golden, name):
+    g = golden('ops_micro')
+    x = g[f'{name}.x'].astype(F64)
+    close(O.upsample_bilinear_ac(x, g[f'{name}.y'].shape[2:]), g[f'{name}.y'])
+    close(O.upsample_bilinear_ac_bwd(x.shape[2:], g[f'{name}.dy'].astype(F64)), g[f'{name}.dx'])
+
+
+def test_bilinear_module_scale2(golden):
+    g = golden('ops_micro')
+    x = g['up2_module.x'].astype(F64)
+    close(O.upsample_bilinear_ac(x, (12, 20)), g['up2_module.y'])
+
+
+def test_pixel_shuffle(golden):
+    g = golden('ops_micro')
+    np.testing.assert_array_equal(O.pixel_shuffle(g['pixel_shuffle.x'], 8), g['pixel_shuffle.y'])
+    np.testing.assert_array_equal(O.pixel_shuffle_bwd(g['pixel_shuffle.dy'], 8), g['pixel_shuffle.dx'])
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_batchnorm(golden, mode):
+    g = golden('ops_micro')
+    p = f'bn_{mode}'
+    x, gamma, beta = g[f'{p}.x'].astype(F64), g[f'{p}.gamma'].astype(F64), g[f'{p}.beta'].astype(F64)
+    rm0, rv0, dy = g[f'{p}.rm0'].astype(F64), g[f'{p}.rv0'].astype(F64), g[f'{p}.dy'].astype(F64)
+    if mode == 'train':
+        y, (mean, invstd), (rm1, rv1) = O.batchnorm_train(x, gamma, beta, rm0, rv0)
+        dx, dg, db = O.batchnorm_train_bwd(x, gamma, mean, invstd, dy)
+        close(rm1, g[f'{p}.rm1']); close(rv1, g[f'{p}.rv1'])
+    else:
+        y, (mean, invstd) = O.batchnorm_eval(x, gamma, beta, rm0, rv0)
+        dx, dg, db = O.batchnorm_eval_bwd(x, gamma, mean, invstd, dy)
+        close(rm0, g[f'{p}.rm1']); close(rv0, g[f'{p}.rv1'])
+    close(y, g[f'{p}.y']); close(dx, g[f'{p}.dx']); close(dg, g[f'{p}.dgamma']); close(db, g[f'{p}.dbeta'])
+
+
+def test_pools(golden):
+    g = golden('ops_micro')
+    close(O.global_avg_pool(g['gap.x'].astype(F64)), g['gap.y'])
+    close(O.global_avg_pool_bwd((16, 32), g['gap.dy'].astype(F64)), g['gap.dx'])
+    y, arg = O.max_pool3x3s2(g['maxpool.x'].astype(F64))
+    close(y, g['maxpool.y'])
+    close(O.max_pool3x3s2_bwd((16, 32), arg, g['maxpool.dy'].astype(F64)), g['maxpool.dx'])
+    close(O.avg_pool2d(g['avgpool8.x'].astype(F64), 8), g['avgpool8.y'])
+
+
+def test_ce_mse_sgd(golden):
+    g = golden('ops_micro')
+    lg, tg = g['ce.logits'].astype(F64), g['ce.target']
+    close(O.cross_entropy(lg, tg), g['ce.loss'], 1e-5)
+    close(O.cross_entropy_bwd(lg, tg), g['ce.dlogits'])
+    a, b = g['mse.a'].astype(F64), g['mse.b'].astype(F64)
+    close(O.mse(a, b), g['mse.loss'], 1e-5); close(O.mse_bwd(a, b), g['mse.da'])
+    p, buf = g['sgd.p0'].astype(F64), None
+    for step in range(2):
+        p, buf = O.sgd_step(p, g[f'sgd.g{step}'].astype(F64), buf, 0.006, 0.9, 5e-4)
+        close(p, g[f'sgd.p{step + 1}'], 1e-6)
+
+
+# ------------------------------------------------------------------------------------ composite head
+def _run_oracle_head(widths, stage, pseed, iseed, batch, h16, w16, training, backward=True):
+    P = {k: v.astype(F64) for k, v in gen.make_head_params(pseed, widths, stage).items()}
+    x16, x4, target, org = gen.make_head_inputs(iseed, batch, h16, w16, widths)
+    out = O.head_forward(P, x16.astype(F64), x4.astype(F64), stage, training)
+    L = O.total_loss(out, target, org.astype(F64), stage, backward=backward)
+    return out, L
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_head_small(golden, mode):
+    g = golden('head_small')
+    out, L = _run_oracle_head(gen.SMALL, 3, 101, 202, 2, 2, 4, mode == 'train')
+    for n in ('SSSR', 'SISR', 'SSSR_ft', 'SISR_ft'):
+        close(getattr(out, n).v, g[f'{mode}.{n}'], 1e-4, name=n)
+    close(np.array(L), g[f'{mode}.losses'], 1e-4, name='losses')
+    for k, v in out.params.items():
+        ref = g[f'{mode}.grad.{k}']
+        got = v.g if v.g is not None else np.zeros_like(ref)
+        close(got, ref, 2e-3, name='grad ' + k)
+    close(out.inputs[0].g, g[f'{mode}.grad.backbone_features'], 2e-3, name='dx16')
+    close(out.inputs[1].g, g[f'{mode}.grad.lowlevel_features'], 2e-3, name='dx4')
+    if mode == 'train':
+        for k, (rm, rv) in out.new_running.items():
+            close(rm, g[f'train.new.{k}.running_mean'], name=k); close(rv, g[f'train.new.{k}.running_var'], name=k)
+
+
+@pytest.mark.parametrize('stage', [1, 2])
+def test_head_small_stage_gating(golden, stage):
+    g = golden('head_small')
+    out, L = _run_oracle_head(gen.SMALL, stage, 101, 202, 2, 2, 4, True)
+    close(out.SSSR.v, g[f'stage{stage}.SSSR'], 1e-4)
+    close(np.array(L), g[f'stage{stage}.losses'], 1e-4)
+    close(out.params['SSSR_decoder.cls_conv.weight'].g, g[f'stage{stage}.grad.cls_w'], 2e-3)
+    assert out.SSSR_ft is None and (out.SISR is None) == (stage == 1)
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_head_fullwidth(golden, mode):
+    g = golden('head_fullwidth')
+    out, L = _run_oracle_head(gen.FULL, 3, 303, 404, 2, 4, 8, mode == 'train')
+    close(gen.strided_sample(out.SSSR.v, 65536), g[f'{mode}.SSSR_sample'], 1e-4)
+    assert (out.SSSR.v.argmax(axis=1) == g[f'{mode}.SSSR_argmax']).mean() > 0.9999
+    close(gen.strided_sample(out.SISR.v, 16384), g[f'{mode}.SISR_sample'], 1e-4)
+    close(out.SSSR_ft.v, g[f'{mode}.SSSR_ft'], 1e-4); close(out.SISR_ft.v, g[f'{mode}.SISR_ft'], 1e-4)
+    close(np.array(L), g[f'{mode}.losses'], 1e-4)          # eval: FA is NaN in the reference too (all-zero map)
+    if mode == 'train':
+        for k, v in out.params.items():
+            if f'{mode}.grad.{k}' in g:
+                close(v.g, g[f'{mode}.grad.{k}'], 3e-3, name='grad ' + k)
+            else:
+                close(gen.strided_sample(v.g, 4096), g[f'{mode}.gradsample.{k}'], 3e-3, name='gradsample ' + k)
+                cs, ref = gen.checksum(v.g), g[f'{mode}.gradsum.{k}']
+                assert abs(cs[1] - ref[1]) <= 2e-3 * ref[1], k
+
+
+def test_train_steps(golden):
+    """Two SGD steps of the small head reproduce the reference's losses and parameters."""
+    g = golden('train_steps')
+    W = gen.SMALL
+    P = {k: v.astype(F64) for k, v in gen.make_head_params(101, W, 3).items()}
+    bufs = {}
+    for step in range(2):
+        x16, x4, target, org = gen.make_head_inputs(700 + step, 2, 2, 4, W)
+        out = O.head_forward(P, x16.astype(F64), x4.astype(F64), 3, True)
+        L = O.total_loss(out, target, org.astype(F64), 3)
+        close(np.array(L), g[f'step{step}.losses'], 2e-4)
+        for k, v in out.params.items():
+            P[k], bufs[k] = O.sgd_step(P[k], v.g, bufs.get(k), 0.006, 0.9, 5e-4)
+        for k, (rm, rv) in out.new_running.items():
+            P[k + '.running_mean'], P[k + '.running_var'] = rm, rv
+        for k in P:
+            close(P[k], g[f'step{step}.{k}'], 2e-4, name=f'step{step} {k}')
+
+
+def test_philox_known_answer():
+    """Random123 known-answer test for Philox4x32-10 (counter = key = 0 and the all-ones vector)."""
+    from oracle import philox
+    r = philox.philox4x32_10(np.uint32(0), np.uint32(0), np.uint32(0), np.uint32(0), 0, 0)
+    assert [int(v) for v in r] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    r = philox.philox4x32_10(np.uint32(0xffffffff), np.uint32(0xffffffff), np.uint32(0xffffffff), np.uint32(0xffffffff), 0xffffffff, 0xffffffff)
+    assert [int(v) for v in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    m = philox.dropout_keep_mask_nchw((2, 19, 16, 32), 0.2, 1234, 3)
+    assert abs(m.mean() - 0.8) < 0.02
