@@ -1,0 +1,116 @@
+"""ctypes binding of libdsrl_hip.so (include/dsrl_hip.h).
+
+The library is the product's only arithmetic path: if it cannot be loaded, or a call returns an error code,
+a RuntimeError is raised - there is no CPU or stock-PyTorch fallback behind these wrappers.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (imported first so the HIP runtime the allocator uses is the one the library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdsrl_hip.so')
+
+fp = C.c_void_p          # device pointers travel as integers
+i32 = C.c_int
+i64 = C.c_int64
+u64 = C.c_uint64
+u32 = C.c_uint32
+f32 = C.c_float
+sz = C.c_size_t
+stream_t = C.c_void_p
+
+_conv_shape = [i32] * 10                      # N,H,W,C,K,R,S,stride,pad,dil
+
+PROTOTYPES = {
+    'dsrl_version': (i32, []),
+    'dsrl_last_error': (C.c_char_p, []),
+    'dsrl_device_check': (i32, [C.POINTER(i32)]),
+    'dsrl_conv2d_fwd_workspace_bytes': (sz, _conv_shape),
+    'dsrl_conv2d_fwd': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, stream_t]),
+    'dsrl_conv2d_dgrad_workspace_bytes': (sz, _conv_shape),
+    'dsrl_conv2d_dgrad': (i32, [fp, i32, fp, fp, i32] + _conv_shape + [fp, sz, stream_t]),
+    'dsrl_conv2d_wgrad_workspace_bytes': (sz, _conv_shape),
+    'dsrl_conv2d_wgrad': (i32, [fp, i32, fp, i32, fp] + _conv_shape + [fp, sz, stream_t]),
+    'dsrl_conv2d_inbounds_macs': (i64, _conv_shape),
+    'dsrl_colsum_workspace_bytes': (sz, [i64, i32]),
+    'dsrl_colsum': (i32, [fp, i32, i64, i32, fp, fp, sz, stream_t]),
+    'dsrl_bn_workspace_bytes': (sz, [i64, i32]),
+    'dsrl_bn_stats': (i32, [fp, i32, i64, i32, f32, f32, fp, fp, fp, fp, fp, sz, stream_t]),
+    'dsrl_bn_invstd_from_var': (i32, [fp, i32, f32, fp, stream_t]),
+    'dsrl_bn_apply': (i32, [fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, stream_t]),
+    'dsrl_bn_bwd': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, f32, i32, fp, sz, stream_t]),
+    'dsrl_dropout_fwd': (i32, [fp, i32, fp, i32, i64, i32, f32, u64, u32, stream_t]),
+    'dsrl_dropout_bwd': (i32, [fp, i32, fp, i32, i64, i32, f32, u64, u32, stream_t]),
+    'dsrl_bilinear_ac_fwd': (i32, [fp, i32, fp, i32, i32, i32, i32, i32, i32, i32, stream_t]),
+    'dsrl_bilinear_ac_bwd': (i32, [fp, i32, fp, i32, i32, i32, i32, i32, i32, i32, stream_t]),
+    'dsrl_global_avgpool_fwd': (i32, [fp, i32, fp, i32, i32, i32, stream_t]),
+    'dsrl_global_avgpool_bwd': (i32, [fp, fp, i32, i32, i32, i32, stream_t]),
+    'dsrl_maxpool3x3s2_fwd': (i32, [fp, fp, i32, i32, i32, i32, stream_t]),
+    'dsrl_maxpool3x3s2_bwd': (i32, [fp, fp, fp, i32, i32, i32, i32, stream_t]),
+    'dsrl_convt2x2_fwd': (i32, [fp, fp, fp, fp, i32, i32, i32, i32, i32, stream_t]),
+    'dsrl_convt2x2_bwd_workspace_bytes': (sz, [i32] * 5),
+    'dsrl_convt2x2_bwd': (i32, [fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, fp, sz, stream_t]),
+    'dsrl_pixel_shuffle_fwd': (i32, [fp, fp, i32, i32, i32, i32, i32, stream_t]),
+    'dsrl_pixel_shuffle_bwd': (i32, [fp, fp, i32, i32, i32, i32, i32, stream_t]),
+    'dsrl_pointwise_strided_fwd': (i32, [fp, fp, fp, i32, i32, i32, i32, i32, stream_t]),
+    'dsrl_pointwise_strided_bwd_workspace_bytes': (sz, [i32] * 5),
+    'dsrl_pointwise_strided_bwd': (i32, [fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, fp, sz, stream_t]),
+    'dsrl_copy2d': (i32, [fp, i32, fp, i32, i64, i32, stream_t]),
+    'dsrl_nchw_to_nhwc': (i32, [fp, fp, i32, i32, i32, i32, i32, stream_t]),
+    'dsrl_ce_workspace_bytes': (sz, [i64]),
+    'dsrl_ce_fwd': (i32, [fp, i32, fp, i64, i32, i32, fp, fp, sz, stream_t]),
+    'dsrl_ce_bwd': (i32, [fp, i32, fp, i64, i32, i32, fp, fp, fp, i32, stream_t]),
+    'dsrl_mse_workspace_bytes': (sz, [i64]),
+    'dsrl_mse_fwd': (i32, [fp, fp, i64, fp, fp, sz, stream_t]),
+    'dsrl_mse_bwd': (i32, [fp, fp, i64, fp, fp, stream_t]),
+    'dsrl_fa_saved_floats': (sz, [i32] * 5),
+    'dsrl_fa_workspace_bytes': (sz, [i32] * 5),
+    'dsrl_fa_fwd': (i32, [fp, fp, i32, i32, i32, i32, i64, i64, i64, i64, i32, i32, fp, fp, fp, sz, stream_t]),
+    'dsrl_fa_bwd': (i32, [fp, fp, i32, i32, i32, i32, i64, i64, i64, i64, i32, i32, fp, fp, fp, fp, fp, sz, stream_t]),
+    'dsrl_sgd_step': (i32, [fp, fp, fp, i64, f32, f32, f32, f32, stream_t]),
+    'dsrl_nan_check': (i32, [fp, i64, fp, stream_t]),
+    'dsrl_prof_enable': (i32, [i32]),
+    'dsrl_prof_read': (i32, [i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'dsrl_prof_kernel_name': (C.c_char_p, [i32]),
+}
+
+_lib = None
+
+
+class DsrlHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libdsrl_hip.so (once). Raises DsrlHipError with the build hint when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise DsrlHipError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           f'or `make -C {os.path.join(_HERE, "csrc")}` - there is no fallback path')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here means header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dsrl_version() != 1:
+        raise DsrlHipError(f'libdsrl_hip.so ABI version {lib.dsrl_version()} != 1')
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = _lib.dsrl_last_error().decode('utf-8', 'replace') if _lib is not None else ''
+        raise DsrlHipError(f'{what} failed with code {code}: {msg}')
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)

@@ -1,0 +1,296 @@
+// BatchNorm2d (+residual, ReLU, Dropout), column sums and standalone Dropout on pixel-major [P][ld] fp32 tensors.
+// Memory-bound: every kernel maps consecutive threads to consecutive channels of consecutive pixels (ChanMap in
+// common.h), keeps its per-channel constants in registers and reduces deterministically (block partials in the
+// workspace, merged by a finalize kernel in fp64; Chan/Welford merge for the variance).
+#include "common.h"
+#include <algorithm>
+
+namespace dsrl {
+
+constexpr int kMaxRowBlocks = 1024;
+
+static int row_blocks(int64_t P) { return (int)std::max<int64_t>(1, std::min<int64_t>(kMaxRowBlocks, ceil_div(P, 64))); }
+
+// ---------------------------------------------------------------------------------------------- statistics
+// partial[0][bx][c] = n, [1] = mean, [2] = M2 over the rows of block bx
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int ld, long long P, int C, long long rows_per_block,
+                                                          float* __restrict__ part, int nbx) {
+    __shared__ float sh[3][256];
+    const ChanMap m = chan_map(C, blockIdx.y);
+    const long long row0 = blockIdx.x * rows_per_block, row1 = min(P, row0 + rows_per_block);
+    float n = 0.f, s1 = 0.f, s2 = 0.f, k0 = 0.f;
+    if (m.c >= 0) {
+        long long p = row0 + m.slot;
+        if (p < row1) k0 = x[p * ld + m.c];
+        for (; p < row1; p += m.G) {
+            const float d = x[p * ld + m.c] - k0;
+            s1 += d; s2 += d * d; n += 1.f;
+        }
+    }
+    float mean = 0.f, m2 = 0.f;
+    if (n > 0.f) { mean = k0 + s1 / n; m2 = fmaxf(s2 - s1 * s1 / n, 0.f); }
+    sh[0][threadIdx.x] = n; sh[1][threadIdx.x] = mean; sh[2][threadIdx.x] = m2;
+    __syncthreads();
+    if (m.c >= 0 && m.slot == 0) {
+        float na = n, ma = mean, qa = m2;
+        for (int g = 1; g < m.G; ++g) {
+            const int t = g * m.cg + (m.c - m.cg0);
+            const float nb = sh[0][t];
+            if (nb > 0.f) {
+                const float mb = sh[1][t], qb = sh[2][t];
+                const float nt = na + nb, d = mb - ma;
+                ma += d * (nb / nt);
+                qa += qb + d * d * (na * nb / nt);
+                na = nt;
+            }
+        }
+        const long long o = (long long)blockIdx.x * C + m.c;
+        part[o] = na; part[(long long)nbx * C + o] = ma; part[2ll * nbx * C + o] = qa;
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nbx, int C, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rm, float* __restrict__ rv) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double na = 0, ma = 0, qa = 0;
+    for (int b = 0; b < nbx; ++b) {
+        const long long o = (long long)b * C + c;
+        const double nb = part[o];
+        if (nb > 0) {
+            const double mb = part[(long long)nbx * C + o], qb = part[2ll * nbx * C + o];
+            const double nt = na + nb, d = mb - ma;
+            ma += d * (nb / nt);
+            qa += qb + d * d * (na * nb / nt);
+            na = nt;
+        }
+    }
+    const double var = na > 0 ? qa / na : 0.0;
+    mean[c] = (float)ma;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rm) rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * ma);
+    if (rv) rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * (na > 1 ? qa / (na - 1) : var));
+}
+
+__global__ void invstd_from_var_kernel(const float* __restrict__ var, int C, float eps, float* __restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) invstd[c] = (float)(1.0 / sqrt((double)var[c] + (double)eps));
+}
+
+// ---------------------------------------------------------------------------------------------- apply
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long P, int C,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ res, int ldr, int relu, float drop_p, unsigned long long seed, unsigned rng_stream) {
+    const ChanMap m = chan_map(C, blockIdx.y);
+    if (m.c < 0) return;
+    const float sc = gamma[m.c] * invstd[m.c];
+    const float sh = beta[m.c] - mean[m.c] * sc;
+    const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (long long p = (long long)blockIdx.x * m.G + m.slot; p < P; p += (long long)gridDim.x * m.G) {
+        float v = fmaf(x[p * ldx + m.c], sc, sh);
+        if (res) v += res[p * ldr + m.c];
+        if (relu) v = fmaxf(v, 0.f);
+        if (drop_p > 0.f) v = (philox_uniform((unsigned long long)p * C + m.c, seed, rng_stream) >= drop_p) ? v * keep_scale : 0.f;
+        y[p * ldy + m.c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+__device__ inline float masked_grad(float dy, float y, int relu, float drop_p, float keep_scale) {
+    if (relu) return y > 0.f ? dy * keep_scale : 0.f;
+    if (drop_p > 0.f) return y != 0.f ? dy * keep_scale : 0.f;
+    return dy;
+}
+
+// part[0][bx][c] = sum g, part[1][bx][c] = sum g*xhat
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
+                                                              const float* __restrict__ dy, int lddy, long long P, int C, long long rows_per_block,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              int relu, float drop_p, float* __restrict__ part, int nbx) {
+    __shared__ float sh[2][256];
+    const ChanMap m = chan_map(C, blockIdx.y);
+    const long long row0 = blockIdx.x * rows_per_block, row1 = min(P, row0 + rows_per_block);
+    float sg = 0.f, sgx = 0.f;
+    if (m.c >= 0) {
+        const float mu = mean[m.c], is = invstd[m.c];
+        const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+        const bool need_y = relu || drop_p > 0.f;
+        for (long long p = row0 + m.slot; p < row1; p += m.G) {
+            const float g = masked_grad(dy[p * lddy + m.c], need_y ? y[p * ldy + m.c] : 1.f, relu, drop_p, ks);
+            sg += g; sgx += g * ((x[p * ldx + m.c] - mu) * is);
+        }
+    }
+    sh[0][threadIdx.x] = sg; sh[1][threadIdx.x] = sgx;
+    __syncthreads();
+    if (m.c >= 0 && m.slot == 0) {
+        for (int g = 1; g < m.G; ++g) { const int t = g * m.cg + (m.c - m.cg0); sg += sh[0][t]; sgx += sh[1][t]; }
+        const long long o = (long long)blockIdx.x * C + m.c;
+        part[o] = sg; part[(long long)nbx * C + o] = sgx;
+    }
+}
+
+// sums[0][c] = dbeta, sums[1][c] = dgamma (fp32 copies also written to the parameter gradients)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nbx, int C, float* __restrict__ sums,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, b = 0;
+    for (int i = 0; i < nbx; ++i) { a += part[(long long)i * C + c]; b += part[(long long)nbx * C + (long long)i * C + c]; }
+    sums[c] = (float)a; sums[C + c] = (float)b;
+    if (dbeta) dbeta[c] = (float)a;
+    if (dgamma) dgamma[c] = (float)b;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
+                                                            const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
+                                                            float* __restrict__ dres, int lddr, long long P, int C,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ sums, int relu, float drop_p, int training) {
+    const ChanMap m = chan_map(C, blockIdx.y);
+    if (m.c < 0) return;
+    const float mu = mean[m.c], is = invstd[m.c], gi = gamma[m.c] * is;
+    const float inv_n = 1.f / (float)P;
+    const float mb = training ? sums[m.c] * inv_n : 0.f, mg = training ? sums[C + m.c] * inv_n : 0.f;
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const bool need_y = relu || drop_p > 0.f;
+    for (long long p = (long long)blockIdx.x * m.G + m.slot; p < P; p += (long long)gridDim.x * m.G) {
+        const float g = masked_grad(dy[p * lddy + m.c], need_y ? y[p * ldy + m.c] : 1.f, relu, drop_p, ks);
+        const float xh = (x[p * ldx + m.c] - mu) * is;
+        dx[p * lddx + m.c] = gi * (g - mb - xh * mg);
+        if (dres) dres[p * lddr + m.c] = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- column sums
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ld, long long P, int C, long long rows_per_block,
+                                                              float* __restrict__ part) {
+    __shared__ float sh[256];
+    const ChanMap m = chan_map(C, blockIdx.y);
+    const long long row0 = blockIdx.x * rows_per_block, row1 = min(P, row0 + rows_per_block);
+    float s = 0.f;
+    if (m.c >= 0) for (long long p = row0 + m.slot; p < row1; p += m.G) s += x[p * ld + m.c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (m.c >= 0 && m.slot == 0) {
+        for (int g = 1; g < m.G; ++g) s += sh[g * m.cg + (m.c - m.cg0)];
+        part[(long long)blockIdx.x * C + m.c] = s;
+    }
+}
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nbx, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0;
+    for (int i = 0; i < nbx; ++i) a += part[(long long)i * C + c];
+    out[c] = (float)a;
+}
+
+// ---------------------------------------------------------------------------------------------- dropout
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long P, int C,
+                                                       float p_drop, unsigned long long seed, unsigned rng_stream) {
+    const long long total = P * C;
+    const float ks = 1.f / (1.f - p_drop);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long p = e / C; const int c = (int)(e - p * C);
+        const float v = x[p * ldx + c];
+        y[p * ldy + c] = (philox_uniform((unsigned long long)e, seed, rng_stream) >= p_drop) ? v * ks : 0.f;
+    }
+}
+
+static dim3 apply_grid(int64_t P, int C) {
+    const int groups = (int)ceil_div(C, 256);
+    const int cg = std::min(C, 256), G = 256 / cg;
+    int64_t bx = std::min<int64_t>(ceil_div(P, (int64_t)G * 4), std::max(1, 2048 / groups));
+    return dim3((unsigned)std::max<int64_t>(1, bx), (unsigned)groups);
+}
+
+}  // namespace dsrl
+using namespace dsrl;
+
+extern "C" size_t dsrl_bn_workspace_bytes(int64_t P, int C) { return (size_t)(3 * (size_t)row_blocks(P) + 2) * C * sizeof(float); }
+extern "C" size_t dsrl_colsum_workspace_bytes(int64_t P, int C) { return (size_t)row_blocks(P) * C * sizeof(float); }
+
+extern "C" int dsrl_bn_stats(const float* x, int ldx, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,
+                             float* running_mean, float* running_var, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_REQUIRE(x && mean && invstd && ws && P > 0 && C > 0 && ldx >= C, DSRL_E_BADARG, "bn_stats: bad arguments (P=%lld C=%d ldx=%d)", (long long)P, C, ldx);
+    DSRL_REQUIRE(ws_bytes >= dsrl_bn_workspace_bytes(P, C), DSRL_E_WORKSPACE, "bn_stats: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const int nbx = row_blocks(P);
+    const long long rpb = ceil_div(P, nbx);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ldx, (long long)P, C, rpb, (float*)ws, nbx);
+    if (int e = launch_status("bn_partial_kernel")) return e;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, (const float*)ws, nbx, C, eps, momentum, mean, invstd, running_mean, running_var);
+    return launch_status("bn_finalize_kernel");
+}
+
+extern "C" int dsrl_bn_invstd_from_var(const float* running_var, int C, float eps, float* invstd, dsrl_stream_t stream) {
+    DSRL_REQUIRE(running_var && invstd && C > 0, DSRL_E_BADARG, "bn_invstd_from_var: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(invstd_from_var_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, running_var, C, eps, invstd);
+    return launch_status("invstd_from_var_kernel");
+}
+
+extern "C" int dsrl_bn_apply(const float* x, int ldx, float* y, int ldy, int64_t P, int C, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, const float* residual, int ldr, int relu, float drop_p,
+                             uint64_t seed, uint32_t rng_stream, dsrl_stream_t stream) {
+    DSRL_REQUIRE(x && y && mean && invstd && gamma && beta && P > 0 && C > 0 && ldx >= C && ldy >= C, DSRL_E_BADARG, "bn_apply: bad arguments");
+    DSRL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, DSRL_E_BADARG, "bn_apply: dropout p=%f outside [0,1)", drop_p);
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(bn_apply_kernel, apply_grid(P, C), dim3(256), 0, st, x, ldx, y, ldy, (long long)P, C, mean, invstd, gamma, beta, residual, ldr,
+                       relu, drop_p, (unsigned long long)seed, (unsigned)rng_stream);
+    return launch_status("bn_apply_kernel");
+}
+
+extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
+                           float* dresidual, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
+                           float* dgamma, float* dbeta, int relu, float drop_p, int training, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_REQUIRE(x && dy && dx && mean && invstd && gamma && ws && P > 0 && C > 0, DSRL_E_BADARG, "bn_bwd: bad arguments");
+    DSRL_REQUIRE(y || !(relu || drop_p > 0.f), DSRL_E_BADARG, "bn_bwd: forward output needed for the relu/dropout mask");
+    DSRL_REQUIRE(ws_bytes >= dsrl_bn_workspace_bytes(P, C), DSRL_E_WORKSPACE, "bn_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const int nbx = row_blocks(P);
+    const long long rpb = ceil_div(P, nbx);
+    float* part = (float*)ws;
+    float* sums = part + 3ll * nbx * C;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, (long long)P, C, rpb,
+                       mean, invstd, relu, drop_p, part, nbx);
+    if (int e = launch_status("bn_bwd_partial_kernel")) return e;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, (const float*)part, nbx, C, sums, dgamma, dbeta);
+    if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, apply_grid(P, C), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (long long)P, C,
+                       mean, invstd, gamma, (const float*)sums, relu, drop_p, training);
+    return launch_status("bn_bwd_apply_kernel");
+}
+
+extern "C" int dsrl_colsum(const float* x, int ld, int64_t P, int C, float* out, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_REQUIRE(x && out && ws && P > 0 && C > 0 && ld >= C, DSRL_E_BADARG, "colsum: bad arguments");
+    DSRL_REQUIRE(ws_bytes >= dsrl_colsum_workspace_bytes(P, C), DSRL_E_WORKSPACE, "colsum: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const int nbx = row_blocks(P);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ld, (long long)P, C, (long long)ceil_div(P, nbx), (float*)ws);
+    if (int e = launch_status("colsum_partial_kernel")) return e;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, (const float*)ws, nbx, C, out);
+    return launch_status("colsum_finalize_kernel");
+}
+
+static int dropout_common(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float p, uint64_t seed, uint32_t rng_stream, dsrl_stream_t stream) {
+    DSRL_REQUIRE(x && y && P > 0 && C > 0 && p >= 0.f && p < 1.f, DSRL_E_BADARG, "dropout: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const long long total = (long long)P * C;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 8192)), dim3(256), 0, st, x, ldx, y, ldy, (long long)P, C, p,
+                       (unsigned long long)seed, (unsigned)rng_stream);
+    return launch_status("dropout_kernel");
+}
+extern "C" int dsrl_dropout_fwd(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float p, uint64_t seed, uint32_t rng_stream, dsrl_stream_t stream) {
+    return dropout_common(x, ldx, y, ldy, P, C, p, seed, rng_stream, stream);
+}
+// the same mask applied to the gradient (the mask is regenerated, never stored)
+extern "C" int dsrl_dropout_bwd(const float* dy, int lddy, float* dx, int lddx, int64_t P, int C, float p, uint64_t seed, uint32_t rng_stream, dsrl_stream_t stream) {
+    return dropout_common(dy, lddy, dx, lddx, P, C, p, seed, rng_stream, stream);
+}

@@ -1,0 +1,89 @@
+// Shared host/device helpers of libdsrl_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/dsrl_hip.h"
+
+namespace dsrl {
+
+// ---------------------------------------------------------------- error reporting (thread-local)
+void set_error(const char* fmt, ...);
+int launch_status(const char* what);
+
+#define DSRL_REQUIRE(cond, code, ...)        \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::dsrl::set_error(__VA_ARGS__);  \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+// Binds the calling thread to the device that owns `stream` (autograd runs backward on its own thread).
+int bind_stream_device(hipStream_t s);
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+constexpr int kWave = 64;
+constexpr int kNumCU = 256;     // MI355X
+constexpr int kNumXCD = 8;
+
+// ---------------------------------------------------------------- Philox4x32-10 (same as oracle/philox.py)
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// uniform in [0,1) for element e: word (e&3) of philox(counter = e>>2, stream), u = (word>>8) * 2^-24
+__device__ inline float philox_uniform(uint64_t e, uint64_t seed, uint32_t stream) {
+    uint32_t r[4];
+    const uint64_t q = e >> 2;
+    philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    return (float)(r[e & 3] >> 8) * 5.9604644775390625e-08f;
+}
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Per-channel thread mapping for pixel-major [P][ld] tensors with C channels (channel group of <= 256):
+// G = 256 / cg pixels are processed side by side, thread t < G*cg owns channel (t % cg) of pixel slot (t / cg).
+struct ChanMap {
+    int cg0;     // first channel of this block's group
+    int cg;      // channels in the group (<= 256)
+    int G;       // pixel slots
+    int c;       // my channel (absolute), -1 if idle
+    int slot;    // my pixel slot
+};
+__device__ inline ChanMap chan_map(int C, int group_idx) {
+    ChanMap m;
+    m.cg0 = group_idx * 256;
+    m.cg = min(256, C - m.cg0);
+    m.G = 256 / m.cg;
+    const int t = threadIdx.x;
+    if (t < m.G * m.cg) { m.c = m.cg0 + t % m.cg; m.slot = t / m.cg; }
+    else { m.c = -1; m.slot = 0; }
+    return m;
+}
+
+}  // namespace dsrl

@@ -1,0 +1,412 @@
+// Loss kernels of the training step (train_or_resume.py:116-119, 435-438): CrossEntropy(ignore_index), MSE and the
+// Feature-Affinity loss (models/losses/FALoss.py), plus the SGD update and the NaN check.  All HBM-bound or tiny.
+#include "common.h"
+#include <algorithm>
+
+namespace dsrl {
+
+__device__ inline double block_sum_d(double v, double* sh) {     // sh: 4 doubles
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---------------------------------------------------------------------------------------------- cross entropy
+// A block stages 256 pixels x C logits through LDS (contiguous global reads), one thread per pixel.
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld, const unsigned char* __restrict__ target, long long P, int C,
+                                                      int ignore_index, double* __restrict__ part) {
+    extern __shared__ float tile[];         // [256][C]
+    __shared__ double shd[4];
+    double loss = 0.0, cnt = 0.0;
+    for (long long p0 = (long long)blockIdx.x * 256; p0 < P; p0 += (long long)gridDim.x * 256) {
+        const int np = (int)min(256ll, P - p0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < np * C; t += 256) { const int r = t / C, c = t - r * C; tile[t] = logits[(p0 + r) * ld + c]; }
+        __syncthreads();
+        if ((int)threadIdx.x < np) {
+            const int tg = target[p0 + threadIdx.x];
+            if (tg != ignore_index) {
+                const float* v = tile + threadIdx.x * C;
+                float m = v[0];
+                for (int c = 1; c < C; ++c) m = fmaxf(m, v[c]);
+                float s = 0.f;
+                for (int c = 0; c < C; ++c) s += expf(v[c] - m);
+                loss += (double)(m + logf(s) - v[min(tg, C - 1)]);
+                cnt += 1.0;
+            }
+        }
+    }
+    const double l = block_sum_d(loss, shd);
+    const double n = block_sum_d(cnt, shd);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = l; part[2 * blockIdx.x + 1] = n; }
+}
+__global__ void ce_finalize_kernel(const double* __restrict__ part, int nb, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double l = 0, n = 0;
+        for (int i = 0; i < nb; ++i) { l += part[2 * i]; n += part[2 * i + 1]; }
+        out[0] = (float)(l / n);        // 0/0 = NaN when every pixel is ignored, as torch
+        out[1] = (float)n;
+    }
+}
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int ld, const unsigned char* __restrict__ target, long long P, int C,
+                                                      int ignore_index, const float* __restrict__ loss_out, const float* __restrict__ grad_out,
+                                                      float* __restrict__ dl, int lddl) {
+    extern __shared__ float tile[];
+    const float scale = grad_out[0] / loss_out[1];
+    for (long long p0 = (long long)blockIdx.x * 256; p0 < P; p0 += (long long)gridDim.x * 256) {
+        const int np = (int)min(256ll, P - p0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < np * C; t += 256) { const int r = t / C, c = t - r * C; tile[t] = logits[(p0 + r) * ld + c]; }
+        __syncthreads();
+        if ((int)threadIdx.x < np) {
+            const int tg = target[p0 + threadIdx.x];
+            float* v = tile + threadIdx.x * C;
+            if (tg != ignore_index) {
+                float m = v[0];
+                for (int c = 1; c < C; ++c) m = fmaxf(m, v[c]);
+                float s = 0.f;
+                for (int c = 0; c < C; ++c) s += expf(v[c] - m);
+                const float inv = 1.f / s;
+                for (int c = 0; c < C; ++c) v[c] = (expf(v[c] - m) * inv - (c == tg ? 1.f : 0.f)) * scale;
+            } else {
+                for (int c = 0; c < C; ++c) v[c] = 0.f;
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < np * C; t += 256) { const int r = t / C, c = t - r * C; dl[(p0 + r) * lddl + c] = tile[t]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- MSE
+__global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, double* __restrict__ part) {
+    __shared__ double shd[4];
+    double s = 0.0;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const float d = a[e] - b[e];
+        s += (double)(d * d);
+    }
+    const double t = block_sum_d(s, shd);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ void mse_finalize_kernel(const double* __restrict__ part, int nb, long long n, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < nb; ++i) s += part[i];
+        out[0] = (float)(s / (double)n);
+    }
+}
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, const float* __restrict__ grad_out,
+                                                       float* __restrict__ da) {
+    const float sc = 2.f * grad_out[0] / (float)n;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) da[e] = (a[e] - b[e]) * sc;
+}
+
+// ---------------------------------------------------------------------------------------------- FA loss
+// One block per (b,c) slice pair.  Per map: k x k average pooling -> X (h' x w'), G = X^T X in fp64, the dominant
+// eigenpair of G by repeated squaring (20 squarings = power 2^20: converged for any spectral gap a float can
+// resolve; the eigenvalue is then the Rayleigh quotient on the original G), sigma_1 = sqrt(lambda), S = G/lambda.
+constexpr int FA_MAXW = 32, FA_MAXH = 64, FA_SQUARINGS = 20;
+
+struct FaSmem {
+    double g0[FA_MAXW * FA_MAXW];
+    double ga[FA_MAXW * FA_MAXW];
+    double gb[FA_MAXW * FA_MAXW];
+    double red[4];
+    double vec[FA_MAXW];
+    float x[FA_MAXH * FA_MAXW];
+    float s1[FA_MAXW * FA_MAXW];
+    float s2[FA_MAXW * FA_MAXW];
+    float u[FA_MAXH];
+    float scal[4];
+};
+
+__device__ void fa_pool(const float* __restrict__ fm, long long sh_, long long sw_, int hp, int wp, int k, float* X) {
+    const float inv = 1.f / (float)(k * k);
+    for (int cell = threadIdx.x; cell < hp * wp; cell += 256) {
+        const int i = cell / wp, j = cell - i * wp;
+        float s = 0.f;
+        for (int r = 0; r < k; ++r)
+            for (int q = 0; q < k; ++q) s += fm[(long long)(i * k + r) * sh_ + (long long)(j * k + q) * sw_];
+        X[cell] = s * inv;
+    }
+    __syncthreads();
+}
+
+// leaves: sm.g0 = G, sm.vec = unit dominant eigenvector, sm.scal[0] = lambda (float), returns lambda (double, uniform)
+__device__ double fa_top_eig(FaSmem& sm, int hp, int wp) {
+    const int nn = wp * wp;
+    for (int e = threadIdx.x; e < nn; e += 256) {
+        const int a = e / wp, b = e - a * wp;
+        double s = 0.0;
+        for (int i = 0; i < hp; ++i) s += (double)sm.x[i * wp + a] * (double)sm.x[i * wp + b];
+        sm.g0[e] = s; sm.ga[e] = s;
+    }
+    __syncthreads();
+    double* cur = sm.ga; double* nxt = sm.gb;
+    for (int it = 0; it < FA_SQUARINGS; ++it) {
+        // normalise by the largest diagonal entry (G is PSD: max |entry| sits on the diagonal)
+        double mx = 0.0;
+        for (int a = 0; a < wp; ++a) mx = fmax(mx, cur[a * wp + a]);
+        if (!(mx > 0.0)) break;             // all-zero (or NaN) map: lambda = 0 -> S = 0/0 = NaN exactly like the reference
+        const double inv = 1.0 / mx;
+        for (int e = threadIdx.x; e < nn; e += 256) {
+            const int a = e / wp, b = e - a * wp;
+            double s = 0.0;
+            for (int q = 0; q < wp; ++q) s += (cur[a * wp + q] * inv) * (cur[q * wp + b] * inv);
+            nxt[e] = s;
+        }
+        __syncthreads();
+        double* t = cur; cur = nxt; nxt = t;
+    }
+    // dominant eigenvector ~ the column of G^(2^s) with the largest diagonal entry
+    int best = 0; double bd = -1.0;
+    for (int a = 0; a < wp; ++a) { const double d = cur[a * wp + a]; if (d > bd) { bd = d; best = a; } }
+    double nrm = 0.0;
+    for (int a = 0; a < wp; ++a) nrm += cur[a * wp + best] * cur[a * wp + best];
+    nrm = sqrt(nrm);
+    if ((int)threadIdx.x < wp) sm.vec[threadIdx.x] = nrm > 0.0 ? cur[threadIdx.x * wp + best] / nrm : (threadIdx.x == 0 ? 1.0 : 0.0);
+    __syncthreads();
+    double lam = 0.0;                        // Rayleigh quotient on the original G (every thread computes it: wp^2 <= 1024 fp64 FMAs)
+    for (int a = 0; a < wp; ++a) {
+        double s = 0.0;
+        for (int b = 0; b < wp; ++b) s += sm.g0[a * wp + b] * sm.vec[b];
+        lam += sm.vec[a] * s;
+    }
+    return lam;
+}
+
+__global__ __launch_bounds__(256) void fa_fwd_kernel(const float* __restrict__ fm1, const float* __restrict__ fm2, int C, int hp, int wp, int k,
+                                                      long long sb, long long sc, long long sh_, long long sw_, int reduction,
+                                                      float* __restrict__ out_none, float* __restrict__ saved, long long saved_stride, double* __restrict__ part) {
+    __shared__ FaSmem sm;
+    const int slice = blockIdx.x, b = slice / C, c = slice - b * C;
+    const int n = wp * wp;
+    float* sv = saved + (long long)slice * saved_stride;      // [S1 n][S2 n][sigma1, sigma2][u1 hp][v1 wp][u2 hp][v2 wp]
+    for (int map = 0; map < 2; ++map) {
+        const float* fm = (map == 0 ? fm1 : fm2) + b * sb + c * sc;
+        fa_pool(fm, sh_, sw_, hp, wp, k, sm.x);
+        const double lam = fa_top_eig(sm, hp, wp);
+        const double sigma = sqrt(lam);
+        float* S = map == 0 ? sm.s1 : sm.s2;
+        for (int e = threadIdx.x; e < n; e += 256) { const float v = (float)(sm.g0[e] / lam); S[e] = v; sv[map * n + e] = v; }
+        float* uv = sv + 2 * n + 2 + map * (hp + wp);
+        for (int i = threadIdx.x; i < hp; i += 256) {
+            double s = 0.0;
+            for (int a = 0; a < wp; ++a) s += (double)sm.x[i * wp + a] * sm.vec[a];
+            uv[i] = (float)(s / sigma);
+        }
+        if ((int)threadIdx.x < wp) uv[hp + threadIdx.x] = (float)sm.vec[threadIdx.x];
+        if (threadIdx.x == 0) sv[2 * n + map] = (float)sigma;
+        __syncthreads();
+    }
+    // all pairs |S1_i - S2_j|
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float a = sm.s1[i];
+        float s = 0.f;
+        if (reduction == 2) {
+            float* o = out_none + ((long long)slice * n + i) * n;
+            for (int j = 0; j < n; ++j) { const float d = fabsf(a - sm.s2[j]); o[j] = d; }
+        } else {
+            for (int j = 0; j < n; ++j) s += fabsf(a - sm.s2[j]);
+        }
+        acc += (double)s;
+    }
+    const double tot = block_sum_d(acc, sm.red);
+    if (threadIdx.x == 0) part[slice] = tot;
+}
+__global__ void fa_finalize_kernel(const double* __restrict__ part, int nslices, int n, int reduction, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < nslices; ++i) s += part[i];
+        out[0] = (float)(reduction == 0 ? s / ((double)nslices * n * n) : s);
+    }
+}
+
+__global__ __launch_bounds__(256) void fa_bwd_kernel(const float* __restrict__ fm1, const float* __restrict__ fm2, int nslices, int C, int H, int W, int hp, int wp, int k,
+                                                      long long sb, long long sc, long long sh_, long long sw_, int reduction,
+                                                      const float* __restrict__ grad_out, const float* __restrict__ saved, long long saved_stride,
+                                                      float* __restrict__ d1, float* __restrict__ d2) {
+    __shared__ float X[FA_MAXH * FA_MAXW];
+    __shared__ float S1[FA_MAXW * FA_MAXW], S2[FA_MAXW * FA_MAXW], dS[FA_MAXW * FA_MAXW];
+    __shared__ float dXn[FA_MAXH * FA_MAXW];
+    __shared__ double red[4];
+    const int slice = blockIdx.x, b = slice / C, c = slice - b * C;
+    const int n = wp * wp;
+    const float* sv = saved + (long long)slice * saved_stride;
+    for (int e = threadIdx.x; e < n; e += 256) { S1[e] = sv[e]; S2[e] = sv[n + e]; }
+    __syncthreads();
+    const float scale = grad_out[0] * (reduction == 0 ? (float)(1.0 / ((double)nslices * n * n)) : 1.f);
+    for (int map = 0; map < 2; ++map) {
+        // dS_map
+        for (int e = threadIdx.x; e < n; e += 256) {
+            int cnt = 0;
+            if (map == 0) { const float a = S1[e]; for (int j = 0; j < n; ++j) { const float d = a - S2[j]; cnt += (d > 0.f) - (d < 0.f); } }
+            else { const float v = S2[e]; for (int i = 0; i < n; ++i) { const float d = S1[i] - v; cnt -= (d > 0.f) - (d < 0.f); } }
+            dS[e] = scale * (float)cnt;
+        }
+        const float* fm = (map == 0 ? fm1 : fm2) + b * sb + c * sc;
+        fa_pool(fm, sh_, sw_, hp, wp, k, X);        // ends with a barrier (dS complete too)
+        const float sigma = sv[2 * n + map];
+        const float* u1 = sv + 2 * n + 2 + map * (hp + wp);
+        const float* v1 = u1 + hp;
+        // dXn = (X/sigma) (dS + dS^T);  dot = sum dXn * X
+        double dot = 0.0;
+        for (int e = threadIdx.x; e < hp * wp; e += 256) {
+            const int i = e / wp, a = e - i * wp;
+            float s = 0.f;
+            for (int q = 0; q < wp; ++q) s += X[i * wp + q] * (dS[q * wp + a] + dS[a * wp + q]);
+            s /= sigma;
+            dXn[e] = s;
+            dot += (double)s * (double)X[e];
+        }
+        const double tot = block_sum_d(dot, red);
+        const float dsigma = (float)(-tot / ((double)sigma * (double)sigma));
+        float* dst = (map == 0 ? d1 : d2) + (long long)slice * H * W;
+        const float invk2 = 1.f / (float)(k * k);
+        for (int e = threadIdx.x; e < H * W; e += 256) {
+            const int h = e / W, w = e - h * W;
+            const int i = h / k, a = w / k;
+            float v = 0.f;
+            if (i < hp && a < wp) v = (dXn[i * wp + a] / sigma + dsigma * u1[i] * v1[a]) * invk2;
+            dst[e] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- SGD, NaN check
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long long n,
+                                                   float lr, float mom, float wd, float gscale) {
+    const long long n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p); const float4* g4 = reinterpret_cast<const float4*>(g); float4* b4 = reinterpret_cast<float4*>(buf);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
+        float4 pv = p4[e]; const float4 gv = g4[e]; float4 bv = b4[e];
+        bv.x = mom * bv.x + fmaf(wd, pv.x, gv.x * gscale); pv.x -= lr * bv.x;
+        bv.y = mom * bv.y + fmaf(wd, pv.y, gv.y * gscale); pv.y -= lr * bv.y;
+        bv.z = mom * bv.z + fmaf(wd, pv.z, gv.z * gscale); pv.z -= lr * bv.z;
+        bv.w = mom * bv.w + fmaf(wd, pv.w, gv.w * gscale); pv.w -= lr * bv.w;
+        p4[e] = pv; b4[e] = bv;
+    }
+    for (long long e = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const float d = fmaf(wd, p[e], g[e] * gscale);
+        const float bv = mom * buf[e] + d;
+        buf[e] = bv; p[e] -= lr * bv;
+    }
+}
+__global__ __launch_bounds__(256) void nan_check_kernel(const float* __restrict__ x, long long n, int* __restrict__ flag) {
+    bool bad = false;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) bad |= (x[e] != x[e]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+static int loss_blocks(long long work) { return (int)std::max<long long>(1, std::min<long long>(1024, ceil_div(work, 256))); }
+
+}  // namespace dsrl
+using namespace dsrl;
+
+extern "C" size_t dsrl_ce_workspace_bytes(int64_t P) { return (size_t)2 * loss_blocks(P) * sizeof(double); }
+extern "C" int dsrl_ce_fwd(const float* logits, int ld, const uint8_t* target, int64_t P, int C, int ignore_index, float* loss_out,
+                           void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_REQUIRE(logits && target && loss_out && ws && P > 0 && C > 0 && C <= 60 && ld >= C, DSRL_E_BADARG, "ce_fwd: bad arguments (C=%d)", C);
+    DSRL_REQUIRE(ws_bytes >= dsrl_ce_workspace_bytes(P), DSRL_E_WORKSPACE, "ce_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const int nb = loss_blocks(P);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), (size_t)256 * C * sizeof(float), st, logits, ld, target, (long long)P, C, ignore_index, (double*)ws);
+    if (int e = launch_status("ce_fwd_kernel")) return e;
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, loss_out);
+    return launch_status("ce_finalize_kernel");
+}
+extern "C" int dsrl_ce_bwd(const float* logits, int ld, const uint8_t* target, int64_t P, int C, int ignore_index, const float* loss_out,
+                           const float* grad_out, float* dlogits, int lddl, dsrl_stream_t stream) {
+    DSRL_REQUIRE(logits && target && loss_out && grad_out && dlogits && P > 0 && C > 0 && C <= 60 && ld >= C && lddl >= C, DSRL_E_BADARG, "ce_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)std::min<long long>(ceil_div(P, 256), 8192)), dim3(256), (size_t)256 * C * sizeof(float), st,
+                       logits, ld, target, (long long)P, C, ignore_index, loss_out, grad_out, dlogits, lddl);
+    return launch_status("ce_bwd_kernel");
+}
+
+extern "C" size_t dsrl_mse_workspace_bytes(int64_t n) { return (size_t)loss_blocks(n / 4 + 1) * sizeof(double); }
+extern "C" int dsrl_mse_fwd(const float* a, const float* b, int64_t n, float* loss_out, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_REQUIRE(a && b && loss_out && ws && n > 0, DSRL_E_BADARG, "mse_fwd: bad arguments");
+    DSRL_REQUIRE(ws_bytes >= dsrl_mse_workspace_bytes(n), DSRL_E_WORKSPACE, "mse_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const int nb = loss_blocks(n / 4 + 1);
+    hipLaunchKernelGGL(mse_fwd_kernel, dim3(nb), dim3(256), 0, st, a, b, (long long)n, (double*)ws);
+    if (int e = launch_status("mse_fwd_kernel")) return e;
+    hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, (long long)n, loss_out);
+    return launch_status("mse_finalize_kernel");
+}
+extern "C" int dsrl_mse_bwd(const float* a, const float* b, int64_t n, const float* grad_out, float* da, dsrl_stream_t stream) {
+    DSRL_REQUIRE(a && b && grad_out && da && n > 0, DSRL_E_BADARG, "mse_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 1024), 8192)), dim3(256), 0, st, a, b, (long long)n, grad_out, da);
+    return launch_status("mse_bwd_kernel");
+}
+
+static int fa_dims(int H, int W, int k, int& hp, int& wp) {
+    DSRL_REQUIRE(k > 0 && H >= k && W >= k, DSRL_E_BADARG, "fa_loss: subsample factor %d larger than the %dx%d map", k, H, W);
+    hp = H / k; wp = W / k;
+    DSRL_REQUIRE(hp <= FA_MAXH && wp <= FA_MAXW, DSRL_E_UNSUPPORTED, "fa_loss: pooled map %dx%d exceeds %dx%d", hp, wp, FA_MAXH, FA_MAXW);
+    return DSRL_OK;
+}
+static long long fa_saved_stride(int hp, int wp) { return 2ll * wp * wp + 2 + 2ll * (hp + wp); }
+extern "C" size_t dsrl_fa_saved_floats(int B, int C, int H, int W, int k) {
+    if (k <= 0) return 0;
+    return (size_t)B * C * fa_saved_stride(H / k, W / k);
+}
+extern "C" size_t dsrl_fa_workspace_bytes(int B, int C, int H, int W, int k) { (void)H; (void)W; (void)k; return (size_t)B * C * sizeof(double); }
+
+extern "C" int dsrl_fa_fwd(const float* fm1, const float* fm2, int B, int C, int H, int W, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                           int k, int reduction, float* out, float* saved, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_REQUIRE(fm1 && fm2 && out && saved && ws && B > 0 && C > 0 && reduction >= 0 && reduction <= 2, DSRL_E_BADARG, "fa_fwd: bad arguments");
+    int hp, wp;
+    if (int e = fa_dims(H, W, k, hp, wp)) return e;
+    DSRL_REQUIRE(ws_bytes >= dsrl_fa_workspace_bytes(B, C, H, W, k), DSRL_E_WORKSPACE, "fa_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(fa_fwd_kernel, dim3(B * C), dim3(256), 0, st, fm1, fm2, C, hp, wp, k, (long long)sb, (long long)sc, (long long)sh, (long long)sw, reduction,
+                       out, saved, fa_saved_stride(hp, wp), (double*)ws);
+    if (int e = launch_status("fa_fwd_kernel")) return e;
+    if (reduction != 2) {
+        hipLaunchKernelGGL(fa_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, B * C, wp * wp, reduction, out);
+        return launch_status("fa_finalize_kernel");
+    }
+    return DSRL_OK;
+}
+extern "C" int dsrl_fa_bwd(const float* fm1, const float* fm2, int B, int C, int H, int W, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                           int k, int reduction, const float* grad_out, const float* saved, float* d1, float* d2, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    (void)ws; (void)ws_bytes;
+    DSRL_REQUIRE(fm1 && fm2 && grad_out && saved && d1 && d2 && B > 0 && C > 0, DSRL_E_BADARG, "fa_bwd: bad arguments");
+    DSRL_REQUIRE(reduction == 0 || reduction == 1, DSRL_E_UNSUPPORTED, "fa_bwd: only 'mean' and 'sum' reductions have a backward kernel");
+    int hp, wp;
+    if (int e = fa_dims(H, W, k, hp, wp)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(fa_bwd_kernel, dim3(B * C), dim3(256), 0, st, fm1, fm2, B * C, C, H, W, hp, wp, k, (long long)sb, (long long)sc, (long long)sh, (long long)sw,
+                       reduction, grad_out, saved, fa_saved_stride(hp, wp), d1, d2);
+    return launch_status("fa_bwd_kernel");
+}
+
+extern "C" int dsrl_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float weight_decay, float grad_scale, dsrl_stream_t stream) {
+    DSRL_REQUIRE(p && g && buf && n > 0, DSRL_E_BADARG, "sgd_step: bad arguments");
+    DSRL_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)buf % 16) == 0, DSRL_E_BADARG, "sgd_step: arenas must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 1024), 4096)), dim3(256), 0, st, p, g, buf, (long long)n, lr, momentum, weight_decay, grad_scale);
+    return launch_status("sgd_kernel");
+}
+extern "C" int dsrl_nan_check(const float* x, int64_t n, int* flag, dsrl_stream_t stream) {
+    DSRL_REQUIRE(x && flag && n > 0, DSRL_E_BADARG, "nan_check: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(nan_check_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 2048), 4096)), dim3(256), 0, st, x, (long long)n, flag);
+    return launch_status("nan_check_kernel");
+}

@@ -1,0 +1,517 @@
+// Memory-bound spatial operators on pixel-major fp32 tensors: align-corners bilinear resize, global average /
+// 3x3s2 max pooling, ConvTranspose2d(k2,s2), PixelShuffle, the 1x1 stride-s single-output conv of the feature
+// transformers and the NCHW->pixel-major import.  Consecutive lanes always touch consecutive channels / pixels.
+#include "common.h"
+#include <algorithm>
+
+namespace dsrl {
+
+static unsigned flat_grid(long long total, int per_block = 256, int cap = 8192) {
+    return (unsigned)std::max<long long>(1, std::min<long long>(ceil_div(total, per_block), cap));
+}
+
+// ---------------------------------------------------------------------------------------------- bilinear
+// torch upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1) evaluated in fp32.
+__device__ inline void ac_src(int dst, float scale, int n_in, int& i0, int& ip, float& l1) {
+    const float r = scale * (float)dst;
+    i0 = min((int)r, n_in - 1);
+    ip = (i0 < n_in - 1) ? 1 : 0;
+    l1 = r - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                            int N, int H, int W, int C, int Ho, int Wo, float sh, float sw) {
+    const long long total = (long long)N * Ho * Wo * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long long pix = e / C;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho); const int n = (int)(pix / Ho);
+        int h0, hp, w0, wp; float lh, lw;
+        ac_src(ho, sh, H, h0, hp, lh); ac_src(wo, sw, W, w0, wp, lw);
+        const float* b = x + ((long long)(n * H + h0) * W + w0) * ldx + c;
+        const float x00 = b[0], x01 = b[(long long)wp * ldx], x10 = b[(long long)hp * W * ldx], x11 = b[((long long)hp * W + wp) * ldx];
+        const float v = (1.f - lh) * ((1.f - lw) * x00 + lw * x01) + lh * ((1.f - lw) * x10 + lw * x11);
+        y[((long long)(n * Ho + ho) * Wo + wo) * ldy + c] = v;
+    }
+}
+
+__device__ inline float ac_weight(int dst, float scale, int n_in, int src) {
+    int i0, ip; float l1;
+    ac_src(dst, scale, n_in, i0, ip, l1);
+    float w = 0.f;
+    if (i0 == src) w += 1.f - l1;
+    if (i0 + ip == src) w += l1;
+    return w;
+}
+__device__ inline void ac_range(int src, float scale, int n_out, int& lo, int& hi) {
+    if (scale <= 0.f) { lo = 0; hi = n_out - 1; return; }
+    lo = max(0, (int)floorf((float)(src - 1) / scale) - 1);
+    hi = min(n_out - 1, (int)ceilf((float)(src + 1) / scale) + 1);
+}
+
+// gather form of the backward: deterministic, no atomics
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
+                                                            int N, int H, int W, int C, int Ho, int Wo, float sh, float sw) {
+    const long long total = (long long)N * H * W * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long long pix = e / C;
+        const int w = (int)(pix % W); pix /= W;
+        const int h = (int)(pix % H); const int n = (int)(pix / H);
+        int hlo, hhi, wlo, whi;
+        ac_range(h, sh, Ho, hlo, hhi); ac_range(w, sw, Wo, wlo, whi);
+        float acc = 0.f;
+        for (int ho = hlo; ho <= hhi; ++ho) {
+            const float wh = ac_weight(ho, sh, H, h);
+            if (wh == 0.f) continue;
+            float row = 0.f;
+            const float* r = dy + ((long long)(n * Ho + ho) * Wo) * lddy + c;
+            for (int wo = wlo; wo <= whi; ++wo) {
+                const float ww = ac_weight(wo, sw, W, w);
+                if (ww != 0.f) row += ww * r[(long long)wo * lddy];
+            }
+            acc += wh * row;
+        }
+        dx[((long long)(n * H + h) * W + w) * lddx + c] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- pools
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int HW, int C) {
+    __shared__ float sh[256];
+    const ChanMap m = chan_map(C, blockIdx.y);
+    const int n = blockIdx.x;
+    float s = 0.f;
+    if (m.c >= 0) for (int p = m.slot; p < HW; p += m.G) s += x[((long long)n * HW + p) * ldx + m.c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (m.c >= 0 && m.slot == 0) {
+        for (int g = 1; g < m.G; ++g) s += sh[g * m.cg + (m.c - m.cg0)];
+        y[(long long)n * C + m.c] = s / (float)HW;
+    }
+}
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int lddx, int N, int HW, int C) {
+    const long long total = (long long)N * HW * C;
+    const float inv = 1.f / (float)HW;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C); const long long p = e / C; const int n = (int)(p / HW);
+        dx[p * lddx + c] = dy[(long long)n * C + c] * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+    const long long total = (long long)N * Ho * Wo * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long long pix = e / C;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho); const int n = (int)(pix / Ho);
+        float best = -INFINITY;
+        for (int r = 0; r < 3; ++r) {
+            const int h = 2 * ho - 1 + r;
+            if (h < 0 || h >= H) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int w = 2 * wo - 1 + s;
+                if (w < 0 || w >= W) continue;
+                const float v = x[((long long)(n * H + h) * W + w) * C + c];
+                if (v > best || v != v) best = v;
+            }
+        }
+        y[e] = best;
+    }
+}
+// the gradient of a window goes to its first maximum in scan order (torch max_pool2d)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                           int N, int H, int W, int C, int Ho, int Wo) {
+    const long long total = (long long)N * H * W * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long long pix = e / C;
+        const int w = (int)(pix % W); pix /= W;
+        const int h = (int)(pix % H); const int n = (int)(pix / H);
+        float acc = 0.f;
+        for (int ho = max(0, h / 2); ho <= min(Ho - 1, (h + 1) / 2); ++ho)
+            for (int wo = max(0, w / 2); wo <= min(Wo - 1, (w + 1) / 2); ++wo) {
+                float best = -INFINITY; int bh = -1, bw = -1;
+                for (int r = 0; r < 3; ++r) {
+                    const int hh = 2 * ho - 1 + r;
+                    if (hh < 0 || hh >= H) continue;
+                    for (int s = 0; s < 3; ++s) {
+                        const int ww = 2 * wo - 1 + s;
+                        if (ww < 0 || ww >= W) continue;
+                        const float v = x[((long long)(n * H + hh) * W + ww) * C + c];
+                        if (v > best || v != v) { best = v; bh = hh; bw = ww; }
+                    }
+                }
+                if (bh == h && bw == w) acc += dy[((long long)(n * Ho + ho) * Wo + wo) * C + c];
+            }
+        dx[e] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- ConvTranspose2d k2 s2
+// One block = 256 consecutive output pixels of one output row; the input row segment, the two filter
+// slices of that row parity and the output tile go through LDS so that all global traffic is contiguous.
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int N, int H, int W) {
+    constexpr int COP = (CO + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) float wsh[2][CI][COP];
+    __shared__ float xs[128 * CI];
+    __shared__ float ys[256 * CO];
+    const int Wo = 2 * W;
+    const int row = blockIdx.y;                 // n*Ho + ho
+    const int ho = row % (2 * H), n = row / (2 * H);
+    const int i = ho & 1, h = ho >> 1;
+    const int wo0 = blockIdx.x * 256;
+    const int npix = min(256, Wo - wo0), nin = (npix + 1) / 2;
+    for (int t = threadIdx.x; t < 2 * CI * COP; t += 256) {
+        const int co = t % COP, ci = (t / COP) % CI, j = t / (COP * CI);
+        wsh[j][ci][co] = co < CO ? w[((ci * CO + co) * 2 + i) * 2 + j] : 0.f;
+    }
+    const float* xrow = x + ((long long)(n * H + h) * W + wo0 / 2) * CI;
+    for (int t = threadIdx.x; t < nin * CI; t += 256) xs[t] = xrow[t];
+    __syncthreads();
+    if ((int)threadIdx.x < npix) {
+        const int j = threadIdx.x & 1;
+        float xin[CI];
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) xin[ci] = xs[(threadIdx.x >> 1) * CI + ci];
+        float acc[COP];
+#pragma unroll
+        for (int co = 0; co < COP; ++co) acc[co] = (bias != nullptr && co < CO) ? bias[co] : 0.f;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+#pragma unroll
+            for (int q = 0; q < COP / 4; ++q) {
+                const float4 wv = *reinterpret_cast<const float4*>(&wsh[j][ci][q * 4]);
+                acc[q * 4 + 0] = fmaf(xin[ci], wv.x, acc[q * 4 + 0]);
+                acc[q * 4 + 1] = fmaf(xin[ci], wv.y, acc[q * 4 + 1]);
+                acc[q * 4 + 2] = fmaf(xin[ci], wv.z, acc[q * 4 + 2]);
+                acc[q * 4 + 3] = fmaf(xin[ci], wv.w, acc[q * 4 + 3]);
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < CO; ++co) ys[threadIdx.x * CO + co] = acc[co];
+    }
+    __syncthreads();
+    float* yrow = y + ((long long)row * Wo + wo0) * CO;
+    for (int t = threadIdx.x; t < npix * CO; t += 256) yrow[t] = ys[t];
+}
+
+// dx[n,h,w,ci] = sum_{i,j,co} dy[n,2h+i,2w+j,co] * w[ci,co,i,j]: one block = 128 input pixels of one row.
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void convt2x2_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                           int N, int H, int W) {
+    constexpr int CIP = (CI + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) float wsh[4][CO][CIP];     // [i*2+j][co][ci]
+    __shared__ float dys[2][256 * CO];
+    __shared__ float part[2][128 * CI];
+    const int row = blockIdx.y;                 // n*H + h
+    const int w0 = blockIdx.x * 128;
+    const int npx = min(128, W - w0);
+    for (int t = threadIdx.x; t < 4 * CO * CIP; t += 256) {
+        const int ci = t % CIP, co = (t / CIP) % CO, ij = t / (CIP * CO);
+        wsh[ij][co][ci] = ci < CI ? w[(ci * CO + co) * 4 + ij] : 0.f;
+    }
+    const int n = row / H, h = row % H;
+    for (int i = 0; i < 2; ++i) {
+        const float* r = dy + (((long long)(n * 2 * H + 2 * h + i)) * (2 * W) + 2 * w0) * CO;
+        for (int t = threadIdx.x; t < 2 * npx * CO; t += 256) dys[i][t] = r[t];
+    }
+    __syncthreads();
+    const int px = threadIdx.x & 127, i = threadIdx.x >> 7;
+    if (px < npx) {
+        float acc[CIP];
+#pragma unroll
+        for (int ci = 0; ci < CIP; ++ci) acc[ci] = 0.f;
+        for (int j = 0; j < 2; ++j)
+            for (int co = 0; co < CO; ++co) {
+                const float g = dys[i][(2 * px + j) * CO + co];
+#pragma unroll
+                for (int q = 0; q < CIP / 4; ++q) {
+                    const float4 wv = *reinterpret_cast<const float4*>(&wsh[i * 2 + j][co][q * 4]);
+                    acc[q * 4 + 0] = fmaf(g, wv.x, acc[q * 4 + 0]);
+                    acc[q * 4 + 1] = fmaf(g, wv.y, acc[q * 4 + 1]);
+                    acc[q * 4 + 2] = fmaf(g, wv.z, acc[q * 4 + 2]);
+                    acc[q * 4 + 3] = fmaf(g, wv.w, acc[q * 4 + 3]);
+                }
+            }
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) part[i][px * CI + ci] = acc[ci];
+    }
+    __syncthreads();
+    float* o = dx + ((long long)row * W + w0) * CI;
+    for (int t = threadIdx.x; t < npx * CI; t += 256) o[t] = part[0][t] + part[1][t];
+}
+
+// dw[ci,co,i,j] = sum_pixels x[p,ci] * dy[p@(i,j),co]; db[co] = sum dy.  Each block walks row segments of 64 input
+// pixels, every thread owns a fixed set of the CI*CO*4 (+CO) outputs; block partials are merged by a second kernel.
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void convt2x2_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                           int N, int H, int W, int nseg_per_row, long long nseg) {
+    constexpr int NOUT = CI * CO * 4, PER = (NOUT + CO + 255) / 256, TP = 64;
+    __shared__ float xs[TP * CI];
+    __shared__ float dys[TP * 4 * CO];      // [px][i][j][co]
+    float acc[PER];
+    int oci[PER], ocol[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        acc[k] = 0.f;
+        const int o = threadIdx.x + 256 * k;
+        if (o < NOUT) { oci[k] = o / (4 * CO); ocol[k] = o % (4 * CO); }       // col = (i*2+j)*CO + co
+        else if (o < NOUT + CO) { oci[k] = -1; ocol[k] = o - NOUT; }            // bias gradient for channel co
+        else { oci[k] = -2; ocol[k] = 0; }
+    }
+    for (long long seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const long long row = seg / nseg_per_row;       // n*H + h
+        const int w0 = (int)(seg % nseg_per_row) * TP;
+        const int npx = min(TP, W - w0);
+        const int n = (int)(row / H), h = (int)(row % H);
+        __syncthreads();
+        const float* xr = x + (row * W + w0) * CI;
+        for (int t = threadIdx.x; t < npx * CI; t += 256) xs[t] = xr[t];
+        for (int i = 0; i < 2; ++i) {
+            const float* r = dy + (((long long)(n * 2 * H + 2 * h + i)) * (2 * W) + 2 * w0) * CO;
+            for (int t = threadIdx.x; t < 2 * npx * CO; t += 256) {
+                const int px = t / (2 * CO), rem = t % (2 * CO);
+                dys[(px * 2 + i) * 2 * CO + rem] = r[t];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (oci[k] >= 0) {
+                float s = 0.f;
+                for (int px = 0; px < npx; ++px) s = fmaf(xs[px * CI + oci[k]], dys[px * 4 * CO + ocol[k]], s);
+                acc[k] += s;
+            } else if (oci[k] == -1) {
+                float s = 0.f;
+                for (int px = 0; px < npx; ++px)
+                    for (int ij = 0; ij < 4; ++ij) s += dys[px * 4 * CO + ij * CO + ocol[k]];
+                acc[k] += s;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int o = threadIdx.x + 256 * k;
+        if (o < NOUT + CO) part[(long long)blockIdx.x * (NOUT + CO) + o] = acc[k];
+    }
+}
+template <int CI, int CO>
+__global__ void convt2x2_dw_finalize_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ dw, float* __restrict__ db) {
+    constexpr int NOUT = CI * CO * 4;
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= NOUT + CO) return;
+    double s = 0;
+    for (int b = 0; b < nblocks; ++b) s += part[(long long)b * (NOUT + CO) + o];
+    if (o < NOUT) {
+        const int ci = o / (4 * CO), col = o % (4 * CO), ij = col / CO, co = col % CO;
+        dw[(ci * CO + co) * 4 + ij] = (float)s;
+    } else if (db) db[o - NOUT] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------- PixelShuffle
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H, int W, int c, int r, int inverse) {
+    // forward: dst (N,H*r,W*r,c) <- src (N,H,W,c*r*r); inverse: dst (N,H,W,c*r*r) <- src (N,H*r,W*r,c)
+    const long long total = (long long)N * H * W * c * r * r;
+    const int Wr = W * r, Hr = H * r, C = c * r * r;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        // e enumerates the (N,Hr,Wr,c) tensor
+        const int ch = (int)(e % c);
+        long long pix = e / c;
+        const int wr = (int)(pix % Wr); pix /= Wr;
+        const int hr = (int)(pix % Hr); const int n = (int)(pix / Hr);
+        const int h = hr / r, i = hr % r, w = wr / r, j = wr % r;
+        const long long lo = ((long long)(n * H + h) * W + w) * C + ch * r * r + i * r + j;
+        if (inverse) dst[lo] = src[e]; else dst[e] = src[lo];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- 1x1 stride-s, single output
+__global__ __launch_bounds__(256) void pointwise_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                             int N, int H, int W, int C, int s, int Ho, int Wo) {
+    const long long total = (long long)N * Ho * Wo;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int wo = (int)(e % Wo); const long long t = e / Wo; const int ho = (int)(t % Ho), n = (int)(t / Ho);
+        const float* p = x + ((long long)(n * H + ho * s) * W + wo * s) * C;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc = fmaf(p[c], w[c], acc);
+        y[e] = acc;
+    }
+}
+// dx on the stride grid (+= when accumulate), per-block partial dw in part[block][C]
+__global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+                                                             float* __restrict__ dx, float* __restrict__ part, int accumulate,
+                                                             int N, int H, int W, int C, int s, int Ho, int Wo) {
+    extern __shared__ float sh[];           // [256][C] would be large; reduce channel by channel through [256]
+    const long long total = (long long)N * Ho * Wo;
+    for (int c = 0; c < C; ++c) {
+        float acc = 0.f;
+        const float wc = w[c];
+        for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+            const int wo = (int)(e % Wo); const long long t = e / Wo; const int ho = (int)(t % Ho), n = (int)(t / Ho);
+            const long long o = ((long long)(n * H + ho * s) * W + wo * s) * C + c;
+            const float g = dy[e];
+            acc = fmaf(g, x[o], acc);
+            if (accumulate) dx[o] += g * wc; else dx[o] = g * wc;
+        }
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) part[(long long)blockIdx.x * C + c] = sh[0];
+        __syncthreads();
+    }
+}
+__global__ void pointwise_dw_finalize_kernel(const float* __restrict__ part, int nblocks, int C, float* __restrict__ dw) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int b = 0; b < nblocks; ++b) s += part[(long long)b * C + c];
+    dw[c] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------- NCHW -> pixel-major
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int HW, int Cpad) {
+    const long long total = (long long)N * HW;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long n = e / HW, p = e - n * HW;
+        for (int c = 0; c < Cpad; ++c) y[e * Cpad + c] = c < C ? x[(n * C + c) * HW + p] : 0.f;
+    }
+}
+
+}  // namespace dsrl
+using namespace dsrl;
+
+#define DSRL_PROLOGUE(cond, name)                                                   \
+    DSRL_REQUIRE(cond, DSRL_E_BADARG, name ": bad arguments");                      \
+    hipStream_t st = (hipStream_t)stream;                                           \
+    if (int e_ = bind_stream_device(st)) return e_;
+
+static float ac_scale(int n_in, int n_out) { return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f; }
+
+extern "C" int dsrl_bilinear_ac_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int Ho, int Wo, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && ldx >= C && ldy >= C, "bilinear_ac_fwd")
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(flat_grid((long long)N * Ho * Wo * C)), dim3(256), 0, st, x, ldx, y, ldy, N, H, W, C, Ho, Wo, ac_scale(H, Ho), ac_scale(W, Wo));
+    return launch_status("bilinear_fwd_kernel");
+}
+extern "C" int dsrl_bilinear_ac_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int Ho, int Wo, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && lddy >= C && lddx >= C, "bilinear_ac_bwd")
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(flat_grid((long long)N * H * W * C)), dim3(256), 0, st, dy, lddy, dx, lddx, N, H, W, C, Ho, Wo, ac_scale(H, Ho), ac_scale(W, Wo));
+    return launch_status("bilinear_bwd_kernel");
+}
+extern "C" int dsrl_global_avgpool_fwd(const float* x, int ldx, float* y, int N, int HW, int C, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(x && y && N > 0 && HW > 0 && C > 0 && ldx >= C, "global_avgpool_fwd")
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(N, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ldx, y, HW, C);
+    return launch_status("gap_fwd_kernel");
+}
+extern "C" int dsrl_global_avgpool_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(dy && dx && N > 0 && HW > 0 && C > 0 && lddx >= C, "global_avgpool_bwd")
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(flat_grid((long long)N * HW * C)), dim3(256), 0, st, dy, dx, lddx, N, HW, C);
+    return launch_status("gap_bwd_kernel");
+}
+extern "C" int dsrl_maxpool3x3s2_fwd(const float* x, float* y, int N, int H, int W, int C, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "maxpool3x3s2_fwd")
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(flat_grid((long long)N * Ho * Wo * C)), dim3(256), 0, st, x, y, N, H, W, C, Ho, Wo);
+    return launch_status("maxpool_fwd_kernel");
+}
+extern "C" int dsrl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool3x3s2_bwd")
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(flat_grid((long long)N * H * W * C)), dim3(256), 0, st, x, dy, dx, N, H, W, C, Ho, Wo);
+    return launch_status("maxpool_bwd_kernel");
+}
+
+// ConvTranspose2d channel counts instantiated: the reference uses NUM_CLASSES -> NUM_CLASSES (19, Cityscapes).
+#define DSRL_CONVT_DISPATCH(CI_, CO_, BODY)                         \
+    if (Cin == CI_ && Cout == CO_) { constexpr int CI = CI_, CO = CO_; BODY }
+
+extern "C" int dsrl_convt2x2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(x && w && y && N > 0 && H > 0 && W > 0, "convt2x2_fwd")
+    dim3 grid((unsigned)ceil_div(2 * W, 256), (unsigned)(N * 2 * H));
+    DSRL_CONVT_DISPATCH(19, 19, hipLaunchKernelGGL((convt2x2_fwd_kernel<CI, CO>), grid, dim3(256), 0, st, x, w, bias, y, N, H, W); return launch_status("convt2x2_fwd_kernel");)
+    DSRL_CONVT_DISPATCH(8, 8, hipLaunchKernelGGL((convt2x2_fwd_kernel<CI, CO>), grid, dim3(256), 0, st, x, w, bias, y, N, H, W); return launch_status("convt2x2_fwd_kernel");)
+    set_error("convt2x2_fwd: channel counts %d->%d not instantiated (19->19, 8->8)", Cin, Cout);
+    return DSRL_E_UNSUPPORTED;
+}
+static int convt_dw_blocks(int N, int H, int W) { return (int)std::min<long long>(1024, (long long)N * H * ceil_div(W, 64)); }
+extern "C" size_t dsrl_convt2x2_bwd_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+    return (size_t)convt_dw_blocks(N, H, W) * (Cin * Cout * 4 + Cout) * sizeof(float);
+}
+extern "C" int dsrl_convt2x2_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dbias,
+                                 int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(x && w && dy && dx && dw && ws && N > 0 && H > 0 && W > 0, "convt2x2_bwd")
+    DSRL_REQUIRE(ws_bytes >= dsrl_convt2x2_bwd_workspace_bytes(N, H, W, Cin, Cout), DSRL_E_WORKSPACE, "convt2x2_bwd: workspace too small");
+    const int nb = convt_dw_blocks(N, H, W);
+    const int nseg_per_row = (int)ceil_div(W, 64);
+    const long long nseg = (long long)N * H * nseg_per_row;
+    dim3 gdx((unsigned)ceil_div(W, 128), (unsigned)(N * H));
+#define DSRL_CONVT_BWD_BODY                                                                                                         \
+    hipLaunchKernelGGL((convt2x2_dx_kernel<CI, CO>), gdx, dim3(256), 0, st, dy, w, dx, N, H, W);                                    \
+    if (int e = launch_status("convt2x2_dx_kernel")) return e;                                                                      \
+    hipLaunchKernelGGL((convt2x2_dw_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, x, dy, (float*)ws, N, H, W, nseg_per_row, nseg);   \
+    if (int e = launch_status("convt2x2_dw_kernel")) return e;                                                                      \
+    hipLaunchKernelGGL((convt2x2_dw_finalize_kernel<CI, CO>), dim3((unsigned)ceil_div(CI * CO * 4 + CO, 256)), dim3(256), 0, st,    \
+                       (const float*)ws, nb, dw, dbias);                                                                            \
+    return launch_status("convt2x2_dw_finalize_kernel");
+    DSRL_CONVT_DISPATCH(19, 19, DSRL_CONVT_BWD_BODY)
+    DSRL_CONVT_DISPATCH(8, 8, DSRL_CONVT_BWD_BODY)
+    set_error("convt2x2_bwd: channel counts %d->%d not instantiated (19->19, 8->8)", Cin, Cout);
+    return DSRL_E_UNSUPPORTED;
+}
+
+extern "C" int dsrl_pixel_shuffle_fwd(const float* x, float* y, int N, int H, int W, int c, int r, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(x && y && N > 0 && H > 0 && W > 0 && c > 0 && r > 0, "pixel_shuffle_fwd")
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(flat_grid((long long)N * H * W * c * r * r)), dim3(256), 0, st, x, y, N, H, W, c, r, 0);
+    return launch_status("pixel_shuffle_kernel");
+}
+extern "C" int dsrl_pixel_shuffle_bwd(const float* dy, float* dx, int N, int H, int W, int c, int r, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(dy && dx && N > 0 && H > 0 && W > 0 && c > 0 && r > 0, "pixel_shuffle_bwd")
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(flat_grid((long long)N * H * W * c * r * r)), dim3(256), 0, st, dy, dx, N, H, W, c, r, 1);
+    return launch_status("pixel_shuffle_kernel");
+}
+
+extern "C" int dsrl_pointwise_strided_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int stride, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(x && w && y && N > 0 && H > 0 && W > 0 && C > 0 && stride > 0, "pointwise_strided_fwd")
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    hipLaunchKernelGGL(pointwise_fwd_kernel, dim3(flat_grid((long long)N * Ho * Wo)), dim3(256), 0, st, x, w, y, N, H, W, C, stride, Ho, Wo);
+    return launch_status("pointwise_fwd_kernel");
+}
+static int pointwise_blocks(int N, int H, int W, int stride) {
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    return (int)flat_grid((long long)N * Ho * Wo, 256, 256);
+}
+extern "C" size_t dsrl_pointwise_strided_bwd_workspace_bytes(int N, int H, int W, int C, int stride) {
+    return (size_t)pointwise_blocks(N, H, W, stride) * C * sizeof(float);
+}
+extern "C" int dsrl_pointwise_strided_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int accumulate,
+                                          int N, int H, int W, int C, int stride, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(x && w && dy && dx && dw && ws && N > 0 && H > 0 && W > 0 && C > 0 && stride > 0, "pointwise_strided_bwd")
+    DSRL_REQUIRE(ws_bytes >= dsrl_pointwise_strided_bwd_workspace_bytes(N, H, W, C, stride), DSRL_E_WORKSPACE, "pointwise_strided_bwd: workspace too small");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    if (!accumulate) {
+        if (hipMemsetAsync(dx, 0, (size_t)N * H * W * C * sizeof(float), st) != hipSuccess) return launch_status("hipMemsetAsync(dx)");
+    }
+    const int nb = pointwise_blocks(N, H, W, stride);
+    hipLaunchKernelGGL(pointwise_bwd_kernel, dim3(nb), dim3(256), 256 * sizeof(float), st, x, w, dy, dx, (float*)ws, accumulate, N, H, W, C, stride, Ho, Wo);
+    if (int e = launch_status("pointwise_bwd_kernel")) return e;
+    hipLaunchKernelGGL(pointwise_dw_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, (const float*)ws, nb, C, dw);
+    return launch_status("pointwise_dw_finalize_kernel");
+}
+
+extern "C" int dsrl_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "nchw_to_nhwc")
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(flat_grid((long long)N * H * W)), dim3(256), 0, st, x, y, N, C, H * W, Cpad);
+    return launch_status("nchw_to_nhwc_kernel");
+}
+
+extern "C" int dsrl_copy2d(const float* src, int ld_src, float* dst, int ld_dst, int64_t P, int C, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(src && dst && P > 0 && C > 0 && ld_src >= C && ld_dst >= C, "copy2d")
+    if (hipMemcpy2DAsync(dst, (size_t)ld_dst * sizeof(float), src, (size_t)ld_src * sizeof(float), (size_t)C * sizeof(float), (size_t)P,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return launch_status("hipMemcpy2DAsync");
+    return DSRL_OK;
+}

@@ -1,0 +1,138 @@
+"""Data-parallel gradient reduction and the SGD update on flat fp32 arenas.
+
+Replaces what the reference gets from `torch.nn.parallel.DistributedDataParallel(model)` + `torch.optim.SGD`
+(command_handlers/train_or_resume.py:63-66, 105-106, 444-445) with a layout chosen for RCCL over xGMI:
+
+  * all parameters live in ONE contiguous arena (and their gradients / momentum buffers in two more), ordered in reverse
+    registration order, i.e. roughly the order in which backward produces gradients;
+  * the gradient arena is all-reduced in a few large contiguous chunks (default 32 MiB) straight out of that memory - no
+    bucket gather/scatter copies - and each chunk is launched asynchronously from an autograd hook as soon as every
+    gradient in it has been accumulated, so RCCL overlaps with the rest of backward;
+  * the mean (1/world) is folded into the fused SGD kernel (one launch over the whole arena);
+  * BatchNorm running statistics sit in a fourth small arena that rank 0 broadcasts in one collective per step (DDP's
+    broadcast_buffers=True default, which train_or_resume.py:106 relies on).
+
+One process per GPU; `torch.distributed` backend 'nccl' is RCCL on ROCm.  With world size 1 (or no process group) the
+collectives are skipped and only the arena + fused optimiser remain.
+"""
+import torch
+import torch.distributed as dist
+
+from . import functional as HF
+
+
+def _align(n, a=4):
+    return (n + a - 1) // a * a
+
+
+class FlatParams:
+    def __init__(self, model, chunk_bytes=32 << 20, process_group=None, broadcast_buffers=True):
+        self.model = model
+        params = [p for p in model.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError('model has no trainable parameters')
+        dev = params[0].device
+        self.device = dev
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.params = list(reversed(params))                 # backward order first
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off += _align(p.numel())
+        self.offsets, self.numel = offs, off
+        self.p_flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.g_flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.m_flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                if p.dtype != torch.float32:
+                    raise TypeError('fp32 parameters expected')
+                if not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
+                    p.data = p.data.contiguous()          # the arena views need dense storage
+                view = self.p_flat.as_strided(p.shape, p.stride(), o)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.g_flat.as_strided(p.shape, p.stride(), o)
+        # float buffers (BN running statistics) in their own arena
+        self.buffers = []
+        boff = 0
+        for mod in model.modules():
+            for name, b in list(mod._buffers.items()):
+                if b is not None and b.dtype == torch.float32:
+                    self.buffers.append((mod, name, boff, b))
+                    boff += _align(b.numel())
+        self.b_flat = torch.zeros(max(boff, 4), device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for mod, name, o, b in self.buffers:
+                view = self.b_flat[o:o + b.numel()].view(b.shape)
+                view.copy_(b)
+                mod._buffers[name] = view
+        self.broadcast_buffers_enabled = broadcast_buffers
+        # chunks of the gradient arena, each a contiguous range of whole parameters
+        per = max(1, chunk_bytes // 4)
+        self.chunks, start, count = [], 0, 0
+        self._chunk_of = {}
+        for i, (p, o) in enumerate(zip(self.params, offs)):
+            self._chunk_of[i] = len(self.chunks)
+            count += 1
+            end = o + _align(p.numel())
+            if end - start >= per or i == len(self.params) - 1:
+                self.chunks.append([start, end, count])
+                start, count = end, 0
+        self._pending = [c[2] for c in self.chunks]
+        self._works = []
+        self._hooks = []
+        if self.world > 1:
+            dist.broadcast(self.p_flat, 0, group=self.pg)          # DDP constructor semantics: rank 0's weights win
+            dist.broadcast(self.b_flat, 0, group=self.pg)
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    # ------------------------------------------------------------------ gradient reduction
+    def _make_hook(self, i):
+        ci = self._chunk_of[i]
+
+        def hook(_param):
+            self._pending[ci] -= 1
+            if self._pending[ci] == 0:
+                a, b, _ = self.chunks[ci]
+                self._works.append(dist.all_reduce(self.g_flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        return hook
+
+    def zero_grad(self):
+        self.g_flat.zero_()
+        self._pending = [c[2] for c in self.chunks]
+        self._works = []
+
+    def finish_reduction(self):
+        """Waits (stream-wise) for the chunk all-reduces launched during backward; chunks whose hooks did not all fire
+        (parameters unused in this step) are reduced here so that every rank issues the same collectives."""
+        if self.world == 1:
+            return
+        for ci, left in enumerate(self._pending):
+            if left > 0:
+                a, b, _ = self.chunks[ci]
+                self._works.append(dist.all_reduce(self.g_flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self._pending[ci] = 0
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    def sync_buffers(self):
+        if self.world > 1 and self.broadcast_buffers_enabled:
+            dist.broadcast(self.b_flat, 0, group=self.pg)
+
+    # ------------------------------------------------------------------ optimiser
+    def sgd_step(self, lr, momentum, weight_decay):
+        """torch.optim.SGD(momentum, weight_decay).step() on the whole arena; gradients are averaged over ranks here."""
+        self.finish_reduction()
+        HF.sgd_step_(self.p_flat, self.g_flat, self.m_flat, lr, momentum, weight_decay, 1.0 / self.world)
+
+    def state_dict(self):
+        return {'momentum_arena': self.m_flat.clone(), 'numel': self.numel}
+
+    def load_state_dict(self, sd):
+        if sd['numel'] != self.numel:
+            raise ValueError('optimizer arena size mismatch')
+        self.m_flat.copy_(sd['momentum_arena'])

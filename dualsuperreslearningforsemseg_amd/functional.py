@@ -1,0 +1,604 @@
+"""torch.autograd.Function wrappers over the C ABI of libdsrl_hip.so (include/dsrl_hip.h).
+
+Tensors keep the reference's logical NCHW shapes; physically they are torch.channels_last ("pixel-major"
+[P][ld] for the kernels), which the wrappers enforce with at most one strided copy at the boundary.  Every op
+raises if its tensors are not on a HIP device: there is no CPU / stock-ATen fallback in this package.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, query, DsrlHipError
+
+CL = torch.channels_last
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise DsrlHipError('dualsuperreslearningforsemseg_amd ops run on the HIP device only (got a CPU tensor); '
+                               'there is no CPU fallback - move the model and inputs to cuda')
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise DsrlHipError(f'fp32 tensors expected, got {t.dtype}')
+    return t
+
+
+def new_cl(shape, like):
+    return torch.empty(shape, device=like.device, dtype=torch.float32, memory_format=CL)
+
+
+def _ws(nbytes, like):
+    return torch.empty(max(int(nbytes), 256), device=like.device, dtype=torch.uint8)
+
+
+def _ld_of(t):
+    """Pixel stride if `t` (N,C,H,W) is pixel-major (channel stride 1, dense pixels with stride ld), else None."""
+    N, C, H, W = t.shape
+    st = t.stride()
+    if C > 1 and st[1] != 1:
+        return None
+    if W > 1:
+        ld = st[3]
+    elif H > 1:
+        ld = st[2]
+    elif N > 1:
+        ld = st[0]
+    else:
+        ld = C
+    if ld < C:
+        return None
+    if (W > 1 and st[3] != ld) or (H > 1 and st[2] != W * ld) or (N > 1 and st[0] != H * W * ld):
+        return None
+    return ld
+
+
+def pm(t):
+    """-> (tensor, ld): a pixel-major view of `t` (copying into channels_last only when needed)."""
+    _need_gpu(t); _f32(t)
+    if t.dim() != 4:
+        raise DsrlHipError(f'4-D (N,C,H,W) tensor expected, got shape {tuple(t.shape)}')
+    ld = _ld_of(t)
+    if ld is None or (t.data_ptr() % 4) != 0:
+        out = new_cl(tuple(t.shape), t)
+        out.copy_(t)
+        return out, t.shape[1]
+    return t, ld
+
+
+def pm_dense(t):
+    """pixel-major with ld == C"""
+    t, ld = pm(t)
+    if ld != t.shape[1]:
+        out = new_cl(tuple(t.shape), t)
+        N, Cc, H, W = t.shape
+        call('dsrl_copy2d', t.data_ptr(), ld, out.data_ptr(), Cc, N * H * W, Cc, _stream())
+        return out
+    return t
+
+
+def pm_vec4(t):
+    """pixel-major view the float4 loaders of the MFMA kernels accept: 16-byte aligned base, ld a multiple of 4;
+    a channel count that is not a multiple of 4 (the 19 class logits) is copied into a zero-padded buffer."""
+    t, ld = pm(t)
+    N, Cc, H, W = t.shape
+    if Cc % 4 == 0 and ld % 4 == 0 and t.data_ptr() % 16 == 0:
+        return t, ld
+    cp = (Cc + 3) & ~3
+    buf = new_cl((N, cp, H, W), t)
+    if cp != Cc:
+        buf.zero_()
+    call('dsrl_copy2d', t.data_ptr(), ld, buf.data_ptr(), cp, N * H * W, Cc, _stream())
+    return buf[:, :Cc], cp
+
+
+def w_cl(w):
+    _need_gpu(w); _f32(w)
+    return w.contiguous(memory_format=CL)
+
+
+def _out_size(n, k, stride, pad, dil):
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+_rng_state = {'seed': 0x5EED, 'step': 0, 'current': 0}
+
+
+def set_dropout_seed(seed):
+    """Base key of the Philox dropout generator; every forward pass (begin_forward) derives its own key from it."""
+    _rng_state['seed'] = int(seed) & 0xFFFFFFFFFFFF
+    _rng_state['step'] = 0
+
+
+def _derive(step):
+    return (_rng_state['seed'] * 1000003 + step) & 0xFFFFFFFFFFFFFFFF
+
+
+def peek_next_seed():
+    return _derive(_rng_state['step'] + 1)
+
+
+def begin_forward():
+    """Called once per model forward: all Dropout modules of that pass share one key and differ by stream id."""
+    _rng_state['step'] += 1
+    _rng_state['current'] = _derive(_rng_state['step'])
+    return _rng_state['current']
+
+
+def current_seed():
+    return _rng_state['current']
+
+
+# ------------------------------------------------------------------------------------------------ conv2d
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, dil):
+        x, ldx = pm_vec4(x)
+        w = w_cl(w)
+        N, Cc, H, W = x.shape
+        K, Cw, R, S = w.shape
+        if Cw != Cc:
+            raise DsrlHipError(f'conv2d: input has {Cc} channels, weight expects {Cw}')
+        Ho, Wo = _out_size(H, R, stride, pad, dil), _out_size(W, S, stride, pad, dil)
+        y = new_cl((N, K, Ho, Wo), x)
+        shp = (N, H, W, Cc, K, R, S, stride, pad, dil)
+        ws = _ws(query('dsrl_conv2d_fwd_workspace_bytes', *shp), x)
+        if bias is not None:
+            _need_gpu(bias)
+        call('dsrl_conv2d_fwd', x.data_ptr(), ldx, w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), K,
+             *shp, ws.data_ptr(), ws.numel(), _stream())
+        ctx.save_for_backward(x, w)
+        ctx.shp = shp
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        shp = ctx.shp
+        N, H, W, Cc, K, R, S, stride, pad, dil = shp
+        dy, lddy = pm_vec4(dy)
+        ldx = _ld_of(x)
+        dx = dw = db = None
+        st = _stream()
+        if ctx.needs_input_grad[0]:
+            dx = new_cl((N, Cc, H, W), x)
+            ws = _ws(query('dsrl_conv2d_dgrad_workspace_bytes', *shp), x)
+            call('dsrl_conv2d_dgrad', dy.data_ptr(), lddy, w.data_ptr(), dx.data_ptr(), Cc, *shp, ws.data_ptr(), ws.numel(), st)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((K, Cc, R, S), device=x.device, dtype=torch.float32, memory_format=CL)
+            ws = _ws(query('dsrl_conv2d_wgrad_workspace_bytes', *shp), x)
+            call('dsrl_conv2d_wgrad', x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(), *shp, ws.data_ptr(), ws.numel(), st)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            P = dy.shape[0] * dy.shape[2] * dy.shape[3]
+            db = torch.empty(K, device=x.device, dtype=torch.float32)
+            ws = _ws(query('dsrl_colsum_workspace_bytes', P, K), x)
+            call('dsrl_colsum', dy.data_ptr(), lddy, P, K, db.data_ptr(), ws.data_ptr(), ws.numel(), st)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+    """nn.Conv2d arithmetic (square stride/padding/dilation) on the MFMA implicit-GEMM kernels."""
+    if x.shape[1] % 4 != 0:
+        # 3-channel image stem (ResNet101.py:28): pad input and filter to 4 channels (zeros contribute nothing)
+        padc = 4 - x.shape[1] % 4
+        x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, padc))
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, padc))
+    return _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation))
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm (+res, relu, dropout)
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, drop_p, seed, rng_stream, residual):
+        x, ldx = pm(x)
+        _need_gpu(gamma, beta, running_mean, running_var)
+        N, Cc, H, W = x.shape
+        P = N * H * W
+        st = _stream()
+        ws = _ws(query('dsrl_bn_workspace_bytes', P, Cc), x)
+        if training:
+            if P <= 1:
+                raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
+            mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
+            invstd = torch.empty_like(mean)
+            call('dsrl_bn_stats', x.data_ptr(), ldx, P, Cc, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
+                 None if running_mean is None else running_mean.data_ptr(), None if running_var is None else running_var.data_ptr(),
+                 ws.data_ptr(), ws.numel(), st)
+        else:
+            mean = running_mean
+            invstd = torch.empty(Cc, device=x.device, dtype=torch.float32)
+            call('dsrl_bn_invstd_from_var', running_var.data_ptr(), Cc, float(eps), invstd.data_ptr(), st)
+        y = new_cl((N, Cc, H, W), x)
+        res_ptr, ldr = None, 0
+        if residual is not None:
+            residual, ldr = pm(residual)
+            res_ptr = residual.data_ptr()
+        call('dsrl_bn_apply', x.data_ptr(), ldx, y.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+             res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream), st)
+        ctx.save_for_backward(x, y, mean, invstd, gamma)
+        ctx.cfg = (bool(training), bool(relu), float(drop_p), residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd, gamma = ctx.saved_tensors
+        training, relu, drop_p, has_res = ctx.cfg
+        dy, lddy = pm(dy)
+        _, ldx = pm(x)
+        N, Cc, H, W = x.shape
+        P = N * H * W
+        dx = new_cl((N, Cc, H, W), x)
+        dres = new_cl((N, Cc, H, W), x) if has_res else None
+        dgamma = torch.empty(Cc, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty_like(dgamma)
+        ws = _ws(query('dsrl_bn_workspace_bytes', P, Cc), x)
+        call('dsrl_bn_bwd', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,
+             None if dres is None else dres.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+             dgamma.data_ptr(), dbeta.data_ptr(), int(relu), drop_p, int(training), ws.data_ptr(), ws.numel(), _stream())
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, dres
+
+
+def batch_norm_act(x, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual=None):
+    """BatchNorm2d `bn` (an nn.BatchNorm2d holding the parameters/buffers) + optional residual add, ReLU, Dropout."""
+    training = bn.training or bn.running_mean is None
+    if training and bn.running_mean is not None:
+        bn._dsrl_batches = getattr(bn, '_dsrl_batches', 0) + 1      # flushed into num_batches_tracked by HipBatchNorm2d.state_dict
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, relu,
+                        drop_p if training or drop_p == 0.0 else 0.0, seed, rng_stream, residual)
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, rng_stream):
+        x, ldx = pm(x)
+        N, Cc, H, W = x.shape
+        y = new_cl((N, Cc, H, W), x)
+        call('dsrl_dropout_fwd', x.data_ptr(), ldx, y.data_ptr(), Cc, N * H * W, Cc, float(p), int(seed), int(rng_stream), _stream())
+        ctx.cfg = (float(p), int(seed), int(rng_stream))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, rng_stream = ctx.cfg
+        dy, ld = pm(dy)
+        N, Cc, H, W = dy.shape
+        dx = new_cl((N, Cc, H, W), dy)
+        call('dsrl_dropout_bwd', dy.data_ptr(), ld, dx.data_ptr(), Cc, N * H * W, Cc, p, seed, rng_stream, _stream())
+        return dx, None, None, None
+
+
+def dropout(x, p, training, seed, rng_stream):
+    if not training or p == 0.0:
+        return x
+    return _Dropout.apply(x, p, seed, rng_stream)
+
+
+# ------------------------------------------------------------------------------------------------ resize / pools / concat
+class _UpsampleAC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        x, ldx = pm(x)
+        N, Cc, H, W = x.shape
+        y = new_cl((N, Cc, Ho, Wo), x)
+        call('dsrl_bilinear_ac_fwd', x.data_ptr(), ldx, y.data_ptr(), Cc, N, H, W, Cc, Ho, Wo, _stream())
+        ctx.shp = (N, Cc, H, W, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cc, H, W, Ho, Wo = ctx.shp
+        dy, ld = pm(dy)
+        dx = new_cl((N, Cc, H, W), dy)
+        call('dsrl_bilinear_ac_bwd', dy.data_ptr(), ld, dx.data_ptr(), Cc, N, H, W, Cc, Ho, Wo, _stream())
+        return dx, None, None
+
+
+def upsample_bilinear_ac(x, size):
+    return _UpsampleAC.apply(x, int(size[0]), int(size[1]))
+
+
+class _GlobalAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x, ldx = pm(x)
+        N, Cc, H, W = x.shape
+        y = new_cl((N, Cc, 1, 1), x)
+        call('dsrl_global_avgpool_fwd', x.data_ptr(), ldx, y.data_ptr(), N, H * W, Cc, _stream())
+        ctx.shp = (N, Cc, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cc, H, W = ctx.shp
+        dy = dy.contiguous().view(N, Cc)
+        dx = new_cl((N, Cc, H, W), dy)
+        call('dsrl_global_avgpool_bwd', dy.data_ptr(), dx.data_ptr(), Cc, N, H * W, Cc, _stream())
+        return dx
+
+
+def global_avg_pool(x):
+    return _GlobalAvgPool.apply(x)
+
+
+class _MaxPool3x3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = pm_dense(x)
+        N, Cc, H, W = x.shape
+        y = new_cl((N, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1), x)
+        call('dsrl_maxpool3x3s2_fwd', x.data_ptr(), y.data_ptr(), N, H, W, Cc, _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        N, Cc, H, W = x.shape
+        dy = pm_dense(dy)
+        dx = new_cl((N, Cc, H, W), x)
+        call('dsrl_maxpool3x3s2_bwd', x.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, H, W, Cc, _stream())
+        return dx
+
+
+def max_pool3x3s2(x):
+    return _MaxPool3x3s2.apply(x)
+
+
+class _Cat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [pm(x) for x in xs]
+        N, _, H, W = xs[0][0].shape
+        ctot = sum(x.shape[1] for x, _ in xs)
+        y = new_cl((N, ctot, H, W), xs[0][0])
+        off = 0
+        st = _stream()
+        for x, ld in xs:
+            call('dsrl_copy2d', x.data_ptr(), ld, y.data_ptr() + 4 * off, ctot, N * H * W, x.shape[1], st)
+            off += x.shape[1]
+        ctx.sizes = [x.shape[1] for x, _ in xs]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        outs, off = [], 0
+        for c in ctx.sizes:
+            outs.append(dy[:, off:off + c])       # channel-slice views (pixel-major with ld = total channels)
+            off += c
+        return tuple(outs)
+
+
+def cat_channels(xs):
+    return _Cat.apply(*xs)
+
+
+# ------------------------------------------------------------------------------------------------ ConvTranspose k2s2 / PixelShuffle / pointwise
+class _ConvT2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = pm_dense(x)
+        _need_gpu(w, bias)
+        w = w.contiguous()
+        N, Ci, H, W = x.shape
+        Co = w.shape[1]
+        if w.shape[0] != Ci or tuple(w.shape[2:]) != (2, 2):
+            raise DsrlHipError(f'conv_transpose2d_k2s2: weight {tuple(w.shape)} does not match input channels {Ci}')
+        y = new_cl((N, Co, 2 * H, 2 * W), x)
+        call('dsrl_convt2x2_fwd', x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), N, H, W, Ci, Co, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, Ci, H, W = x.shape
+        Co = w.shape[1]
+        dy = pm_dense(dy)
+        dx = new_cl((N, Ci, H, W), x)
+        dw = torch.empty_like(w)
+        db = torch.empty(Co, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        ws = _ws(query('dsrl_convt2x2_bwd_workspace_bytes', N, H, W, Ci, Co), x)
+        call('dsrl_convt2x2_bwd', x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(),
+             N, H, W, Ci, Co, ws.data_ptr(), ws.numel(), _stream())
+        return dx, dw, db
+
+
+def conv_transpose2d_k2s2(x, weight, bias=None):
+    return _ConvT2x2.apply(x, weight, bias)
+
+
+class _PixelShuffle(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r):
+        x = pm_dense(x)
+        N, Cc, H, W = x.shape
+        c = Cc // (r * r)
+        y = new_cl((N, c, H * r, W * r), x)
+        call('dsrl_pixel_shuffle_fwd', x.data_ptr(), y.data_ptr(), N, H, W, c, r, _stream())
+        ctx.shp = (N, Cc, H, W, c, r)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cc, H, W, c, r = ctx.shp
+        dy = pm_dense(dy)
+        dx = new_cl((N, Cc, H, W), dy)
+        call('dsrl_pixel_shuffle_bwd', dy.data_ptr(), dx.data_ptr(), N, H, W, c, r, _stream())
+        return dx, None
+
+
+def pixel_shuffle(x, r):
+    return _PixelShuffle.apply(x, int(r))
+
+
+class _PointwiseStrided(torch.autograd.Function):
+    """1x1 conv, stride s, one output channel, no bias (DSRL.py:88-93)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        x = pm_dense(x)
+        _need_gpu(w)
+        N, Cc, H, W = x.shape
+        wf = w.contiguous().view(-1)
+        if wf.numel() != Cc:
+            raise DsrlHipError('pointwise_strided: weight must be (1,C,1,1)')
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = new_cl((N, 1, Ho, Wo), x)
+        call('dsrl_pointwise_strided_fwd', x.data_ptr(), wf.data_ptr(), y.data_ptr(), N, H, W, Cc, stride, _stream())
+        ctx.save_for_backward(x, wf)
+        ctx.stride = stride
+        ctx.wshape = tuple(w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wf = ctx.saved_tensors
+        N, Cc, H, W = x.shape
+        dy = dy.contiguous()
+        dx = new_cl((N, Cc, H, W), x)
+        dw = torch.empty(Cc, device=x.device, dtype=torch.float32)
+        ws = _ws(query('dsrl_pointwise_strided_bwd_workspace_bytes', N, H, W, Cc, ctx.stride), x)
+        call('dsrl_pointwise_strided_bwd', x.data_ptr(), wf.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), 0,
+             N, H, W, Cc, ctx.stride, ws.data_ptr(), ws.numel(), _stream())
+        return dx, dw.view(ctx.wshape), None
+
+
+def pointwise_strided(x, weight, stride):
+    return _PointwiseStrided.apply(x, weight, int(stride))
+
+
+# ------------------------------------------------------------------------------------------------ losses
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        logits, ld = pm(logits)
+        _need_gpu(target)
+        if target.dtype != torch.uint8:
+            target = target.to(torch.uint8)
+        target = target.contiguous()
+        N, Cc, H, W = logits.shape
+        P = N * H * W
+        if target.numel() != P:
+            raise DsrlHipError(f'cross_entropy: target has {target.numel()} pixels, logits {P}')
+        out = torch.empty(2, device=logits.device, dtype=torch.float32)
+        ws = _ws(query('dsrl_ce_workspace_bytes', P), logits)
+        call('dsrl_ce_fwd', logits.data_ptr(), ld, target.data_ptr(), P, Cc, int(ignore_index), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+        ctx.save_for_backward(logits, target, out)
+        ctx.ignore_index = int(ignore_index)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, out = ctx.saved_tensors
+        _, ld = pm(logits)
+        N, Cc, H, W = logits.shape
+        g = g.reshape(1).contiguous().float()
+        dl = new_cl((N, Cc, H, W), logits)
+        call('dsrl_ce_bwd', logits.data_ptr(), ld, target.data_ptr(), N * H * W, Cc, ctx.ignore_index, out.data_ptr(), g.data_ptr(),
+             dl.data_ptr(), Cc, _stream())
+        return dl, None, None
+
+
+def cross_entropy(logits, target, ignore_index=255):
+    """nn.CrossEntropyLoss(ignore_index) with mean reduction; target (N,H,W) uint8/long."""
+    return _CrossEntropy.apply(logits, target, ignore_index)
+
+
+class _MSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a = pm_dense(a)
+        b = pm_dense(b)
+        if a.shape != b.shape:
+            raise DsrlHipError(f'mse: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}')
+        n = a.numel()
+        out = torch.empty(1, device=a.device, dtype=torch.float32)
+        ws = _ws(query('dsrl_mse_workspace_bytes', n), a)
+        call('dsrl_mse_fwd', a.data_ptr(), b.data_ptr(), n, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+        ctx.save_for_backward(a, b)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.reshape(1).contiguous().float()
+        da = new_cl(tuple(a.shape), a)
+        call('dsrl_mse_bwd', a.data_ptr(), b.data_ptr(), a.numel(), g.data_ptr(), da.data_ptr(), _stream())
+        return da, None
+
+
+def mse_loss(a, b):
+    return _MSE.apply(a, b)
+
+
+_RED = {'mean': 0, 'sum': 1, 'none': 2}
+
+
+class _FALoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fm1, fm2, k, reduction):
+        _need_gpu(fm1, fm2); _f32(fm1); _f32(fm2)
+        if fm1.stride() != fm2.stride() or fm1.data_ptr() % 4 or fm2.data_ptr() % 4:
+            fm1, fm2 = fm1.contiguous(), fm2.contiguous()
+        B, Cc, H, W = fm1.shape
+        red = _RED[reduction]
+        n = (W // k) ** 2
+        out = torch.empty((B, Cc, n * n) if red == 2 else (1,), device=fm1.device, dtype=torch.float32)
+        saved = torch.empty(query('dsrl_fa_saved_floats', B, Cc, H, W, k), device=fm1.device, dtype=torch.float32)
+        ws = _ws(query('dsrl_fa_workspace_bytes', B, Cc, H, W, k), fm1)
+        sb, sc, sh, sw = fm1.stride()
+        call('dsrl_fa_fwd', fm1.data_ptr(), fm2.data_ptr(), B, Cc, H, W, sb, sc, sh, sw, k, red, out.data_ptr(), saved.data_ptr(),
+             ws.data_ptr(), ws.numel(), _stream())
+        ctx.save_for_backward(fm1, fm2, saved)
+        ctx.cfg = (k, red)
+        return out if red == 2 else out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        fm1, fm2, saved = ctx.saved_tensors
+        k, red = ctx.cfg
+        if red == 2:
+            raise DsrlHipError("FALoss(reduction='none') has no backward kernel; use 'mean' or 'sum'")
+        B, Cc, H, W = fm1.shape
+        g = g.reshape(1).contiguous().float()
+        d1 = torch.empty((B, Cc, H, W), device=fm1.device, dtype=torch.float32)
+        d2 = torch.empty_like(d1)
+        sb, sc, sh, sw = fm1.stride()
+        call('dsrl_fa_bwd', fm1.data_ptr(), fm2.data_ptr(), B, Cc, H, W, sb, sc, sh, sw, k, red, g.data_ptr(), saved.data_ptr(),
+             d1.data_ptr(), d2.data_ptr(), None, 0, _stream())
+        return d1, d2, None, None
+
+
+def fa_loss(fm1, fm2, subsample_factor=8, reduction='mean'):
+    return _FALoss.apply(fm1, fm2, int(subsample_factor), reduction)
+
+
+# ------------------------------------------------------------------------------------------------ optimiser / checks
+def sgd_step_(p, g, buf, lr, momentum, weight_decay, grad_scale=1.0):
+    """In-place SGD(momentum, weight_decay) on flat fp32 arenas."""
+    _need_gpu(p, g, buf)
+    call('dsrl_sgd_step', p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), float(lr), float(momentum), float(weight_decay),
+         float(grad_scale), _stream())
+
+
+def nan_check_(flag, *tensors):
+    """ORs 1 into the int32 device scalar `flag` if any tensor holds a NaN (one readback for all of them)."""
+    st = _stream()
+    for t in tensors:
+        if t is None or not t.is_cuda:
+            continue
+        td = t if t.is_contiguous() or t.is_contiguous(memory_format=CL) else t.contiguous()
+        call('dsrl_nan_check', td.data_ptr(), td.numel(), flag.data_ptr(), st)
+
+
+def conv2d_inbounds_macs(N, H, W, Cc, K, R, S, stride, pad, dil):
+    return query('dsrl_conv2d_inbounds_macs', N, H, W, Cc, K, R, S, stride, pad, dil)

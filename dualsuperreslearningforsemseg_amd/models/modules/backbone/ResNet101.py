@@ -1,0 +1,115 @@
+"""ResNet-101 (output stride 16) - counterpart of the reference's models/modules/backbone/ResNet101.py:6-107.
+
+The reference builds it from torchvision 0.8.1's `Bottleneck` (ResNet101.py:13,76), which is absent on the target;
+the bottleneck below restates that block (1x1 -> 3x3(stride, dilation) -> 1x1 expansion 4, stride on the 3x3) with
+torchvision's attribute names, so the state_dict keys equal torchvision's resnet101 and pretrained weights load.
+Every convolution / BN / pooling runs on the HIP kernels.
+"""
+import os
+
+import torch as t
+
+from ....nn_modules import HipBatchNorm2d, HipConv2d, HipMaxPool2d, HipReLU, HipSequential
+from .... import functional as HF
+
+
+class Bottleneck(t.nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or HipBatchNorm2d
+        width = int(planes * (base_width / 64.)) * groups
+        self.conv1 = HipConv2d(inplanes, width, kernel_size=1, stride=1, bias=False)
+        self.bn1 = norm_layer(width)
+        self.conv2 = HipConv2d(width, width, kernel_size=3, stride=stride, padding=dilation, groups=groups, dilation=dilation, bias=False)
+        self.bn2 = norm_layer(width)
+        self.conv3 = HipConv2d(width, planes * self.expansion, kernel_size=1, stride=1, bias=False)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.relu = HipReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = HF.batch_norm_act(self.conv1(x), self.bn1, relu=True)
+        out = HF.batch_norm_act(self.conv2(out), self.bn2, relu=True)
+        return HF.batch_norm_act(self.conv3(out), self.bn3, relu=True, residual=identity)      # bn3 + identity, then ReLU
+
+
+class ResNet101(t.nn.Module):
+    PRETRAINED_WEIGHTS_URL = "https://download.pytorch.org/models/resnet101-5d3b4d8f.pth"
+    PRETRAINED_WEIGHTS_FILE = 'resnet101_pretrained.pth'
+
+    def __init__(self, groups=1, width_per_group=64, replace_stride_with_dilation=None, init_weights=True, BatchNorm2d=HipBatchNorm2d):
+        super().__init__()
+        layers = [3, 4, 23, 3]
+        self._norm_layer = BatchNorm2d
+        self.inplanes = 64
+        self.dilation = 1
+        if replace_stride_with_dilation is None:
+            replace_stride_with_dilation = [False, False, False]
+        assert len(replace_stride_with_dilation) == 3, \
+            "replace_stride_with_dilation should be None or a 3-element tuple, got {}".format(replace_stride_with_dilation)
+        self.groups = groups
+        self.base_width = width_per_group
+        self.conv1 = HipConv2d(3, self.inplanes, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = BatchNorm2d(self.inplanes)
+        self.relu = HipReLU(inplace=True)
+        self.maxpool = HipMaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], stride=2, dilate=replace_stride_with_dilation[0])
+        self.layer3 = self._make_layer(256, layers[2], stride=2, dilate=replace_stride_with_dilation[1])
+        self.layer4 = self._make_layer(512, layers[3], stride=2, dilate=replace_stride_with_dilation[2])
+        if init_weights:
+            self._init_weights(BatchNorm2d)
+
+    @t.no_grad()
+    def _init_weights(self, BatchNorm2d):
+        # ResNet101.py:45-55: kaiming for convs, BN (1,0), zero-init of every bottleneck's last BN
+        for m in self.modules():
+            if isinstance(m, t.nn.Conv2d):
+                t.nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, BatchNorm2d):
+                m.weight.fill_(1.0)
+                m.bias.zero_()
+        for m in self.modules():
+            if isinstance(m, Bottleneck):
+                t.nn.init.constant_(m.bn3.weight, 0)
+
+    def initialize_with_pretrained_weights(self, weights_dir, map_location=t.device('cpu')):
+        """ResNet101.py:58-65 downloads the torchvision checkpoint; the target has no network, so the file must already
+        sit at <weights_dir>/resnet101_pretrained.pth (the name the reference caches it under)."""
+        path = os.path.join(weights_dir, self.PRETRAINED_WEIGHTS_FILE)
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"'{path}' not found; fetch {self.PRETRAINED_WEIGHTS_URL} to that path (no network access from here)")
+        state = t.load(path, map_location=map_location)
+        missing_keys, _ = self.load_state_dict(state, strict=False)
+        assert len(missing_keys) == 0, "BUG CHECK: Pretrained weights from model zoo for ResNet101 has missing keys: {}.".format(missing_keys)
+
+    def _make_layer(self, planes, blocks, stride=1, dilate=False):
+        norm_layer = self._norm_layer
+        downsample = None
+        previous_dilation = self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        if stride != 1 or self.inplanes != planes * Bottleneck.expansion:
+            downsample = HipSequential(HipConv2d(self.inplanes, planes * Bottleneck.expansion, kernel_size=1, stride=stride, bias=False),
+                                       norm_layer(planes * Bottleneck.expansion))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample, self.groups, self.base_width, previous_dilation, norm_layer)]
+        self.inplanes = planes * Bottleneck.expansion
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes, groups=self.groups, base_width=self.base_width, dilation=self.dilation,
+                                     norm_layer=norm_layer))
+        return t.nn.Sequential(*layers)
+
+    def forward(self, x: t.Tensor):
+        x = HF.batch_norm_act(self.conv1(x), self.bn1, relu=True)        # ResNet101.py:92-94
+        x = self.maxpool(x)
+        x = self.layer1(x)
+        low_level_features = x                                            # ResNet101.py:98
+        x = self.layer2(x)
+        x = self.layer3(x)
+        x = self.layer4(x)
+        return x, low_level_features

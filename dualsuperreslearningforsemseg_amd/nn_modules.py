@@ -1,0 +1,119 @@
+"""torch.nn module classes whose forward runs on libdsrl_hip.so.
+
+They subclass the stock torch classes (same constructor arguments, parameter names and state_dict keys, so
+`isinstance(m, nn.Conv2d)` style code of the reference - weight init, BN freezing - keeps working) but their
+arithmetic is the HIP kernels; `HipSequential` additionally fuses Conv -> BN -> ReLU -> Dropout runs.
+"""
+import torch
+from torch import nn
+
+from . import functional as HF
+
+
+def _single(v):
+    if isinstance(v, (tuple, list)):
+        if any(x != v[0] for x in v):
+            raise HF.DsrlHipError(f'only square stride/padding/dilation are implemented, got {v}')
+        return int(v[0])
+    return int(v)
+
+
+class HipConv2d(nn.Conv2d):
+    def forward(self, x):
+        if self.groups != 1 or self.padding_mode != 'zeros':
+            raise HF.DsrlHipError('HipConv2d: groups=1 and zero padding only')
+        k = self.kernel_size
+        if self.out_channels == 1 and k == (1, 1) and self.bias is None and self.in_channels % 4 != 0:
+            return HF.pointwise_strided(x, self.weight, _single(self.stride))          # feature transformers, DSRL.py:88-93
+        return HF.conv2d(x, self.weight, self.bias, _single(self.stride), _single(self.padding), _single(self.dilation))
+
+
+class HipBatchNorm2d(nn.BatchNorm2d):
+    def forward(self, x):
+        return HF.batch_norm_act(x, self)
+
+    def _flush_batches(self):
+        n = getattr(self, '_dsrl_batches', 0)
+        if n and self.num_batches_tracked is not None:
+            self.num_batches_tracked += n
+            self._dsrl_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_batches()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+
+class HipReLU(nn.ReLU):
+    def forward(self, x):
+        raise HF.DsrlHipError('HipReLU is always fused into the preceding BatchNorm by HipSequential')
+
+
+class HipDropout(nn.Dropout):
+    rng_stream = 0
+
+    def forward(self, x):
+        return HF.dropout(x, self.p, self.training, HF.current_seed(), self.rng_stream)
+
+
+class HipConvTranspose2d(nn.ConvTranspose2d):
+    def forward(self, x):
+        if self.kernel_size != (2, 2) or self.stride != (2, 2) or self.padding != (0, 0) or self.output_padding != (0, 0) or self.groups != 1:
+            raise HF.DsrlHipError('HipConvTranspose2d implements kernel_size=2, stride=2, padding=0 (DSRL.py:55-69)')
+        return HF.conv_transpose2d_k2s2(x, self.weight, self.bias)
+
+
+class HipUpsamplingBilinear2d(nn.UpsamplingBilinear2d):
+    def forward(self, x):
+        if self.size is not None:
+            size = self.size if isinstance(self.size, (tuple, list)) else (self.size, self.size)
+        else:
+            sf = self.scale_factor if isinstance(self.scale_factor, (tuple, list)) else (self.scale_factor, self.scale_factor)
+            size = (int(x.shape[2] * sf[0]), int(x.shape[3] * sf[1]))
+        return HF.upsample_bilinear_ac(x, size)
+
+
+class HipPixelShuffle(nn.PixelShuffle):
+    def forward(self, x):
+        return HF.pixel_shuffle(x, self.upscale_factor)
+
+
+class HipAdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
+    def forward(self, x):
+        if self.output_size not in (1, (1, 1)):
+            raise HF.DsrlHipError('HipAdaptiveAvgPool2d implements output_size=(1,1) (ASPP.py:22)')
+        return HF.global_avg_pool(x)
+
+
+class HipMaxPool2d(nn.MaxPool2d):
+    def forward(self, x):
+        if (_single(self.kernel_size), _single(self.stride), _single(self.padding), _single(self.dilation)) != (3, 2, 1, 1) or self.ceil_mode:
+            raise HF.DsrlHipError('HipMaxPool2d implements kernel 3, stride 2, padding 1 (ResNet101.py:32)')
+        return HF.max_pool3x3s2(x)
+
+
+class HipSequential(nn.Sequential):
+    """nn.Sequential that runs Conv2d -> BatchNorm2d -> ReLU -> Dropout as conv + one fused BN/activation pass."""
+
+    def forward(self, x, residual=None):
+        mods = list(self)
+        i, n = 0, len(mods)
+        seed = HF.current_seed()
+        while i < n:
+            m = mods[i]
+            if isinstance(m, nn.BatchNorm2d):
+                relu = i + 1 < n and isinstance(mods[i + 1], nn.ReLU)
+                j = i + (2 if relu else 1)
+                p, stream = 0.0, 0
+                if relu and j < n and isinstance(mods[j], nn.Dropout):
+                    if mods[j].training and mods[j].p > 0:
+                        p, stream = mods[j].p, getattr(mods[j], 'rng_stream', 0)
+                    j += 1
+                last = j >= n
+                x = HF.batch_norm_act(x, m, relu=relu, drop_p=p, seed=seed, rng_stream=stream, residual=residual if last else None)
+                i = j
+            elif isinstance(m, nn.ReLU):
+                raise HF.DsrlHipError('HipSequential: ReLU must follow a BatchNorm2d')
+            else:
+                x = m(x)
+                i += 1
+        return x

@@ -1,0 +1,185 @@
+/*
+ * dsrl_hip.h - C ABI of libdsrl_hip.so: the MI355X (gfx950) arithmetic of the DSRL stage-3 training hot path.
+ *
+ * The reference (sanje2v/DualSuperResLearningForSemSeg) has no FFI of its own: every operation below
+ * replaces the torch.nn call the reference makes at the cited file:line (paths under /root/reference).
+ * The host side (dualsuperreslearningforsemseg_amd/functional.py) binds these with ctypes and keeps the
+ * reference's nn.Module surface above them; INTEGRATION.md shows the binding a reference maintainer adds.
+ *
+ * Conventions
+ *   - fp32 only. Activations are "pixel-major": element (n,h,w,c) of a logical NCHW tensor lives at
+ *     ((n*H + h)*W + w)*ld + c   (= torch.channels_last); `ld` >= C is the pixel stride in floats, so a
+ *     channel slice of a concatenation buffer is addressed by (ptr + first_channel, ld = total channels).
+ *   - Conv weights are [K][R][S][C] (= torch (K,C,R,S) in channels_last), ConvTranspose weights are the
+ *     plain torch layout (Cin,Cout,2,2).
+ *   - Every function enqueues on `stream` (a hipStream_t) and returns immediately; no allocation, no host
+ *     synchronisation, no global mutable state: re-entrant from the autograd worker thread.
+ *   - The caller owns all buffers including `ws` (workspace, >= the matching *_workspace_bytes()).
+ *   - Return 0 on success, a negative DSRL_E_* otherwise; dsrl_last_error() has the message (thread-local).
+ */
+#ifndef DSRL_HIP_H
+#define DSRL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSRL_ABI_VERSION 1
+
+#define DSRL_OK 0
+#define DSRL_E_BADARG (-1)      /* inconsistent shape / null pointer / alignment                      */
+#define DSRL_E_UNSUPPORTED (-2) /* shape outside what the kernels implement                            */
+#define DSRL_E_WORKSPACE (-3)   /* workspace too small                                                 */
+#define DSRL_E_LAUNCH (-4)      /* hipGetLastError() after launch                                      */
+
+typedef void* dsrl_stream_t; /* hipStream_t */
+
+int dsrl_version(void);
+const char* dsrl_last_error(void);
+/* fills cu_count; returns 0 only on a gfx950 device */
+int dsrl_device_check(int* cu_count);
+
+/* ------------------------------------------------------------------------------------------------
+ * conv2d: implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).
+ * replaces nn.Conv2d forward/backward at ASPP.py:10-15,19; DSRL.py:19-23,34-38,42-46,50,78-83 and the
+ * ResNet101.py convolutions; x (N,H,W,C) -> y (N,Ho,Wo,K).
+ * ---------------------------------------------------------------------------------------------- */
+size_t dsrl_conv2d_fwd_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
+int dsrl_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias /*nullable*/, float* y, int ldy,
+                    int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                    void* ws, size_t ws_bytes, dsrl_stream_t stream);
+/* dx (N,H,W,C) from dy (N,Ho,Wo,K) */
+size_t dsrl_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
+int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                      void* ws, size_t ws_bytes, dsrl_stream_t stream);
+/* dw [K][R][S][C] from x and dy */
+size_t dsrl_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
+int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
+                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                      void* ws, size_t ws_bytes, dsrl_stream_t stream);
+/* in-bounds multiply-accumulates of one forward conv (zero-padding taps excluded): the roofline numerator */
+int64_t dsrl_conv2d_inbounds_macs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
+
+/* column sums: out[c] = sum_p x[p*ld + c]  (conv / convT bias gradients, DSRL.py:50,64-69,78-83) */
+size_t dsrl_colsum_workspace_bytes(int64_t P, int C);
+int dsrl_colsum(const float* x, int ld, int64_t P, int C, float* out, void* ws, size_t ws_bytes, dsrl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d (+ optional residual add, ReLU, Dropout) - nn.BatchNorm2d/ReLU/Dropout at ASPP.py:20-21,
+ * DSRL.py:24-25,39-41,47-49,61-63,94-95 and the ResNet bottlenecks.
+ * ---------------------------------------------------------------------------------------------- */
+size_t dsrl_bn_workspace_bytes(int64_t P, int C);
+/* training statistics: mean[c], invstd[c] = 1/sqrt(biased var + eps); running stats updated in place
+ * (unbiased var, momentum) when non-null */
+int dsrl_bn_stats(const float* x, int ldx, int64_t P, int C, float eps, float momentum,
+                  float* mean, float* invstd, float* running_mean /*nullable*/, float* running_var /*nullable*/,
+                  void* ws, size_t ws_bytes, dsrl_stream_t stream);
+/* invstd[c] = 1/sqrt(running_var[c] + eps) (eval mode / frozen BN, train_or_resume.py:379-382) */
+int dsrl_bn_invstd_from_var(const float* running_var, int C, float eps, float* invstd, dsrl_stream_t stream);
+/* y = dropout(relu((x-mean)*invstd*gamma + beta + residual)); flags: bit0 relu; dropout when p > 0 */
+int dsrl_bn_apply(const float* x, int ldx, float* y, int ldy, int64_t P, int C,
+                  const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  const float* residual /*nullable*/, int ldr, int relu, float drop_p, uint64_t seed, uint32_t rng_stream,
+                  dsrl_stream_t stream);
+/* backward of dsrl_bn_apply. y is the forward output (mask = y > 0 covers relu and dropout).
+ * training != 0: batch-statistics gradient; == 0: statistics are constants. dresidual nullable. */
+int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy,
+                float* dx, int lddx, float* dresidual /*nullable*/, int lddr, int64_t P, int C,
+                const float* mean, const float* invstd, const float* gamma,
+                float* dgamma, float* dbeta, int relu, float drop_p, int training,
+                void* ws, size_t ws_bytes, dsrl_stream_t stream);
+
+/* standalone Dropout (DSRL.py:54): Philox4x32-10 keyed by (seed, rng_stream), element index = p*C + c */
+int dsrl_dropout_fwd(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float p, uint64_t seed, uint32_t rng_stream, dsrl_stream_t stream);
+int dsrl_dropout_bwd(const float* dy, int lddy, float* dx, int lddx, int64_t P, int C, float p, uint64_t seed, uint32_t rng_stream, dsrl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * bilinear resize, align_corners=True (ASPP.py:41, DSRL.py:53, DSRL.py:163) and pools
+ * ---------------------------------------------------------------------------------------------- */
+int dsrl_bilinear_ac_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int Ho, int Wo, dsrl_stream_t stream);
+int dsrl_bilinear_ac_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int Ho, int Wo, dsrl_stream_t stream);
+/* nn.AdaptiveAvgPool2d((1,1)) (ASPP.py:22,38) */
+int dsrl_global_avgpool_fwd(const float* x, int ldx, float* y, int N, int HW, int C, dsrl_stream_t stream);
+int dsrl_global_avgpool_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, dsrl_stream_t stream);
+/* nn.MaxPool2d(3, stride 2, pad 1) (ResNet101.py:32) */
+int dsrl_maxpool3x3s2_fwd(const float* x, float* y, int N, int H, int W, int C, dsrl_stream_t stream);
+int dsrl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, dsrl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ConvTranspose2d(kernel 2, stride 2, pad 0) (DSRL.py:55-60, 64-69); w is (Cin,Cout,2,2) contiguous
+ * ---------------------------------------------------------------------------------------------- */
+int dsrl_convt2x2_fwd(const float* x, const float* w, const float* bias /*nullable*/, float* y, int N, int H, int W, int Cin, int Cout, dsrl_stream_t stream);
+size_t dsrl_convt2x2_bwd_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int dsrl_convt2x2_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dbias /*nullable*/,
+                      int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, dsrl_stream_t stream);
+
+/* nn.PixelShuffle(r) (DSRL.py:84): x (N,H,W,c*r*r) -> y (N,H*r,W*r,c) */
+int dsrl_pixel_shuffle_fwd(const float* x, float* y, int N, int H, int W, int c, int r, dsrl_stream_t stream);
+int dsrl_pixel_shuffle_bwd(const float* dy, float* dx, int N, int H, int W, int c, int r, dsrl_stream_t stream);
+
+/* 1x1 stride-s conv with a single output channel, no bias (feature transformers, DSRL.py:88-93) */
+int dsrl_pointwise_strided_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int stride, dsrl_stream_t stream);
+size_t dsrl_pointwise_strided_bwd_workspace_bytes(int N, int H, int W, int C, int stride);
+/* dx is fully written (zeros off the stride grid) when accumulate == 0, else dx += on the stride grid only */
+int dsrl_pointwise_strided_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int accumulate,
+                               int N, int H, int W, int C, int stride, void* ws, size_t ws_bytes, dsrl_stream_t stream);
+
+/* channel concatenation (ASPP.py:44, DSRL.py:165): dst[p*ld_dst + c] = src[p*ld_src + c], c < C (strided 2-D copy) */
+int dsrl_copy2d(const float* src, int ld_src, float* dst, int ld_dst, int64_t P, int C, dsrl_stream_t stream);
+
+/* layout converters at the boundary (NCHW image in, ResNet101.py:92): y has Cpad >= C channels, extra = 0 */
+int dsrl_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, dsrl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * losses (train_or_resume.py:116-119, 435-438)
+ * ---------------------------------------------------------------------------------------------- */
+size_t dsrl_ce_workspace_bytes(int64_t P);
+/* nn.CrossEntropyLoss(ignore_index): logits [P][C] pixel-major, target uint8 [P]; loss_out[0] = mean NLL over
+ * valid pixels, loss_out[1] = number of valid pixels */
+int dsrl_ce_fwd(const float* logits, int ld, const uint8_t* target, int64_t P, int C, int ignore_index,
+                float* loss_out, void* ws, size_t ws_bytes, dsrl_stream_t stream);
+/* dlogits = (softmax - onehot) * grad_out[0] / n_valid ; loss_out is the pair written by dsrl_ce_fwd */
+int dsrl_ce_bwd(const float* logits, int ld, const uint8_t* target, int64_t P, int C, int ignore_index,
+                const float* loss_out, const float* grad_out, float* dlogits, int lddl, dsrl_stream_t stream);
+size_t dsrl_mse_workspace_bytes(int64_t n);
+int dsrl_mse_fwd(const float* a, const float* b, int64_t n, float* loss_out, void* ws, size_t ws_bytes, dsrl_stream_t stream);
+int dsrl_mse_bwd(const float* a, const float* b, int64_t n, const float* grad_out, float* da, dsrl_stream_t stream);
+
+/* FALoss (models/losses/FALoss.py:8-34). fm1/fm2 are (B,C,H,W) with element strides (sb,sc,sh,sw).
+ * reduction: 0 mean, 1 sum, 2 none (out has B*C*n*n floats, n = (W/k)^2).
+ * `saved` (>= dsrl_fa_saved_floats) carries S1,S2,sigma,u1,v1 to the backward. */
+size_t dsrl_fa_saved_floats(int B, int C, int H, int W, int k);
+size_t dsrl_fa_workspace_bytes(int B, int C, int H, int W, int k);
+int dsrl_fa_fwd(const float* fm1, const float* fm2, int B, int C, int H, int W, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                int k, int reduction, float* out, float* saved, void* ws, size_t ws_bytes, dsrl_stream_t stream);
+/* mean/sum: grad_out is 1 float; d1/d2 are (B,C,H,W) contiguous */
+int dsrl_fa_bwd(const float* fm1, const float* fm2, int B, int C, int H, int W, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                int k, int reduction, const float* grad_out, const float* saved, float* d1, float* d2,
+                void* ws, size_t ws_bytes, dsrl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * optimiser + bookkeeping on the flat parameter arena (train_or_resume.py:63-66, 445, 426-433)
+ * ---------------------------------------------------------------------------------------------- */
+/* torch.optim.SGD(momentum, weight_decay): d = g*grad_scale + wd*p; buf = mom*buf + d; p -= lr*buf */
+int dsrl_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float weight_decay,
+                  float grad_scale, dsrl_stream_t stream);
+/* flag[0] |= 1 if any element is NaN (the reference's per-output NaN asserts folded into one readback) */
+int dsrl_nan_check(const float* x, int64_t n, int* flag, dsrl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * in-library launch timing (bench.py roofline): when enabled every MFMA conv launch is bracketed by HIP
+ * events on its own stream. dsrl_prof_read() synchronises those events and reports per kernel family
+ * (0 conv fwd/dgrad igemm, 1 conv wgrad) the launch count, summed milliseconds and summed in-bounds FLOPs.
+ * ---------------------------------------------------------------------------------------------- */
+int dsrl_prof_enable(int on);
+int dsrl_prof_read(int family, int64_t* launches, double* total_ms, double* total_flops);
+const char* dsrl_prof_kernel_name(int family);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSRL_HIP_H */

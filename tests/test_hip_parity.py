@@ -1,0 +1,362 @@
+"""GPU parity tests: libdsrl_hip.so (through the ctypes C ABI and the autograd wrappers) against the golden vectors
+captured from the reference and against the numpy oracle.  Tolerance: 1e-3 relative fp32 as BASELINE.json's north_star
+states (most checks are held to 1e-4 or tighter because the MFMA path is exact fp32)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gen                     # noqa: E402
+import oracle as O             # noqa: E402
+from hip_helpers import *      # noqa: E402,F401,F403
+from hip_helpers import DEV, HF, D, check, dev, host, make_head, hip_losses   # noqa: E402
+
+TOL = 1e-3
+
+
+def test_library_loaded_and_device():
+    import ctypes
+    from dualsuperreslearningforsemseg_amd import _lib
+    lib = _lib.load()
+    cu = ctypes.c_int(0)
+    assert lib.dsrl_device_check(ctypes.byref(cu)) == 0, lib.dsrl_last_error()
+    assert cu.value == 256
+
+
+def test_cpu_tensor_is_refused():
+    with pytest.raises(RuntimeError):
+        HF.conv2d(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 1, 1))
+
+
+# --------------------------------------------------------------------------------------------- micro ops vs golden
+CONVS = ['conv_d6', 'conv_d12', 'conv_d18', 'conv_1x1', 'conv_3x3', 'conv_s2', 'conv_7x7s2', 'conv_1x1s2', 'conv_d2']
+
+
+@pytest.mark.parametrize('name', CONVS)
+def test_conv_golden(golden, name):
+    g = golden('ops_micro')
+    stride, pad, dil = [int(v) for v in g[f'{name}.cfg']]
+    x = dev(g[f'{name}.x']).requires_grad_(True)
+    w = dev(g[f'{name}.w']).requires_grad_(True)
+    b = dev(g[f'{name}.b']).requires_grad_(True) if f'{name}.b' in g else None
+    y = HF.conv2d(x, w, b, stride, pad, dil)
+    check(host(y), g[f'{name}.y'], 1e-5, 'y')
+    y.backward(dev(g[f'{name}.dy']))
+    check(host(x.grad), g[f'{name}.dx'], 1e-5, 'dx')
+    check(host(w.grad), g[f'{name}.dw'], 1e-5, 'dw')
+    if b is not None:
+        check(host(b.grad), g[f'{name}.db'], 1e-5, 'db')
+
+
+def test_pointwise_strided_golden(golden):
+    g = golden('ops_micro')
+    x = dev(g['conv_s8.x']).requires_grad_(True); w = dev(g['conv_s8.w']).requires_grad_(True)
+    y = HF.pointwise_strided(x, w, 8)
+    check(host(y), g['conv_s8.y'], 1e-5)
+    y.backward(dev(g['conv_s8.dy']))
+    check(host(x.grad), g['conv_s8.dx'], 1e-5); check(host(w.grad), g['conv_s8.dw'], 1e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 2048, 16, 32, 256, 3, 1, 12, 12), (2, 304, 64, 128, 256, 3, 1, 1, 1), (1, 256, 64, 128, 19, 1, 1, 0, 1),
+                                   (2, 304, 32, 64, 192, 3, 1, 1, 1), (2, 256, 32, 64, 48, 1, 1, 0, 1), (3, 64, 33, 47, 64, 3, 2, 1, 1),
+                                   (8, 2048, 1, 1, 256, 1, 1, 0, 1)])
+def test_conv_vs_oracle_real_shapes(shape):
+    """The shapes the DSRL head really launches (ASPP dilated, cat_conv, cls_conv, SISR, shortcut, a strided backbone conv,
+    the pooled ASPP branch) against the fp64 oracle, forward and both gradients."""
+    N, C, H, W, K, R, stride, pad, dil = shape
+    rs = np.random.RandomState(sum(shape))
+    x = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rs.standard_normal((K, C, R, R)) / np.sqrt(C * R * R)).astype(np.float32)
+    b = rs.standard_normal(K).astype(np.float32)
+    yo = O.conv2d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), stride, pad, dil)
+    dy = rs.standard_normal(yo.shape).astype(np.float32)
+    dxo, dwo, dbo = O.conv2d_bwd(x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64), stride, pad, dil, True)
+    xt = dev(x).requires_grad_(True); wt = dev(w).requires_grad_(True); bt = dev(b).requires_grad_(True)
+    y = HF.conv2d(xt, wt, bt, stride, pad, dil)
+    check(host(y), yo, 2e-5, 'y')
+    y.backward(dev(dy))
+    check(host(xt.grad), dxo, 2e-5, 'dx'); check(host(wt.grad), dwo, 2e-5, 'dw'); check(host(bt.grad), dbo, 2e-5, 'db')
+
+
+def test_conv_into_and_from_channel_slices():
+    """ld > C: reading a channel slice of a wider buffer (the concat layout) gives the same result."""
+    rs = np.random.RandomState(5)
+    buf = dev(rs.standard_normal((2, 96, 8, 16)).astype(np.float32))
+    w = dev((rs.standard_normal((32, 32, 3, 3)) * 0.1).astype(np.float32))
+    a = HF.conv2d(buf[:, 32:64], w, None, 1, 1, 1)
+    b = HF.conv2d(buf[:, 32:64].contiguous(memory_format=torch.channels_last), w, None, 1, 1, 1)
+    assert torch.equal(a, b)
+
+
+def test_convT_golden(golden):
+    g = golden('ops_micro')
+    x = dev(g['convT.x']).requires_grad_(True); w = dev(g['convT.w'], cl=False).requires_grad_(True); b = dev(g['convT.b']).requires_grad_(True)
+    y = HF.conv_transpose2d_k2s2(x, w, b)
+    check(host(y), g['convT.y'], 1e-5)
+    y.backward(dev(g['convT.dy']))
+    check(host(x.grad), g['convT.dx'], 1e-5); check(host(w.grad), g['convT.dw'], 1e-5); check(host(b.grad), g['convT.db'], 1e-5)
+
+
+def test_convT_vs_oracle_ragged():
+    rs = np.random.RandomState(9)
+    x = rs.standard_normal((2, 19, 5, 150)).astype(np.float32); w = rs.standard_normal((19, 19, 2, 2)).astype(np.float32)
+    xt = dev(x).requires_grad_(True); wt = dev(w, cl=False).requires_grad_(True)
+    y = HF.conv_transpose2d_k2s2(xt, wt, None)
+    yo = O.conv_transpose2d_k2s2(x.astype(np.float64), w.astype(np.float64))
+    check(host(y), yo, 1e-5)
+    dy = rs.standard_normal(yo.shape).astype(np.float32)
+    y.backward(dev(dy))
+    dxo, dwo, _ = O.conv_transpose2d_k2s2_bwd(x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64))
+    check(host(xt.grad), dxo, 1e-5); check(host(wt.grad), dwo, 1e-5)
+
+
+@pytest.mark.parametrize('name', ['up2', 'up4', 'up_bcast', 'up_odd'])
+def test_bilinear_golden(golden, name):
+    g = golden('ops_micro')
+    x = dev(g[f'{name}.x']).requires_grad_(True)
+    y = HF.upsample_bilinear_ac(x, g[f'{name}.y'].shape[2:])
+    check(host(y), g[f'{name}.y'], 1e-5)
+    y.backward(dev(g[f'{name}.dy']))
+    check(host(x.grad), g[f'{name}.dx'], 1e-5)
+
+
+def test_pixel_shuffle_golden(golden):
+    g = golden('ops_micro')
+    x = dev(g['pixel_shuffle.x']).requires_grad_(True)
+    y = HF.pixel_shuffle(x, 8)
+    assert np.array_equal(host(y), g['pixel_shuffle.y'])
+    y.backward(dev(g['pixel_shuffle.dy']))
+    assert np.array_equal(host(x.grad), g['pixel_shuffle.dx'])
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_batchnorm_golden(golden, mode):
+    g = golden('ops_micro')
+    p = f'bn_{mode}'
+    bn = D.nn_modules.HipBatchNorm2d(19).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(dev(g[f'{p}.gamma'])); bn.bias.copy_(dev(g[f'{p}.beta']))
+        bn.running_mean.copy_(dev(g[f'{p}.rm0'])); bn.running_var.copy_(dev(g[f'{p}.rv0']))
+    bn.train(mode == 'train')
+    x = dev(g[f'{p}.x']).requires_grad_(True)
+    y = bn(x)
+    check(host(y), g[f'{p}.y'], 1e-5)
+    y.backward(dev(g[f'{p}.dy']))
+    check(host(x.grad), g[f'{p}.dx'], 1e-4); check(host(bn.weight.grad), g[f'{p}.dgamma'], 1e-5); check(host(bn.bias.grad), g[f'{p}.dbeta'], 1e-5)
+    check(host(bn.running_mean), g[f'{p}.rm1'], 1e-5); check(host(bn.running_var), g[f'{p}.rv1'], 1e-5)
+    assert int(bn.state_dict()['num_batches_tracked']) == (1 if mode == 'train' else 0)
+
+
+@pytest.mark.parametrize('C', [1, 19, 48, 256, 304, 2048])
+def test_batchnorm_relu_dropout_residual_vs_oracle(C):
+    rs = np.random.RandomState(C)
+    x = (rs.standard_normal((2, C, 6, 10)) * 2 + 0.5).astype(np.float32); res = rs.standard_normal(x.shape).astype(np.float32)
+    gamma = rs.uniform(0.5, 1.5, C).astype(np.float32); beta = rs.standard_normal(C).astype(np.float32)
+    bn = D.nn_modules.HipBatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(dev(gamma)); bn.bias.copy_(dev(beta))
+    bn.train()
+    xt = dev(x).requires_grad_(True); rt = dev(res).requires_grad_(True)
+    y = HF.batch_norm_act(xt, bn, relu=True, drop_p=0.2, seed=77, rng_stream=5, residual=rt)
+    yo, (mean, invstd), _ = O.batchnorm_train(x.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64))
+    keep = O.dropout_mask(x.shape, 0.2, 77, 5)
+    act = np.maximum(yo + res, 0)
+    check(host(y), act * keep / 0.8, 1e-5, 'y')
+    dy = rs.standard_normal(x.shape).astype(np.float32)
+    y.backward(dev(dy))
+    gpre = dy.astype(np.float64) * keep / 0.8 * (act > 0)
+    dxo, dgo, dbo = O.batchnorm_train_bwd(x.astype(np.float64), gamma.astype(np.float64), mean, invstd, gpre)
+    check(host(xt.grad), dxo, 1e-4, 'dx'); check(host(rt.grad), gpre, 1e-5, 'dres')
+    check(host(bn.weight.grad), dgo, 1e-4, 'dgamma'); check(host(bn.bias.grad), dbo, 1e-4, 'dbeta')
+
+
+def test_dropout_matches_oracle_philox():
+    x = np.random.RandomState(3).standard_normal((2, 19, 16, 32)).astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    y = HF.dropout(xt, 0.2, True, 1234, 3)
+    keep = O.dropout_mask(x.shape, 0.2, 1234, 3)
+    assert np.array_equal(host(y) != 0, keep & (x != 0))
+    check(host(y), x * keep / 0.8, 1e-6)
+    y.backward(torch.ones_like(y))
+    check(host(xt.grad), keep / 0.8, 1e-6)
+
+
+def test_pools_golden(golden):
+    g = golden('ops_micro')
+    x = dev(g['gap.x']).requires_grad_(True)
+    y = HF.global_avg_pool(x); check(host(y), g['gap.y'], 1e-5)
+    y.backward(dev(g['gap.dy'])); check(host(x.grad), g['gap.dx'], 1e-5)
+    x = dev(g['maxpool.x']).requires_grad_(True)
+    y = HF.max_pool3x3s2(x); assert np.array_equal(host(y), g['maxpool.y'])
+    y.backward(dev(g['maxpool.dy'])); check(host(x.grad), g['maxpool.dx'], 1e-6)
+
+
+def test_ce_mse_sgd_golden(golden):
+    g = golden('ops_micro')
+    lg = dev(g['ce.logits']).requires_grad_(True)
+    loss = HF.cross_entropy(lg, dev(g['ce.target']), 255)
+    check(host(loss), g['ce.loss'], 1e-5)
+    loss.backward(); check(host(lg.grad), g['ce.dlogits'], 1e-5)
+    a = dev(g['mse.a']).requires_grad_(True)
+    loss = HF.mse_loss(a, dev(g['mse.b'])); check(host(loss), g['mse.loss'], 1e-5)
+    loss.backward(); check(host(a.grad), g['mse.da'], 1e-5)
+    p = dev(g['sgd.p0']).clone(); buf = torch.zeros_like(p)
+    for step in range(2):
+        HF.sgd_step_(p, dev(g[f'sgd.g{step}']), buf, 0.006, 0.9, 5e-4)
+        check(host(p), g[f'sgd.p{step + 1}'], 1e-6)
+
+
+def test_ce_all_ignored_is_nan_and_nan_check():
+    lg = dev(np.zeros((1, 19, 4, 4), np.float32))
+    loss = HF.cross_entropy(lg, torch.full((1, 4, 4), 255, dtype=torch.uint8, device=DEV), 255)
+    assert torch.isnan(loss)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    HF.nan_check_(flag, lg); assert int(flag) == 0
+    HF.nan_check_(flag, lg, loss.reshape(1)); assert int(flag) == 1
+
+
+# --------------------------------------------------------------------------------------------- FA loss
+@pytest.mark.parametrize('case', ['rand', 'c3', 'big', 'signed', 'relu_like', 'same', 'near_degenerate'])
+def test_fa_golden(golden, case):
+    g = golden('fa_loss')
+    f1 = dev(g[f'{case}.fm1'], cl=False).requires_grad_(True); f2 = dev(g[f'{case}.fm2'], cl=False).requires_grad_(True)
+    for red in ('mean', 'sum'):
+        check(host(D.FALoss(reduction=red)(f1, f2)), g[f'{case}.{red}'], 2e-5, red)
+    none = D.FALoss(reduction='none')(f1, f2)
+    assert tuple(none.shape) == tuple(g[f'{case}.none_shape'])
+    check(gen.strided_sample(host(none)), g[f'{case}.none_sample'], 1e-4, 'none')
+    D.FALoss()(f1, f2).backward()
+    tol = 2e-2 if case == 'near_degenerate' else 2e-3          # sign-count / degenerate sigma_1 sensitivity, as in the oracle test
+    check(host(f1.grad), g[f'{case}.g1'], tol, 'g1'); check(host(f2.grad), g[f'{case}.g2'], 2e-3, 'g2')
+
+
+def test_fa_zero_sample_nan_and_shape_asserts(golden):
+    g = golden('fa_loss')
+    assert torch.isnan(D.FALoss()(dev(g['zero_sample.fm1'], cl=False), dev(g['zero_sample.fm2'], cl=False)))
+    with pytest.raises(AssertionError):
+        D.FALoss()(torch.zeros(2, 1, 8, device=DEV), torch.zeros(2, 1, 8, device=DEV))
+    with pytest.raises(AssertionError):
+        D.FALoss()(torch.zeros(2, 1, 8, 8, device=DEV), torch.zeros(2, 1, 8, 16, device=DEV))
+
+
+# --------------------------------------------------------------------------------------------- composite head
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_head_small_golden(golden, mode):
+    g = golden('head_small')
+    head, _ = make_head(gen.SMALL, 3, 101, mode == 'train')
+    x16, x4, target, org = gen.make_head_inputs(202, 2, 2, 4, gen.SMALL)
+    a = dev(x16).requires_grad_(True); b = dev(x4).requires_grad_(True)
+    outs = head(a, b)
+    for n, o in zip(('SSSR', 'SISR', 'SSSR_ft', 'SISR_ft'), outs):
+        check(host(o), g[f'{mode}.{n}'], 1e-4, n)
+    L = hip_losses(outs, dev(target), dev(org), 3)
+    check(np.array([float(v) for v in L]), g[f'{mode}.losses'], 1e-4, 'losses')
+    L[3].backward()
+    for k, p in head.named_parameters():
+        tol = 2e-3 if 'branches.4.0' not in k else 5e-2       # global-pool branch: train BN over a batch of 2 is ill-conditioned
+        check(host(p.grad), g[f'{mode}.grad.{k}'], tol, 'grad ' + k)
+    check(host(a.grad), g[f'{mode}.grad.backbone_features'], 2e-3); check(host(b.grad), g[f'{mode}.grad.lowlevel_features'], 2e-3)
+    if mode == 'train':
+        sd = head.state_dict()
+        for k, v in sd.items():
+            if 'running_' in k:
+                check(host(v), g[f'train.new.{k}'], 1e-4, k)
+
+
+@pytest.mark.parametrize('stage', [1, 2])
+def test_head_small_stage_gating(golden, stage):
+    g = golden('head_small')
+    head, _ = make_head(gen.SMALL, stage, 101, True)
+    x16, x4, target, org = gen.make_head_inputs(202, 2, 2, 4, gen.SMALL)
+    outs = head(dev(x16), dev(x4))
+    check(host(outs[0]), g[f'stage{stage}.SSSR'], 1e-4)
+    assert not outs[2].is_cuda and outs[2].shape == (1,) and (outs[1].is_cuda == (stage > 1))     # DSRL.py:172-174
+    L = hip_losses(outs, dev(target), dev(org), stage)
+    check(np.array([float(v) for v in L]), g[f'stage{stage}.losses'], 1e-4)
+    L[3].backward()
+    check(host(head.SSSR_decoder['cls_conv'].weight.grad), g[f'stage{stage}.grad.cls_w'], 2e-3)
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_head_fullwidth_golden(golden, mode):
+    g = golden('head_fullwidth')
+    head, _ = make_head(gen.FULL, 3, 303, mode == 'train')
+    x16, x4, target, org = gen.make_head_inputs(404, 2, 4, 8, gen.FULL)
+    outs = head(dev(x16), dev(x4))
+    check(gen.strided_sample(host(outs[0]), 65536), g[f'{mode}.SSSR_sample'], TOL)
+    assert np.array_equal(host(outs[0]).argmax(axis=1), g[f'{mode}.SSSR_argmax'])
+    check(gen.strided_sample(host(outs[1]), 16384), g[f'{mode}.SISR_sample'], TOL)
+    check(host(outs[2]), g[f'{mode}.SSSR_ft'], TOL); check(host(outs[3]), g[f'{mode}.SISR_ft'], TOL)
+    L = hip_losses(outs, dev(target), dev(org), 3)
+    check(np.array([float(v) for v in L]), g[f'{mode}.losses'], TOL)        # eval: FA (and total) are NaN in the reference too
+    if mode == 'train':
+        L[3].backward()
+        for k, p in head.named_parameters():
+            gr = host(p.grad)
+            if f'train.grad.{k}' in g:
+                check(gr, g[f'train.grad.{k}'], 3e-3, 'grad ' + k)
+            else:
+                check(gen.strided_sample(gr, 4096), g[f'train.gradsample.{k}'], 3e-3, 'gradsample ' + k)
+
+
+def test_head_256x512_golden(golden):
+    """BASELINE.json's size: 256x512 input -> 512x1024 logits, B=2, eval: identical argmax map, logits within 1e-3."""
+    g = golden('head_256x512')
+    head, _ = make_head(gen.FULL, 3, 505, False)
+    x16, x4, target, org = gen.make_head_inputs(606, 2, 16, 32, gen.FULL)
+    with torch.no_grad():
+        outs = head(dev(x16), dev(x4))
+        L = hip_losses(outs, dev(target), dev(org), 3)
+    sssr = host(outs[0])
+    check(gen.strided_sample(sssr, 1 << 17), g['SSSR_sample'], TOL)
+    am = sssr.argmax(axis=1).astype(np.uint8)
+    diff = am != g['SSSR_argmax']
+    # a flip is tolerated only where the reference's own top-2 margin is below fp32 resolution of the logits
+    assert not np.any(diff & (g['margin_u8'] > 0)), f'{int(diff.sum())} argmax flips outside near-ties'
+    assert diff.mean() < 1e-5
+    check(gen.checksum(sssr)[:2], g['SSSR_sum'][:2], 1e-4)
+    check(gen.strided_sample(host(outs[1]), 1 << 15), g['SISR_sample'], TOL)
+    check(host(outs[2]), g['SSSR_ft'], TOL); check(host(outs[3]), g['SISR_ft'], TOL)
+    check(np.array([float(v) for v in L]), g['losses'], TOL)
+    pix, mean = O.miou_batch(am, target), O.miou_batch(g['SSSR_argmax'], target)
+    assert abs(pix[0] - mean[0]) < 1e-3 and abs(pix[1] - mean[1]) < 1e-3      # "mIoU vs ref" on the argmax maps
+
+
+def test_head_train_with_dropout_vs_oracle():
+    """Full train mode (batch-stat BN AND the four Dropout(0.2) modules live): HIP vs the fp64 oracle driven by the same
+    Philox keys - the case the reference itself cannot be compared on (torch's RNG stream differs)."""
+    head, P = make_head(gen.SMALL, 3, 101, True, dropout=True)
+    x16, x4, target, org = gen.make_head_inputs(202, 2, 2, 4, gen.SMALL)
+    HF.set_dropout_seed(4242)
+    seed = HF.peek_next_seed()
+    a = dev(x16).requires_grad_(True)
+    outs = head(a, dev(x4))
+    L = hip_losses(outs, dev(target), dev(org), 3)
+    L[3].backward()
+    out = O.head_forward({k: v.astype(np.float64) for k, v in P.items()}, x16.astype(np.float64), x4.astype(np.float64), 3, True, dropout_seed=seed)
+    Lo = O.total_loss(out, target, org.astype(np.float64), 3)
+    check(host(outs[0]), out.SSSR.v, 1e-4, 'SSSR'); check(np.array([float(v) for v in L]), np.array(Lo), 1e-4, 'losses')
+    for k, p in head.named_parameters():
+        if 'branches.4.0' not in k:
+            check(host(p.grad), out.params[k].g, 2e-3, 'grad ' + k)
+    check(host(a.grad), out.inputs[0].g, 2e-3)
+
+
+def test_train_steps_golden(golden):
+    """Two SGD steps of the small head on the flat-arena optimiser reproduce the reference's parameters."""
+    from dualsuperreslearningforsemseg_amd.ddp import FlatParams
+    g = golden('train_steps')
+    head, _ = make_head(gen.SMALL, 3, 101, True)
+    flat = FlatParams(head)
+    for step in range(2):
+        x16, x4, target, org = gen.make_head_inputs(700 + step, 2, 2, 4, gen.SMALL)
+        flat.zero_grad()
+        outs = head(dev(x16), dev(x4))
+        L = hip_losses(outs, dev(target), dev(org), 3)
+        L[3].backward()
+        flat.sgd_step(lr=0.006, momentum=0.9, weight_decay=5e-4)
+        check(np.array([float(v) for v in L]), g[f'step{step}.losses'], 2e-4)
+        for k, v in head.state_dict().items():
+            if 'num_batches' not in k:
+                check(host(v), g[f'step{step}.{k}'], 2e-4, f'step{step} {k}')
