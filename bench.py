@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Headline benchmark: stage-3 DSRL training images/sec at 256x512 -> 512x1024 (BASELINE.json), synthetic device-resident
+Cityscapes-shaped batches, per-rank batch 8 (train_stage3_cmdline.json), one process per GPU, gradients all-reduced over
+RCCL.  A "step" = forward (ResNet-101 + ASPP + SSSR/SISR decoders + feature transformers) + CE/MSE/FA losses + backward +
+gradient reduction + SGD update + the per-iteration loss/NaN readback, exactly what train_or_resume() runs per batch.
+
+    python bench.py [--gpus N --steps K --warmup W]           (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     - the dominant kernel (the MFMA implicit-GEMM conv): achieved in-bounds TFLOP/s from HIP events recorded by the
+                 library around every launch inside the timed region, against the 157.3 TFLOP/s dense fp32-MFMA peak;
+  cpu_baseline - the numpy oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def cpu_baseline(budget_note=True):
+    """Stage-3 head forward + losses + backward of the numpy oracle, B=2 at 256x512 (fp32), on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import numpy as np
+    import gen
+    import oracle as O
+    P = gen.make_head_params(505, gen.FULL, 3)
+    x16, x4, target, org = gen.make_head_inputs(606, 2, 16, 32, gen.FULL)
+    t0 = time.time()
+    out = O.head_forward(P, x16, x4, 3, True)
+    O.total_loss(out, target, org, 3)
+    dt = time.time() - t0
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    return {'value': round(2.0 / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': 'numpy oracle (fp32, BLAS threads = cores): DSRL head only (ASPP + decoders + transformers, no ResNet-101) '
+                      f'forward + CE/MSE/FA + backward, B=2 at 256x512->512x1024, one pass = {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='per-rank batch (train_stage3_cmdline.json: 8)')
+    ap.add_argument('--height', type=int, default=256)
+    ap.add_argument('--width', type=int, default=512)
+    ap.add_argument('--stage', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f'--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank, device_id=dev)
+
+    import dualsuperreslearningforsemseg_amd as D
+    from dualsuperreslearningforsemseg_amd import _lib, settings
+    from dualsuperreslearningforsemseg_amd.command_handlers.train_or_resume import SyntheticCityscapes, TrainStep
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    from dualsuperreslearningforsemseg_amd.ddp import FlatParams
+    lib = _lib.load()
+
+    torch.manual_seed(settings.RANDOM_SEED)                      # identical initial weights on every rank (train_or_resume.py:31)
+    model = D.DSRL(args.stage, cs)
+    with torch.no_grad():                                        # random-init stand-in for the ImageNet backbone: un-zero the residual BNs
+        for m in model.modules():
+            if hasattr(m, 'bn3'):
+                m.bn3.weight.fill_(0.5)
+    model = model.to(dev).to(memory_format=torch.channels_last).train()
+    flat = FlatParams(model)
+    step = TrainStep(model, flat, args.stage, 0.1, 1.0, cs.IGNORE_CLASS_LABEL)
+    data = SyntheticCityscapes(args.batch, (args.height, args.width), dev, rank=rank, length=1)
+    (img, org), (tgt, _) = next(iter(data))
+    hp = dict(lr=0.006, momentum=0.9, weight_decay=5e-4)        # train_stage3_cmdline.json
+
+    def run(n):
+        last = None
+        for _ in range(n):
+            last, _ = step(img, org, tgt, hp['lr'], hp['momentum'], hp['weight_decay'], True)
+        return last
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if not args.no_prof:
+        lib.dsrl_prof_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+
+    roof = None
+    if not args.no_prof:
+        fams = []
+        for fam in (0, 1):
+            n = ctypes.c_int64(0); ms = ctypes.c_double(0); fl = ctypes.c_double(0)
+            _lib.check(lib.dsrl_prof_read(fam, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), 'dsrl_prof_read')
+            fams.append((lib.dsrl_prof_kernel_name(fam).decode(), n.value, ms.value, fl.value))
+        lib.dsrl_prof_enable(0)
+        name, n, ms, fl = max(fams, key=lambda f: f[2])          # dominant = most device time
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                'traffic': None, 'kernel': name, 'launches_per_step': n // max(args.steps, 1), 'avg_launch_ms': round(ms / max(n, 1), 5),
+                'avg_launch_gflop': round(fl / max(n, 1) / 1e9, 3), 'kernel_ms_per_step': round(ms / args.steps, 3),
+                'all_mfma_kernels': {f[0]: {'ms_per_step': round(f[2] / args.steps, 3), 'tflops': round(f[3] / (f[2] * 1e-3) / 1e12, 2) if f[2] > 0 else 0.0}
+                                     for f in fams}}
+
+    if rank == 0:
+        gb = args.batch * world
+        line = {
+            'metric': 'stage-3 train images/sec at 256x512->512x1024' if (args.stage, args.height, args.width) == (3, 256, 512)
+                      else f'stage-{args.stage} train images/sec at {args.height}x{args.width}',
+            'value': round(gb * args.steps / elapsed, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'DSRL stage {args.stage} (ResNet-101 OS16 + ASPP + SSSR/SISR decoders + FA loss), full train step, '
+                                   f'random-init weights, {args.height}x{args.width} input -> {2 * args.height}x{2 * args.width} logits',
+                       'global_batch': gb, 'per_gpu_batch': args.batch, 'parallelism': f'dp{world}', 'optimizer': 'SGD m0.9 wd5e-4 lr0.006',
+                       'losses_last_step': [round(v, 5) for v in losses]},
+            'roofline': roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

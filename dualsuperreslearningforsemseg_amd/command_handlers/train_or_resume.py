@@ -1,0 +1,218 @@
+"""Stage-1/2/3 training driver on the MI355X kernels - counterpart of the reference's
+command_handlers/train_or_resume.py (same `train_or_resume(...)` signature, same seeding, SGD hyper-parameters, loss mix,
+per-epoch polynomial LR, per-rank batch size, mean-reduced gradients and `final.weights` / `.checkpoint` dict formats).
+
+What differs by design:
+  * gradients are reduced and the SGD update applied on flat arenas (ddp.FlatParams) over RCCL instead of torch DDP buckets;
+  * the reference's 8 blocking device->host reads and 3 host-side NaN scans per iteration (train_or_resume.py:406-451) are
+    folded into ONE readback of [CE, MSE, FA, Total, nan_flag] per iteration with the same abort-on-NaN behaviour;
+  * apex mixed precision (`mixed_precision`) is not available: the kernels are fp32 and a non-empty value is rejected;
+  * the input pipeline (torchvision Cityscapes + PIL transforms) is out of scope: `dataset` may carry a 'loader_factory'
+    (callable(split, batch_size, device, rank, world) -> iterable of ((input_image, input_org), (target, _))) and
+    `SyntheticCityscapes` below provides device-resident batches of the Cityscapes shapes.
+"""
+import os
+from datetime import datetime
+
+import torch as t
+import torch.distributed as dist
+
+from .. import functional as HF
+from .. import settings
+from ..ddp import FlatParams
+from ..models import DSRL
+from ..models.losses import FALoss
+
+
+def isCUDAdevice(device):
+    return device.casefold() == 'gpu'
+
+
+def polynomial_lr(base_lr, end_lr, epoch, max_decay_steps, power):
+    """models/schedulers/PolynomialLR.py:22-34: lr used during `epoch` (0-based); epoch 0 keeps the base lr."""
+    if epoch <= 0:
+        return base_lr
+    return (base_lr - end_lr) * ((1. - epoch / max_decay_steps) ** power) + end_lr
+
+
+class SyntheticCityscapes:
+    """Device-resident synthetic batches of the shapes JointScaledImage produces (models/transforms/JointScaledImage.py:27-32):
+    input_org ~ N(0,1) at the output size, input_image = align-corners bilinear resize of it to the input size,
+    target uint8 in [0,19) with ~10 % of the pixels set to the ignore label."""
+
+    def __init__(self, batch_size, input_size, device, rank=0, length=8, num_classes=19, ignore=255, distinct=1):
+        g = t.Generator(device='cpu').manual_seed(1234 + rank)
+        H, W = input_size
+        self.batches = []
+        for _ in range(distinct):
+            org = t.randn((batch_size, 3, 2 * H, 2 * W), generator=g).to(device).contiguous(memory_format=t.channels_last)
+            tgt = t.randint(0, num_classes, (batch_size, 2 * H, 2 * W), generator=g, dtype=t.uint8)
+            tgt[t.rand(tgt.shape, generator=g) < 0.1] = ignore
+            img = HF.upsample_bilinear_ac(org, (H, W))
+            self.batches.append(((img, org), (tgt.to(device), None)))
+        self.length = length
+
+    def __len__(self):
+        return self.length
+
+    def __iter__(self):
+        for i in range(self.length):
+            yield self.batches[i % len(self.batches)]
+
+
+class TrainStep:
+    """One iteration of train_or_resume.py:404-460 for a fixed model/arena."""
+
+    def __init__(self, model, flat, stage, w1, w2, ignore_index):
+        self.model, self.flat, self.stage, self.w1, self.w2, self.ignore = model, flat, stage, w1, w2, ignore_index
+        self.fa = FALoss()
+        dev = flat.device
+        self.flag = t.zeros(1, dtype=t.int32, device=dev)
+        self.zero = t.zeros((), device=dev)
+
+    def losses(self, outs, input_org, target):
+        SSSR, SISR, SSSR_ft, SISR_ft = outs
+        ce = HF.cross_entropy(SSSR, target, self.ignore)                                   # train_or_resume.py:435
+        ms = self.w1 * HF.mse_loss(SISR, input_org) if self.stage > 1 else self.zero       # :436
+        fa = self.w2 * self.fa(SSSR_ft, SISR_ft) if self.stage > 2 else self.zero          # :437
+        return ce, ms, fa, ce + ms + fa                                                    # :438
+
+    def __call__(self, input_image, input_org, target, lr, momentum, weight_decay, do_train=True):
+        flat = self.flat
+        if do_train:
+            flat.zero_grad()                                                               # optimizer.zero_grad(), :418
+            flat.sync_buffers()
+        self.flag.zero_()
+        with t.set_grad_enabled(do_train):
+            outs = self.model(input_image)                                                 # :420
+            HF.nan_check_(self.flag, *[o for o in outs if o.is_cuda])                      # the four NaN asserts, :426-433
+            ce, ms, fa, total = self.losses(outs, input_org, target)
+            if do_train:
+                total.backward()                                                           # :444 (chunked RCCL all-reduce overlaps)
+                flat.sgd_step(lr, momentum, weight_decay)                                  # :445
+        vals = t.cat([t.stack([ce, ms, fa, total]).detach().float(), self.flag.float()]).cpu()   # ONE device->host read
+        if vals[4] != 0:
+            raise AssertionError("network output contains 'NaN' values and so cannot continue.")
+        return [float(v) for v in vals[:4]], outs
+
+
+def _get_state_dict(model):
+    return model.state_dict()
+
+
+def train_or_resume(is_resuming_training, device, distributed, mixed_precision, disable_cudnn_benchmark, num_workers, dataset, val_interval,
+                    checkpoint_interval, checkpoint_history, init_weights, batch_size, epochs, learning_rate, end_learning_rate, momentum,
+                    weights_decay, poly_power, stage, w1, w2, freeze_batch_norm, experiment_id, description, early_stopping, dry_run=False, **other_args):
+    if not isCUDAdevice(device):
+        raise RuntimeError("this build runs on the MI355X only: use device='gpu' (the reference's --device cpu path is its own)")
+    if mixed_precision:
+        raise RuntimeError('apex mixed precision is not available: the HIP kernels are fp32')
+    input_size = other_args.get('model_input_size', settings.MODEL_INPUT_SIZE)
+    if distributed:
+        t.manual_seed(settings.RANDOM_SEED)                                                # identical init on all ranks, :31
+        if not dist.is_initialized():
+            dist.init_process_group(distributed['BACKEND'], distributed['INIT_METHOD'], world_size=distributed['WORLD_SIZE'], rank=distributed['RANK'])
+        if not dist.is_initialized():
+            raise RuntimeError("Couldn't initialize distributed process group!")
+        is_master_rank = (distributed['RANK'] == 0)
+        device_obj = t.device('cuda', distributed['DEVICE_ID'])
+        rank, world = distributed['RANK'], distributed['WORLD_SIZE']
+    else:
+        is_master_rank, device_obj, rank, world = True, t.device('cuda', t.cuda.current_device()), 0, 1
+    t.cuda.set_device(device_obj)
+    if is_master_rank:
+        process_start_timestamp = datetime.now()
+        best_validation_dict = other_args['best_validation_dict'] if is_resuming_training else {'epoch': -1, 'best_miou_percent': 0., 'loss': 0.}
+
+    ds = dataset['settings']
+    model = DSRL(stage, ds)                                                                # :62
+    if is_resuming_training:
+        model.load_state_dict(other_args['model_state_dict'], strict=True)
+        starting_epoch = other_args['epoch']
+    else:
+        starting_epoch = 0
+        if init_weights:
+            model.load_state_dict(t.load(init_weights, map_location='cpu')['model_state_dict'], strict=False)
+        elif stage == 1:
+            if other_args.get('pretrained_backbone', True):
+                model.initialize_with_pretrained_weights(settings.WEIGHTS_ROOT_DIR)
+        else:
+            prev = os.path.join(experiment_id, settings.WEIGHTS_DIR.format(stage=stage - 1), settings.FINAL_WEIGHTS_FILE)
+            if os.path.isfile(prev):
+                model.load_state_dict(t.load(prev, map_location='cpu')['model_state_dict'], strict=False)      # :91-96
+            elif other_args.get('pretrained_backbone', True):
+                model.initialize_with_pretrained_weights(settings.WEIGHTS_ROOT_DIR)
+    model = model.to(device_obj).to(memory_format=t.channels_last)                        # :103 (+ kernel weight layout)
+    flat = FlatParams(model)                                                               # DDP wrap, :105-106
+    if is_resuming_training and 'optimizer_state_dict' in other_args:
+        flat.load_state_dict(other_args['optimizer_state_dict'])
+    step = TrainStep(model, flat, stage, w1, w2, ds.IGNORE_CLASS_LABEL)
+
+    factory = dataset.get('loader_factory')
+    if factory is None:
+        os.makedirs(dataset['path'], exist_ok=True)
+        if len(os.listdir(dataset['path'])) == 0:
+            raise Exception("Cityscapes dataset was not found under '{:s}'.".format(dataset['path']))
+        raise NotImplementedError("the torchvision/PIL input pipeline is out of scope here: pass dataset['loader_factory']")
+    train_loader = factory('train', batch_size, device_obj, rank, world)
+    val_loader = factory('val', batch_size, device_obj, rank, world) if is_master_rank else None
+
+    history = []
+    for epoch in range(starting_epoch + 1, epochs + 1):
+        lr = polynomial_lr(learning_rate, end_learning_rate, epoch - 1, epochs, poly_power)       # scheduler.step() per epoch, :349
+        means = _do_train_val(True, epoch, model, step, train_loader, lr, momentum, weights_decay, freeze_batch_norm, is_master_rank)
+        rec = {'epoch': epoch, 'lr': lr, 'train': means}
+        if is_master_rank:
+            if epoch % checkpoint_interval == 0 and experiment_id:
+                ckpt_dir = os.path.join(experiment_id, settings.CHECKPOINTS_DIR.format(stage=stage))
+                os.makedirs(ckpt_dir, exist_ok=True)
+                t.save({'device': device, 'mixed_precision': mixed_precision, 'amp_state_dict': None, 'batch_size': batch_size, 'epochs': epochs,
+                        'learning_rate': learning_rate, 'end_learning_rate': end_learning_rate, 'momentum': momentum, 'weights_decay': weights_decay,
+                        'poly_power': poly_power, 'stage': stage, 'w1': w1, 'w2': w2, 'freeze_batch_norm': freeze_batch_norm,
+                        'experiment_id': experiment_id, 'description': description, 'early_stopping': early_stopping, 'epoch': epoch,
+                        'best_validation_dict': best_validation_dict, 'CE_train_avg_loss': means[0], 'MSE_train_avg_loss': means[1],
+                        'FA_train_avg_loss': means[2], 'Avg_train_loss': means[3], 'model_state_dict': _get_state_dict(model),
+                        'optimizer_state_dict': flat.state_dict()}, os.path.join(ckpt_dir, settings.CHECKPOINT_FILE.format(epoch=epoch)))
+            if val_loader is not None and epoch % val_interval == 0:
+                rec['val'] = _do_train_val(False, epoch, model, step, val_loader, lr, momentum, weights_decay, False, True)
+                if rec['val'][4] > best_validation_dict['best_miou_percent']:
+                    best_validation_dict = {'epoch': epoch, 'best_miou_percent': rec['val'][4], 'loss': rec['val'][3]}
+        history.append(rec)
+    if is_master_rank and experiment_id:
+        wdir = os.path.join(experiment_id, settings.WEIGHTS_DIR.format(stage=stage))
+        os.makedirs(wdir, exist_ok=True)
+        t.save({'model_state_dict': _get_state_dict(model), 'mixed_precision': mixed_precision, 'amp_state_dict': None},
+               os.path.join(wdir, settings.FINAL_WEIGHTS_FILE))                               # utils.py:277-282
+        history.append({'elapsed': str(datetime.now() - process_start_timestamp)})
+    return history
+
+
+def _do_train_val(do_train, epoch, model, step, data_loader, lr, momentum, weights_decay, freeze_batch_norm, is_master_rank):
+    """train_or_resume.py:373-533 without the progress-bar / TensorBoard plumbing. Returns the running means
+    (CE, MSE, FA, Total, mIoU %, accuracy %); the last two only for validation."""
+    model.train(mode=do_train)
+    if do_train and freeze_batch_norm:
+        for m in model.modules():
+            if isinstance(m, t.nn.modules.batchnorm._BatchNorm):
+                m.eval()                                                                   # :379-382
+    sums, n = [0., 0., 0., 0.], 0
+    nc = model.SSSR_decoder['cls_conv'].out_channels
+    inter = t.zeros(nc, dtype=t.float64); union = t.zeros(nc, dtype=t.float64); correct = total = 0
+    for (input_image, input_org), (target, _) in data_loader:
+        vals, outs = step(input_image, input_org, target, lr, momentum, weights_decay, do_train)
+        b = input_image.shape[0]
+        for i in range(4):
+            sums[i] += vals[i] * b                                                         # AverageMeter.update(value, batch), :457-460
+        n += b
+        if not do_train and is_master_rank:
+            pred = t.argmax(outs[0], dim=1)                                                # :476
+            valid = target != step.ignore
+            tg = target.long()
+            for c in range(nc):                                                            # metrices/mIoU.py:15-41 (sum-intersection / sum-union)
+                p_, t_ = (pred == c) & valid, (tg == c) & valid
+                inter[c] += float((p_ & t_).sum()); union[c] += float((p_ | t_).sum())
+            correct += float(((pred == tg) & valid).sum()); total += float(valid.sum())
+    means = [s / max(n, 1) for s in sums]
+    miou = float(100.0 * inter.sum() / max(float(union.sum()), 1.0)) if not do_train else 0.0
+    acc = 100.0 * correct / max(total, 1.0) if not do_train else 0.0
+    return means + [miou, acc]

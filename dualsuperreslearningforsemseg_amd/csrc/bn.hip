@@ -7,7 +7,7 @@
 
 namespace dsrl {
 
-constexpr int kMaxRowBlocks = 1024;
+constexpr int kMaxRowBlocks = 512;
 
 static int row_blocks(int64_t P) { return (int)std::max<int64_t>(1, std::min<int64_t>(kMaxRowBlocks, ceil_div(P, 64))); }
 
@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     if (m.c >= 0) {
         long long p = row0 + m.slot;
         if (p < row1) k0 = x[p * ld + m.c];
+#pragma unroll 4
         for (; p < row1; p += m.G) {
             const float d = x[p * ld + m.c] - k0;
             s1 += d; s2 += d * d; n += 1.f;
@@ -49,16 +50,33 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nbx, int C, float eps, float momentum,
+// 256 threads = 32 channels x 8 slices of the row blocks; slices are merged through LDS in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nbx, int C, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rm, float* __restrict__ rv) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sh[3][8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double na = 0, ma = 0, qa = 0;
-    for (int b = 0; b < nbx; ++b) {
-        const long long o = (long long)b * C + c;
-        const double nb = part[o];
+    if (c < C) {
+        for (int b = sl; b < nbx; b += 8) {
+            const long long o = (long long)b * C + c;
+            const double nb = part[o];
+            if (nb > 0) {
+                const double mb = part[(long long)nbx * C + o], qb = part[2ll * nbx * C + o];
+                const double nt = na + nb, d = mb - ma;
+                ma += d * (nb / nt);
+                qa += qb + d * d * (na * nb / nt);
+                na = nt;
+            }
+        }
+    }
+    sh[0][sl][cl] = na; sh[1][sl][cl] = ma; sh[2][sl][cl] = qa;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    for (int s2 = 1; s2 < 8; ++s2) {
+        const double nb = sh[0][s2][cl];
         if (nb > 0) {
-            const double mb = part[(long long)nbx * C + o], qb = part[2ll * nbx * C + o];
+            const double mb = sh[1][s2][cl], qb = sh[2][s2][cl];
             const double nt = na + nb, d = mb - ma;
             ma += d * (nb / nt);
             qa += qb + d * d * (na * nb / nt);
@@ -116,6 +134,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         const float mu = mean[m.c], is = invstd[m.c];
         const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
         const bool need_y = relu || drop_p > 0.f;
+#pragma unroll 4
         for (long long p = row0 + m.slot; p < row1; p += m.G) {
             const float g = masked_grad(dy[p * lddy + m.c], need_y ? y[p * ldy + m.c] : 1.f, relu, drop_p, ks);
             sg += g; sgx += g * ((x[p * ldx + m.c] - mu) * is);
@@ -131,12 +150,18 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 }
 
 // sums[0][c] = dbeta, sums[1][c] = dgamma (fp32 copies also written to the parameter gradients)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nbx, int C, float* __restrict__ sums,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nbx, int C, float* __restrict__ sums,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sh[2][8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double a = 0, b = 0;
-    for (int i = 0; i < nbx; ++i) { a += part[(long long)i * C + c]; b += part[(long long)nbx * C + (long long)i * C + c]; }
+    if (c < C)
+        for (int i = sl; i < nbx; i += 8) { a += part[(long long)i * C + c]; b += part[(long long)nbx * C + (long long)i * C + c]; }
+    sh[0][sl][cl] = a; sh[1][sl][cl] = b;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    for (int s2 = 1; s2 < 8; ++s2) { a += sh[0][s2][cl]; b += sh[1][s2][cl]; }
     sums[c] = (float)a; sums[C + c] = (float)b;
     if (dbeta) dbeta[c] = (float)a;
     if (dgamma) dgamma[c] = (float)b;
@@ -177,11 +202,16 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         part[(long long)blockIdx.x * C + m.c] = s;
     }
 }
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nbx, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nbx, int C, float* __restrict__ out) {
+    __shared__ double sh[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double a = 0;
-    for (int i = 0; i < nbx; ++i) a += part[(long long)i * C + c];
+    if (c < C) for (int i = sl; i < nbx; i += 8) a += part[(long long)i * C + c];
+    sh[sl][cl] = a;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    for (int s2 = 1; s2 < 8; ++s2) a += sh[s2][cl];
     out[c] = (float)a;
 }
 
@@ -220,7 +250,7 @@ extern "C" int dsrl_bn_stats(const float* x, int ldx, int64_t P, int C, float ep
     const long long rpb = ceil_div(P, nbx);
     hipLaunchKernelGGL(bn_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ldx, (long long)P, C, rpb, (float*)ws, nbx);
     if (int e = launch_status("bn_partial_kernel")) return e;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, (const float*)ws, nbx, C, eps, momentum, mean, invstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, st, (const float*)ws, nbx, C, eps, momentum, mean, invstd, running_mean, running_var);
     return launch_status("bn_finalize_kernel");
 }
 
@@ -259,7 +289,7 @@ extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, con
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, (long long)P, C, rpb,
                        mean, invstd, relu, drop_p, part, nbx);
     if (int e = launch_status("bn_bwd_partial_kernel")) return e;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, (const float*)part, nbx, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, st, (const float*)part, nbx, C, sums, dgamma, dbeta);
     if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, apply_grid(P, C), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (long long)P, C,
                        mean, invstd, gamma, (const float*)sums, relu, drop_p, training);
@@ -274,7 +304,7 @@ extern "C" int dsrl_colsum(const float* x, int ld, int64_t P, int C, float* out,
     const int nbx = row_blocks(P);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ld, (long long)P, C, (long long)ceil_div(P, nbx), (float*)ws);
     if (int e = launch_status("colsum_partial_kernel")) return e;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, (const float*)ws, nbx, C, out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, st, (const float*)ws, nbx, C, out);
     return launch_status("colsum_finalize_kernel");
 }
 

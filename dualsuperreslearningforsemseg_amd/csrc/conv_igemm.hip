@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs a) 
             bool ok = b_cok && p < a.P;
             long long off = 0;
             if (ok) {
-                const int n = (int)(p / HoWo), rem = (int)(p - (long long)n * HoWo);
+                const int pi = (int)p;
+                const int n = pi / HoWo, rem = pi - n * HoWo;
                 const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
                 const int hi = ho * a.stride + dh, wi = wo * a.stride + dw_;
                 ok = hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
@@ -373,12 +374,18 @@ struct ProfRec { hipEvent_t a, b; int family; double flops; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_event_pool;      // events are recycled: recording costs ~1 us, creating them much more
+static hipEvent_t prof_event() {
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
 struct ProfScope {
     bool on; ProfRec r; hipStream_t s;
     ProfScope(int family, double flops, hipStream_t st) : on(g_prof_on), s(st) {
         if (!on) return;
         r.family = family; r.flops = flops;
-        hipEventCreate(&r.a); hipEventCreate(&r.b);
+        r.a = prof_event(); r.b = prof_event();
         hipEventRecord(r.a, s);
     }
     ~ProfScope() {
@@ -568,6 +575,7 @@ extern "C" int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int l
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
     const WgPlan p = plan_wgrad(N, H, W, C, K, R, S, stride, pad, dil);
+    DSRL_REQUIRE(p.P < (1ll << 31), DSRL_E_UNSUPPORTED, "conv2d_wgrad: more than 2^31 output pixels");
     DSRL_REQUIRE(ws_bytes >= p.ws && (p.ws == 0 || ws), DSRL_E_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, p.ws);
     const int RS = R * S;
     if (p.tl.n < RS) {      // taps that only ever see zero padding have a zero gradient
@@ -602,7 +610,7 @@ extern "C" int dsrl_prof_enable(int on) {
     std::lock_guard<std::mutex> g(g_prof_mu);
     g_prof_on = on != 0;
     if (on) {
-        for (auto& r : g_prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+        for (auto& r : g_prof) { g_event_pool.push_back(r.a); g_event_pool.push_back(r.b); }
         g_prof.clear();
     }
     return DSRL_OK;

@@ -301,12 +301,17 @@ __global__ __launch_bounds__(256) void convt2x2_dw_kernel(const float* __restric
     }
 }
 template <int CI, int CO>
-__global__ void convt2x2_dw_finalize_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ dw, float* __restrict__ db) {
+__global__ __launch_bounds__(256) void convt2x2_dw_finalize_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ dw, float* __restrict__ db) {
     constexpr int NOUT = CI * CO * 4;
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= NOUT + CO) return;
+    __shared__ double sh[8][32];
+    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int o = blockIdx.x * 32 + ol;
     double s = 0;
-    for (int b = 0; b < nblocks; ++b) s += part[(long long)b * (NOUT + CO) + o];
+    if (o < NOUT + CO) for (int b = sl; b < nblocks; b += 8) s += part[(long long)b * (NOUT + CO) + o];
+    sh[sl][ol] = s;
+    __syncthreads();
+    if (sl != 0 || o >= NOUT + CO) return;
+    for (int s2 = 1; s2 < 8; ++s2) s += sh[s2][ol];
     if (o < NOUT) {
         const int ci = o / (4 * CO), col = o % (4 * CO), ij = col / CO, co = col % CO;
         dw[(ci * CO + co) * 4 + ij] = (float)s;
@@ -454,7 +459,7 @@ extern "C" int dsrl_convt2x2_bwd(const float* x, const float* w, const float* dy
     if (int e = launch_status("convt2x2_dx_kernel")) return e;                                                                      \
     hipLaunchKernelGGL((convt2x2_dw_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, x, dy, (float*)ws, N, H, W, nseg_per_row, nseg);   \
     if (int e = launch_status("convt2x2_dw_kernel")) return e;                                                                      \
-    hipLaunchKernelGGL((convt2x2_dw_finalize_kernel<CI, CO>), dim3((unsigned)ceil_div(CI * CO * 4 + CO, 256)), dim3(256), 0, st,    \
+    hipLaunchKernelGGL((convt2x2_dw_finalize_kernel<CI, CO>), dim3((unsigned)ceil_div(CI * CO * 4 + CO, 32)), dim3(256), 0, st,     \
                        (const float*)ws, nb, dw, dbias);                                                                            \
     return launch_status("convt2x2_dw_finalize_kernel");
     DSRL_CONVT_DISPATCH(19, 19, DSRL_CONVT_BWD_BODY)

@@ -1,0 +1,74 @@
+"""World-size-2 gloo test of the flat-arena gradient reducer (ddp.FlatParams) on CPU: the arena views alias the parameters,
+rank 0's weights win at construction, chunked asynchronous all-reduce from the autograd hooks produces the mean gradient,
+and the fused SGD kernel refuses to run without a GPU (no CPU fallback)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from dualsuperreslearningforsemseg_amd.ddp import FlatParams
+        torch.manual_seed(100 + rank)                       # deliberately different init per rank
+        model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 1))
+        model = model.to(memory_format=torch.channels_last)
+        flat = FlatParams(model, chunk_bytes=64)           # tiny chunks -> several collectives
+        assert len(flat.chunks) >= 2
+        w0 = [p.detach().clone() for p in model.parameters()]
+        gathered = [torch.zeros_like(flat.p_flat) for _ in range(world)]
+        dist.all_gather(gathered, flat.p_flat)
+        assert torch.equal(gathered[0], gathered[1]), 'constructor broadcast did not equalise the weights'
+        for p in model.parameters():
+            assert p.data_ptr() >= flat.p_flat.data_ptr() and p.grad.data_ptr() >= flat.g_flat.data_ptr()
+        # per-rank batch; reference = single process on the concatenated batch with BN in eval (BN is unsynced in the reference)
+        model.eval()
+        torch.manual_seed(7)
+        xs = torch.randn(world, 2, 3, 8, 8)
+        flat.zero_grad()
+        model(xs[rank]).square().mean().backward()
+        flat.finish_reduction()
+        mean_grad = flat.g_flat / world
+        ref = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 1)).eval()
+        ref.load_state_dict(model.state_dict())
+        ref(xs.reshape(world * 2, 3, 8, 8)).square().mean().backward()
+        for (n, p), (_, r) in zip(model.named_parameters(), ref.named_parameters()):
+            o = flat.offsets[[id(q_) for q_ in flat.params].index(id(p))]
+            got = mean_grad.as_strided(p.shape, p.stride(), o)
+            assert torch.allclose(got, r.grad, rtol=1e-4, atol=1e-6), n
+        # buffers travel from rank 0
+        model[1].running_mean.fill_(float(rank + 1))
+        flat.sync_buffers()
+        assert float(model[1].running_mean[0]) == 1.0
+        try:
+            flat.sgd_step(0.1, 0.9, 0.0)
+            q.put((rank, 'sgd ran on CPU'))
+        except RuntimeError as e:
+            q.put((rank, 'ok' if 'no CPU fallback' in str(e) else str(e)))
+    except Exception as e:      # noqa: BLE001
+        import traceback; q.put((rank, traceback.format_exc()[-600:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_arena_allreduce_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == {0: 'ok', 1: 'ok'}, res

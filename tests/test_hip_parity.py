@@ -360,3 +360,29 @@ def test_train_steps_golden(golden):
         for k, v in head.state_dict().items():
             if 'num_batches' not in k:
                 check(host(v), g[f'step{step}.{k}'], 2e-4, f'step{step} {k}')
+
+
+def test_full_model_train_steps_run():
+    """Whole DSRL (ResNet-101 on the same kernels: 7x7 s2 stem, strided/dilated bottlenecks, max-pool, residual BN) takes
+    three SGD steps on a 64x128 batch through TrainStep: finite losses, every parameter receives a gradient."""
+    from dualsuperreslearningforsemseg_amd.command_handlers.train_or_resume import SyntheticCityscapes, TrainStep
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    from dualsuperreslearningforsemseg_amd.ddp import FlatParams
+    torch.manual_seed(54321)
+    model = D.DSRL(3, cs)
+    with torch.no_grad():
+        for m in model.modules():
+            if hasattr(m, 'bn3'):
+                m.bn3.weight.fill_(0.5)
+    model = model.to(DEV).to(memory_format=torch.channels_last).train()
+    flat = FlatParams(model)
+    step = TrainStep(model, flat, 3, 0.1, 1.0, 255)
+    (img, org), (tgt, _) = next(iter(SyntheticCityscapes(2, (64, 128), torch.device(DEV), length=1)))
+    hist = [step(img, org, tgt, 0.006, 0.9, 5e-4, True)[0] for _ in range(3)]
+    assert all(np.isfinite(v) for h in hist for v in h), hist
+    p0 = flat.p_flat.clone()
+    step(img, org, tgt, 0.006, 0.9, 5e-4, True)
+    assert float((flat.p_flat - p0).abs().max()) > 0
+    assert all(float(p.grad.abs().sum()) > 0 for p in model.parameters())
+    outs = model.eval()(img)
+    assert outs[0].shape == (2, 19, 128, 256) and outs[1].shape == (2, 3, 128, 256) and outs[2].shape == (2, 1, 16, 32)
