@@ -33,6 +33,11 @@ PROTOTYPES = {
     'dsrl_conv2d_wgrad_workspace_bytes': (sz, _conv_shape),
     'dsrl_conv2d_wgrad': (i32, [fp, i32, fp, i32, fp] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv2d_inbounds_macs': (i64, _conv_shape),
+    'dsrl_conv2d_rowfold_fwd_workspace_bytes': (sz, [i32] * 9),
+    'dsrl_conv2d_rowfold_fwd': (i32, [fp, i32, fp, fp, fp, i32] + [i32] * 9 + [i64, fp, sz, stream_t]),
+    'dsrl_conv2d_rowfold_wgrad_workspace_bytes': (sz, [i32] * 9),
+    'dsrl_conv2d_rowfold_wgrad': (i32, [fp, i32, fp, i32, fp] + [i32] * 9 + [i64, fp, sz, stream_t]),
+    'dsrl_pad_image_nhwc': (i32, [fp, i64, i64, i64, i64, fp] + [i32] * 9 + [stream_t]),
     'dsrl_colsum_workspace_bytes': (sz, [i64, i32]),
     'dsrl_colsum': (i32, [fp, i32, i64, i32, fp, fp, sz, stream_t]),
     'dsrl_bn_workspace_bytes': (sz, [i64, i32]),

@@ -4,12 +4,13 @@
 // workspace, merged by a finalize kernel in fp64; Chan/Welford merge for the variance).
 #include "common.h"
 #include <algorithm>
+#include <initializer_list>
 
 namespace dsrl {
 
-constexpr int kMaxRowBlocks = 512;
+constexpr int kMaxRowBlocks = 256;
 
-static int row_blocks(int64_t P) { return (int)std::max<int64_t>(1, std::min<int64_t>(kMaxRowBlocks, ceil_div(P, 64))); }
+static int row_blocks(int64_t P) { return (int)std::max<int64_t>(1, std::min<int64_t>(kMaxRowBlocks, ceil_div(P, 32))); }
 
 // ---------------------------------------------------------------------------------------------- statistics
 // partial[0][bx][c] = n, [1] = mean, [2] = M2 over the rows of block bx
@@ -50,20 +51,21 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     }
 }
 
-// 256 threads = 32 channels x 8 slices of the row blocks; slices are merged through LDS in a fixed order (deterministic)
+// 256 threads = 8 channels x 32 slices of the row blocks; a slice merges its partials in fp32 (Chan), the 32 slice results are
+// merged in fp64 in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nbx, int C, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rm, float* __restrict__ rv) {
-    __shared__ double sh[3][8][32];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double na = 0, ma = 0, qa = 0;
+    __shared__ float sh[3][32][8];
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    float na = 0.f, ma = 0.f, qa = 0.f;
     if (c < C) {
-        for (int b = sl; b < nbx; b += 8) {
+        for (int b = sl; b < nbx; b += 32) {
             const long long o = (long long)b * C + c;
-            const double nb = part[o];
-            if (nb > 0) {
-                const double mb = part[(long long)nbx * C + o], qb = part[2ll * nbx * C + o];
-                const double nt = na + nb, d = mb - ma;
+            const float nb = part[o];
+            if (nb > 0.f) {
+                const float mb = part[(long long)nbx * C + o], qb = part[2ll * nbx * C + o];
+                const float nt = na + nb, d = mb - ma;
                 ma += d * (nb / nt);
                 qa += qb + d * d * (na * nb / nt);
                 na = nt;
@@ -73,21 +75,22 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     sh[0][sl][cl] = na; sh[1][sl][cl] = ma; sh[2][sl][cl] = qa;
     __syncthreads();
     if (sl != 0 || c >= C) return;
-    for (int s2 = 1; s2 < 8; ++s2) {
+    double n2 = 0, m2 = 0, q2 = 0;
+    for (int s2 = 0; s2 < 32; ++s2) {
         const double nb = sh[0][s2][cl];
         if (nb > 0) {
             const double mb = sh[1][s2][cl], qb = sh[2][s2][cl];
-            const double nt = na + nb, d = mb - ma;
-            ma += d * (nb / nt);
-            qa += qb + d * d * (na * nb / nt);
-            na = nt;
+            const double nt = n2 + nb, d = mb - m2;
+            m2 += d * (nb / nt);
+            q2 += qb + d * d * (n2 * nb / nt);
+            n2 = nt;
         }
     }
-    const double var = na > 0 ? qa / na : 0.0;
-    mean[c] = (float)ma;
+    const double var = n2 > 0 ? q2 / n2 : 0.0;
+    mean[c] = (float)m2;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (rm) rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * ma);
-    if (rv) rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * (na > 1 ? qa / (na - 1) : var));
+    if (rm) rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * m2);
+    if (rv) rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * (n2 > 1 ? q2 / (n2 - 1) : var));
 }
 
 __global__ void invstd_from_var_kernel(const float* __restrict__ var, int C, float eps, float* __restrict__ invstd) {
@@ -152,16 +155,17 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 // sums[0][c] = dbeta, sums[1][c] = dgamma (fp32 copies also written to the parameter gradients)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nbx, int C, float* __restrict__ sums,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double sh[2][8][32];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double sh[2][32][8];
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double a = 0, b = 0;
     if (c < C)
-        for (int i = sl; i < nbx; i += 8) { a += part[(long long)i * C + c]; b += part[(long long)nbx * C + (long long)i * C + c]; }
+        for (int i = sl; i < nbx; i += 32) { a += part[(long long)i * C + c]; b += part[(long long)nbx * C + (long long)i * C + c]; }
     sh[0][sl][cl] = a; sh[1][sl][cl] = b;
     __syncthreads();
     if (sl != 0 || c >= C) return;
-    for (int s2 = 1; s2 < 8; ++s2) { a += sh[0][s2][cl]; b += sh[1][s2][cl]; }
+    a = 0; b = 0;
+    for (int s2 = 0; s2 < 32; ++s2) { a += sh[0][s2][cl]; b += sh[1][s2][cl]; }
     sums[c] = (float)a; sums[C + c] = (float)b;
     if (dbeta) dbeta[c] = (float)a;
     if (dgamma) dgamma[c] = (float)b;
@@ -227,6 +231,184 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     }
 }
 
+
+// ============================================================================================== float4 variants
+// C % 4 == 0, ld % 4 == 0, 16-byte aligned bases: a lane owns 4 consecutive channels (one 16-byte access per tensor and
+// pixel, one Philox call per 4 dropout draws); G pixels are processed side by side.
+struct ChanMap4 { int q0, cq, G, q, slot; };       // q = first channel / 4 (absolute), -1 if idle
+__device__ inline ChanMap4 chan_map4(int C, int group_idx) {
+    ChanMap4 m;
+    const int Q = C >> 2;
+    m.q0 = group_idx * 256;
+    m.cq = min(256, Q - m.q0);
+    m.G = 256 / m.cq;
+    const int t = threadIdx.x;
+    if (t < m.G * m.cq) { m.q = m.q0 + t % m.cq; m.slot = t / m.cq; }
+    else { m.q = -1; m.slot = 0; }
+    return m;
+}
+#define LD4(ptr, p, ld, q) (*reinterpret_cast<const float4*>((ptr) + (p) * (long long)(ld) + 4 * (q)))
+#define ST4(ptr, p, ld, q) (*reinterpret_cast<float4*>((ptr) + (p) * (long long)(ld) + 4 * (q)))
+
+__global__ __launch_bounds__(256) void bn_partial4_kernel(const float* __restrict__ x, int ld, long long P, int C, long long rows_per_block,
+                                                           float* __restrict__ part, int nbx) {
+    __shared__ float sh[3][4][256];
+    const ChanMap4 m = chan_map4(C, blockIdx.y);
+    const long long row0 = blockIdx.x * rows_per_block, row1 = min(P, row0 + rows_per_block);
+    float n = 0.f, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, k0[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m.q >= 0) {
+        long long p = row0 + m.slot;
+        if (p < row1) { const float4 v = LD4(x, p, ld, m.q); k0[0] = v.x; k0[1] = v.y; k0[2] = v.z; k0[3] = v.w; }
+#pragma unroll 4
+        for (; p < row1; p += m.G) {
+            const float4 v = LD4(x, p, ld, m.q);
+            const float d0 = v.x - k0[0], d1 = v.y - k0[1], d2 = v.z - k0[2], d3 = v.w - k0[3];
+            s1[0] += d0; s2[0] += d0 * d0; s1[1] += d1; s2[1] += d1 * d1; s1[2] += d2; s2[2] += d2 * d2; s1[3] += d3; s2[3] += d3 * d3;
+            n += 1.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float mean = 0.f, m2 = 0.f;
+        if (n > 0.f) { mean = k0[j] + s1[j] / n; m2 = fmaxf(s2[j] - s1[j] * s1[j] / n, 0.f); }
+        sh[0][j][threadIdx.x] = n; sh[1][j][threadIdx.x] = mean; sh[2][j][threadIdx.x] = m2;
+    }
+    __syncthreads();
+    if (m.q >= 0 && m.slot == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float na = sh[0][j][threadIdx.x], ma = sh[1][j][threadIdx.x], qa = sh[2][j][threadIdx.x];
+            for (int g = 1; g < m.G; ++g) {
+                const int t = g * m.cq + (m.q - m.q0);
+                const float nb = sh[0][j][t];
+                if (nb > 0.f) {
+                    const float mb = sh[1][j][t], qb = sh[2][j][t];
+                    const float nt = na + nb, d = mb - ma;
+                    ma += d * (nb / nt);
+                    qa += qb + d * d * (na * nb / nt);
+                    na = nt;
+                }
+            }
+            const long long o = (long long)blockIdx.x * C + 4 * m.q + j;
+            part[o] = na; part[(long long)nbx * C + o] = ma; part[2ll * nbx * C + o] = qa;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long P, int C,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ res, int ldr, int relu, float drop_p, unsigned long long seed, unsigned rng_stream) {
+    const ChanMap4 m = chan_map4(C, blockIdx.y);
+    if (m.q < 0) return;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = 4 * m.q + j; sc[j] = gamma[c] * invstd[c]; sh[j] = beta[c] - mean[c] * sc[j]; }
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll 2
+    for (long long p = (long long)blockIdx.x * m.G + m.slot; p < P; p += (long long)gridDim.x * m.G) {
+        const float4 xv = LD4(x, p, ldx, m.q);
+        float v[4] = {fmaf(xv.x, sc[0], sh[0]), fmaf(xv.y, sc[1], sh[1]), fmaf(xv.z, sc[2], sh[2]), fmaf(xv.w, sc[3], sh[3])};
+        if (res) { const float4 r = LD4(res, p, ldr, m.q); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (drop_p > 0.f) {
+            const unsigned long long e = (unsigned long long)p * C + 4ull * m.q;       // multiple of 4: one Philox block
+            unsigned r[4];
+            philox4x32_10((unsigned)(e >> 2), (unsigned)(e >> 34), rng_stream, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ((float)(r[j] >> 8) * 5.9604644775390625e-08f >= drop_p) ? v[j] * ks : 0.f;
+        }
+        ST4(y, p, ldy, m.q) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
+                                                               const float* __restrict__ dy, int lddy, long long P, int C, long long rows_per_block,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               int relu, float drop_p, float* __restrict__ part, int nbx) {
+    __shared__ float sh[2][4][256];
+    const ChanMap4 m = chan_map4(C, blockIdx.y);
+    const long long row0 = blockIdx.x * rows_per_block, row1 = min(P, row0 + rows_per_block);
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m.q >= 0) {
+        float mu[4], is[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mu[j] = mean[4 * m.q + j]; is[j] = invstd[4 * m.q + j]; }
+        const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+        const bool need_y = relu || drop_p > 0.f;
+#pragma unroll 2
+        for (long long p = row0 + m.slot; p < row1; p += m.G) {
+            const float4 dv = LD4(dy, p, lddy, m.q), xv = LD4(x, p, ldx, m.q);
+            float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (need_y) yv = LD4(y, p, ldy, m.q);
+            const float g0 = masked_grad(dv.x, yv.x, relu, drop_p, ks), g1 = masked_grad(dv.y, yv.y, relu, drop_p, ks);
+            const float g2 = masked_grad(dv.z, yv.z, relu, drop_p, ks), g3 = masked_grad(dv.w, yv.w, relu, drop_p, ks);
+            sg[0] += g0; sgx[0] += g0 * ((xv.x - mu[0]) * is[0]);
+            sg[1] += g1; sgx[1] += g1 * ((xv.y - mu[1]) * is[1]);
+            sg[2] += g2; sgx[2] += g2 * ((xv.z - mu[2]) * is[2]);
+            sg[3] += g3; sgx[3] += g3 * ((xv.w - mu[3]) * is[3]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sh[0][j][threadIdx.x] = sg[j]; sh[1][j][threadIdx.x] = sgx[j]; }
+    __syncthreads();
+    if (m.q >= 0 && m.slot == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = sg[j], b = sgx[j];
+            for (int g = 1; g < m.G; ++g) { const int t = g * m.cq + (m.q - m.q0); a += sh[0][j][t]; b += sh[1][j][t]; }
+            const long long o = (long long)blockIdx.x * C + 4 * m.q + j;
+            part[o] = a; part[(long long)nbx * C + o] = b;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
+                                                             const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
+                                                             float* __restrict__ dres, int lddr, long long P, int C,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ sums, int relu, float drop_p, int training) {
+    const ChanMap4 m = chan_map4(C, blockIdx.y);
+    if (m.q < 0) return;
+    float mu[4], is[4], gi[4], mb[4], mg[4];
+    const float inv_n = 1.f / (float)P;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * m.q + j;
+        mu[j] = mean[c]; is[j] = invstd[c]; gi[j] = gamma[c] * is[j];
+        mb[j] = training ? sums[c] * inv_n : 0.f; mg[j] = training ? sums[C + c] * inv_n : 0.f;
+    }
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const bool need_y = relu || drop_p > 0.f;
+#pragma unroll 2
+    for (long long p = (long long)blockIdx.x * m.G + m.slot; p < P; p += (long long)gridDim.x * m.G) {
+        const float4 dv = LD4(dy, p, lddy, m.q), xv = LD4(x, p, ldx, m.q);
+        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (need_y) yv = LD4(y, p, ldy, m.q);
+        const float g0 = masked_grad(dv.x, yv.x, relu, drop_p, ks), g1 = masked_grad(dv.y, yv.y, relu, drop_p, ks);
+        const float g2 = masked_grad(dv.z, yv.z, relu, drop_p, ks), g3 = masked_grad(dv.w, yv.w, relu, drop_p, ks);
+        ST4(dx, p, lddx, m.q) = make_float4(gi[0] * (g0 - mb[0] - (xv.x - mu[0]) * is[0] * mg[0]), gi[1] * (g1 - mb[1] - (xv.y - mu[1]) * is[1] * mg[1]),
+                                            gi[2] * (g2 - mb[2] - (xv.z - mu[2]) * is[2] * mg[2]), gi[3] * (g3 - mb[3] - (xv.w - mu[3]) * is[3] * mg[3]));
+        if (dres) ST4(dres, p, lddr, m.q) = make_float4(g0, g1, g2, g3);
+    }
+}
+
+static bool vec4_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+    if (C % 4) return false;
+    for (int l : lds) if (l % 4) return false;
+    for (const void* p : ptrs) if (p && ((uintptr_t)p % 16)) return false;
+    return true;
+}
+static dim3 apply_grid4(int64_t P, int C) {
+    const int Q = C / 4, groups = (int)ceil_div(Q, 256);
+    const int cq = std::min(Q, 256), G = 256 / cq;
+    int64_t bx = std::min<int64_t>(ceil_div(P, (int64_t)G * 2), std::max(1, 2048 / groups));
+    return dim3((unsigned)std::max<int64_t>(1, bx), (unsigned)groups);
+}
+
 static dim3 apply_grid(int64_t P, int C) {
     const int groups = (int)ceil_div(C, 256);
     const int cg = std::min(C, 256), G = 256 / cg;
@@ -248,9 +430,12 @@ extern "C" int dsrl_bn_stats(const float* x, int ldx, int64_t P, int C, float ep
     if (int e = bind_stream_device(st)) return e;
     const int nbx = row_blocks(P);
     const long long rpb = ceil_div(P, nbx);
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ldx, (long long)P, C, rpb, (float*)ws, nbx);
+    if (vec4_ok(C, {ldx}, {x}))
+        hipLaunchKernelGGL(bn_partial4_kernel, dim3(nbx, (unsigned)ceil_div(C / 4, 256)), dim3(256), 0, st, x, ldx, (long long)P, C, rpb, (float*)ws, nbx);
+    else
+        hipLaunchKernelGGL(bn_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ldx, (long long)P, C, rpb, (float*)ws, nbx);
     if (int e = launch_status("bn_partial_kernel")) return e;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, st, (const float*)ws, nbx, C, eps, momentum, mean, invstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 8)), dim3(256), 0, st, (const float*)ws, nbx, C, eps, momentum, mean, invstd, running_mean, running_var);
     return launch_status("bn_finalize_kernel");
 }
 
@@ -269,8 +454,12 @@ extern "C" int dsrl_bn_apply(const float* x, int ldx, float* y, int ldy, int64_t
     DSRL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, DSRL_E_BADARG, "bn_apply: dropout p=%f outside [0,1)", drop_p);
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
-    hipLaunchKernelGGL(bn_apply_kernel, apply_grid(P, C), dim3(256), 0, st, x, ldx, y, ldy, (long long)P, C, mean, invstd, gamma, beta, residual, ldr,
-                       relu, drop_p, (unsigned long long)seed, (unsigned)rng_stream);
+    if (vec4_ok(C, {ldx, ldy, residual ? ldr : 0}, {x, y, residual}))
+        hipLaunchKernelGGL(bn_apply4_kernel, apply_grid4(P, C), dim3(256), 0, st, x, ldx, y, ldy, (long long)P, C, mean, invstd, gamma, beta, residual, ldr,
+                           relu, drop_p, (unsigned long long)seed, (unsigned)rng_stream);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel, apply_grid(P, C), dim3(256), 0, st, x, ldx, y, ldy, (long long)P, C, mean, invstd, gamma, beta, residual, ldr,
+                           relu, drop_p, (unsigned long long)seed, (unsigned)rng_stream);
     return launch_status("bn_apply_kernel");
 }
 
@@ -286,13 +475,22 @@ extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, con
     const long long rpb = ceil_div(P, nbx);
     float* part = (float*)ws;
     float* sums = part + 3ll * nbx * C;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, (long long)P, C, rpb,
-                       mean, invstd, relu, drop_p, part, nbx);
+    const bool v4 = vec4_ok(C, {ldx, y ? ldy : 0, lddy, lddx, dresidual ? lddr : 0}, {x, y, dy, dx, dresidual});
+    if (v4)
+        hipLaunchKernelGGL(bn_bwd_partial4_kernel, dim3(nbx, (unsigned)ceil_div(C / 4, 256)), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, (long long)P, C, rpb,
+                           mean, invstd, relu, drop_p, part, nbx);
+    else
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, (long long)P, C, rpb,
+                           mean, invstd, relu, drop_p, part, nbx);
     if (int e = launch_status("bn_bwd_partial_kernel")) return e;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, st, (const float*)part, nbx, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 8)), dim3(256), 0, st, (const float*)part, nbx, C, sums, dgamma, dbeta);
     if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, apply_grid(P, C), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (long long)P, C,
-                       mean, invstd, gamma, (const float*)sums, relu, drop_p, training);
+    if (v4)
+        hipLaunchKernelGGL(bn_bwd_apply4_kernel, apply_grid4(P, C), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (long long)P, C,
+                           mean, invstd, gamma, (const float*)sums, relu, drop_p, training);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, apply_grid(P, C), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (long long)P, C,
+                           mean, invstd, gamma, (const float*)sums, relu, drop_p, training);
     return launch_status("bn_bwd_apply_kernel");
 }
 

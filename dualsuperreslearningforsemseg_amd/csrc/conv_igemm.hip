@@ -10,10 +10,13 @@
 // skipped (dilated ASPP convs, ASPP.py:11-13), so the work done equals the in-bounds MAC count the roofline uses.
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 
 namespace dsrl {
+
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }   // tuning knobs (tools/sweep_conv.py)
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -28,13 +31,22 @@ struct ConvArgs {
     int cchunks;             // ceil(C/32)
     int splits;
     long long slab;          // floats per split slab (M*K) when splits > 1
+    unsigned x_bytes, w_bytes, y_bytes;   // extents of the three buffers (< 2^31): buffer loads/stores bounds-check against them
 };
+
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+constexpr unsigned kOOB = 0x80000000u;      // any offset >= 2^31 is outside every descriptor: loads return 0, stores are dropped
+__device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 
-template <int MR, int NR, int WGM, int WGN, bool DGRAD>
-__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
+// 4 waves per SIMD (<= 128 registers) for the tiles that stage at most 8 rows per thread: 4 blocks of 36.9 KB LDS per CU
+template <int MR, int NR, int WGM, int WGN, bool DGRAD, int MINW = 2>
+__global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArgs a) {
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -64,13 +76,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
         else { a_h[i] = ho * a.stride - a.pad; a_w[i] = wo * a.stride - a.pad; }
     }
     const int RS = a.R * a.S;
-    const float* b_ptr[B_IT];
-    bool b_ok[B_IT];
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
+    unsigned b_off[B_IT];         // byte offset of filter row k (kOOB past the last output channel)
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int k = n0 + r0 + 32 * i;
-        b_ok[i] = k < a.K;
-        b_ptr[i] = a.w + (long long)(b_ok[i] ? k : 0) * RS * a.C;
+        b_off[i] = k < a.K ? (unsigned)k * (unsigned)(RS * a.C) * 4u : kOOB;
     }
 
     // ---- taps that touch at least one in-bounds input pixel for this tile (block-uniform)
@@ -117,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
         while (skip--) rem_mask &= rem_mask - 1;
         tap = __builtin_ctzll(rem_mask);
     }
-    long long a_off[A_IT];     // pixel*ldx of the input row for the current tap, -1 if padding
+    unsigned a_off[A_IT];      // byte offset of the input pixel of the current tap, kOOB if it is zero padding
     auto set_tap = [&](int t) {
         const int r = t / a.S, s = t - r * a.S;
 #pragma unroll
@@ -131,21 +143,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
                 hi = a_h[i] + r * a.dil; wi = a_w[i] + s * a.dil;
                 ok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
             }
-            a_off[i] = ok ? ((long long)(a_n[i] * a.H + hi) * a.W + wi) * a.ldx : -1;
+            a_off[i] = ok ? (unsigned)((a_n[i] * a.H + hi) * a.W + wi) * (unsigned)a.ldx * 4u : kOOB;
         }
     };
     float4 ra[A_IT], rb[B_IT];
     auto gload = [&](int t, int ch) {
         const int c = ch * BK + c4 * 4;
-        const bool cok = c < a.C;
+        const unsigned coff = c < a.C ? (unsigned)c * 4u : kOOB;          // channel tail of the last chunk reads as zeros
+        const unsigned woff = coff + (unsigned)(t * a.C) * 4u;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            ra[i] = (cok && a_off[i] >= 0) ? *reinterpret_cast<const float4*>(a.x + a_off[i] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < A_IT; ++i) ra[i] = buf_load4(xr, a_off[i] + coff);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            rb[i] = (cok && b_ok[i]) ? *reinterpret_cast<const float4*>(b_ptr[i] + (long long)t * a.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < B_IT; ++i) rb[i] = buf_load4(wr, b_off[i] + woff);
     };
 
     if (q0 < q1) { set_tap(tap); gload(tap, cc); }
@@ -184,21 +193,23 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: D[row][col], col = lane&31 (out channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue: D[row][col], col = lane&31 (out channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); bounds by the descriptor
     float* yout = a.y + (a.splits > 1 ? (long long)z * a.slab : 0ll);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)yout, 0, (int)a.y_bytes, 0x00020000);
     const int col = lane & 31, rq = (lane >> 5) * 4;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int k = n0 + (wn * NR + j) * 32 + col;
-        if (k >= a.K) continue;
-        const float bv = (a.bias != nullptr) ? a.bias[k] : 0.f;
+        const bool kok = k < a.K;
+        const float bv = (a.bias != nullptr && kok) ? a.bias[k] : 0.f;
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
             const int mb = m0 + (wm * MR + i) * 32 + rq;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = mb + (e & 3) + 8 * (e >> 2);
-                if (m < a.M) yout[(long long)m * a.ldy + k] = acc[i][j][e] + bv;
+                const unsigned off = (kok && m < a.M) ? ((unsigned)m * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e] + bv), yr, (int)off, 0, 0);
             }
         }
     }
@@ -239,6 +250,7 @@ struct WgradArgs {
     int ldx, lddy;
     int N, H, W, C, K, R, S, Ho, Wo, stride, pad, dil;
     long long P;                // N*Ho*Wo
+    unsigned x_bytes, dy_bytes; // buffer extents (< 2^31)
     int ctiles;                 // tiles along C
     int psplits;
     long long slab;             // floats per split slab (K*RS*C) when psplits > 1
@@ -279,28 +291,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs a) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
+    const unsigned a_coff = a_cok ? (unsigned)(k0 + a_col) * 4u : kOOB, b_coff = b_cok ? (unsigned)(c0 + b_col) * 4u : kOOB;
+    const int Pi = (int)a.P;
     float4 ra[A_IT], rb[B_IT];
     auto gload = [&](long long ch) {
-        const long long pb = ch * BP;
+        const int pb = (int)ch * BP;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const long long p = pb + a_row + i * A_RP;
-            ra[i] = (a_cok && p < a.P) ? *reinterpret_cast<const float4*>(a.dy + p * a.lddy + k0 + a_col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int p = pb + a_row + i * A_RP;
+            ra[i] = buf_load4(dr, (p < Pi ? (unsigned)p * (unsigned)a.lddy * 4u : kOOB) + a_coff);
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const long long p = pb + b_row + i * B_RP;
-            bool ok = b_cok && p < a.P;
-            long long off = 0;
-            if (ok) {
-                const int pi = (int)p;
-                const int n = pi / HoWo, rem = pi - n * HoWo;
+            const int p = pb + b_row + i * B_RP;
+            unsigned off = kOOB;
+            if (p < Pi) {
+                const int n = p / HoWo, rem = p - n * HoWo;
                 const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
                 const int hi = ho * a.stride + dh, wi = wo * a.stride + dw_;
-                ok = hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-                off = ((long long)(n * a.H + hi) * a.W + wi) * a.ldx + c0 + b_col;
+                if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) off = (unsigned)((n * a.H + hi) * a.W + wi) * (unsigned)a.ldx * 4u;
             }
-            rb[i] = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = buf_load4(xr, off + b_coff);
         }
     };
     if (ch0 < ch1) gload(ch0);
@@ -396,21 +409,56 @@ struct ProfScope {
     }
 };
 
-enum TileCfg { T128x128, T256x64, T256x32 };
-static TileCfg pick_cfg(int K) {
-    if (K <= 32) return T256x32;
-    const int r = K % 128;
-    if (K <= 64 || (r > 0 && r <= 64)) return T256x64;
-    return T128x128;
+// tile configurations <MR,NR,WGM,WGN>: block tile = (32*MR*WGM) x (32*NR*WGN), always 4 waves
+enum TileCfg { T128x128, T256x64, T256x32, T64x64, T128x64, T64x128, T128x32, kNumCfg };
+static const int kCfgDims[kNumCfg][2] = {{128, 128}, {256, 64}, {256, 32}, {64, 64}, {128, 64}, {64, 128}, {128, 32}};
+#define DSRL_CFG_SWITCH(cfg, LAUNCH)                 \
+    switch (cfg) {                                   \
+        case T128x128: LAUNCH(2, 2, 2, 2); break;    \
+        case T256x64:  LAUNCH(2, 2, 4, 1); break;    \
+        case T256x32:  LAUNCH(2, 1, 4, 1); break;    \
+        case T64x64:   LAUNCH(1, 1, 2, 2); break;    \
+        case T128x64:  LAUNCH(2, 1, 2, 2); break;    \
+        case T64x128:  LAUNCH(1, 2, 2, 2); break;    \
+        default:       LAUNCH(1, 1, 4, 1); break;    \
+    }
+static void cfg_dims(TileCfg c, int& bm, int& bn) { bm = kCfgDims[c][0]; bn = kCfgDims[c][1]; }
+// forward / dgrad (rows = pixels M, columns = output channels N).  Measured on MI355X (tools/sweep_igemm.py): take the largest
+// tile that still yields >= 3 blocks per CU, fall back to 64x64; split K only when the tap/channel loop is very long (ASPP).
+static long long cfg_blocks(TileCfg c, long long M, int N) { return ceil_div(M, kCfgDims[c][0]) * ceil_div(N, kCfgDims[c][1]); }
+static TileCfg pick_cfg(long long M, int N) {
+    const int forced = env_int("DSRL_FORCE_CFG", -1);
+    if (forced >= 0 && forced < kNumCfg) return (TileCfg)forced;
+    if (N <= 32) return cfg_blocks(T256x32, M, N) >= 3 * kNumCU ? T256x32 : T128x32;
+    const int r = N % 128;
+    const bool narrow = N <= 64 || (r > 0 && r <= 64);
+    const TileCfg wide[3] = {T128x128, T128x64, T64x64}, nar[3] = {T256x64, T128x64, T64x64};
+    const TileCfg* cand = narrow ? nar : wide;
+    for (int i = 0; i < 3; ++i)
+        if (cfg_blocks(cand[i], M, N) >= 3 * kNumCU) return cand[i];
+    return T64x64;
 }
-static void cfg_dims(TileCfg c, int& bm, int& bn) {
-    switch (c) { case T128x128: bm = 128; bn = 128; break; case T256x64: bm = 256; bn = 64; break; default: bm = 256; bn = 32; }
+// wgrad: rows are output channels K, columns input channels C.  Measured on MI355X (tools/sweep_wgrad.py): 128x64 tiles
+// (64x64 when K <= 64) with ~4.5 blocks per CU beat the larger tiles on every layer shape of the step.
+static TileCfg pick_cfg_wgrad(int K, int C) {
+    const int forced = env_int("DSRL_FORCE_CFG", -1);
+    if (forced >= 0 && forced < kNumCfg) return (TileCfg)forced;
+    if (C <= 32) return T128x32;
+    return K <= 64 ? T64x64 : T128x64;
+}
+static int pick_psplits(long long tiles, long long chunks) {
+    const int forced = env_int("DSRL_FORCE_PSPLITS", 0);
+    if (forced > 0) return (int)std::max<long long>(1, std::min<long long>(forced, chunks));
+    long long sp = ceil_div(1152, std::max<long long>(tiles, 1));
+    sp = std::min(sp, std::max<long long>(1, chunks / 4));
+    return (int)std::max<long long>(1, std::min<long long>(sp, 128));
 }
 static int pick_splits(long long tiles, int nq) {
-    int s = 1;
-    if (tiles < 2 * kNumCU) s = (int)ceil_div(2 * kNumCU, tiles);
-    s = (int)std::min<long long>(s, std::max(1, nq / 8));
-    return std::max(1, std::min(s, 32));
+    const int forced = env_int("DSRL_FORCE_SPLITS", 0);
+    if (forced > 0) return std::max(1, std::min(forced, std::max(1, nq)));
+    if (tiles >= 3 * kNumCU) return 1;
+    const long long cap = std::min<long long>(8, ceil_div(6 * kNumCU, std::max<long long>(tiles, 1)));
+    return (int)std::max<long long>(1, std::min<long long>(nq / 48, cap));
 }
 
 template <bool DGRAD>
@@ -418,11 +466,14 @@ static int launch_igemm(const ConvArgs& a, TileCfg cfg, hipStream_t st) {
     int bm, bn; cfg_dims(cfg, bm, bn);
     dim3 grid((unsigned)ceil_div(a.M, bm), (unsigned)ceil_div(a.K, bn), (unsigned)a.splits);
     const size_t lds = (size_t)(bm + bn) * LDS_LD * sizeof(float);
-    switch (cfg) {
-        case T128x128: hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 2, 2, 2, DGRAD>), grid, dim3(256), lds, st, a); break;
-        case T256x64:  hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 2, 4, 1, DGRAD>), grid, dim3(256), lds, st, a); break;
-        default:       hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 1, 4, 1, DGRAD>), grid, dim3(256), lds, st, a); break;
+#define DSRL_LAUNCH_IGEMM(a_, b_, c_, d_) hipLaunchKernelGGL((conv_igemm_f32_kernel<a_, b_, c_, d_, DGRAD>), grid, dim3(256), lds, st, a)
+    // 1024+ tiles of 128x128: the <=128-register build keeps 4 blocks per CU resident (one round instead of 1.33)
+    if (cfg == T128x128 && env_int("DSRL_IGEMM_OCC4", (long long)grid.x * grid.y * grid.z > 3 * kNumCU ? 1 : 0)) {
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 2, 2, 2, DGRAD, 4>), grid, dim3(256), lds, st, a);
+    } else {
+        DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_IGEMM)
     }
+#undef DSRL_LAUNCH_IGEMM
     return launch_status("conv_igemm_f32_kernel");
 }
 
@@ -435,10 +486,12 @@ static int check_conv(const void* p0, const void* p1, const void* p2, int N, int
     return 0;
 }
 
+static long long span_bytes(long long pixels, int ld, int c) { return ((pixels - 1) * ld + c) * 4ll; }
+#define DSRL_REQUIRE_31(bytes, what) DSRL_REQUIRE((bytes) > 0 && (bytes) < (1ll << 31), DSRL_E_UNSUPPORTED, what ": tensor of %lld bytes exceeds the 2 GiB buffer-descriptor range", (long long)(bytes))
 struct FwdPlan { int Ho, Wo, M, cchunks, splits; TileCfg cfg; size_t ws; };
 static FwdPlan plan_fwd(int N, int Hin, int Win, int Cin, int Kout, int R, int S, int Ho, int Wo) {
     FwdPlan p; p.Ho = Ho; p.Wo = Wo; p.M = N * Ho * Wo; p.cchunks = (int)ceil_div(Cin, BK);
-    p.cfg = pick_cfg(Kout);
+    p.cfg = pick_cfg(p.M, Kout);
     int bm, bn; cfg_dims(p.cfg, bm, bn);
     p.splits = pick_splits(ceil_div(p.M, bm) * ceil_div(Kout, bn), R * S * p.cchunks);
     p.ws = p.splits > 1 ? (size_t)p.splits * p.M * Kout * sizeof(float) : 0;
@@ -479,6 +532,9 @@ extern "C" int dsrl_conv2d_fwd(const float* x, int ldx, const float* w, const fl
     ConvArgs a{};
     a.x = x; a.w = w; a.ldx = ldx; a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = Ho; a.Wo = Wo;
     a.stride = stride; a.pad = pad; a.dil = dil; a.M = p.M; a.cchunks = p.cchunks; a.splits = p.splits; a.slab = (long long)p.M * K;
+    const long long xb = span_bytes((long long)N * H * W, ldx, C), wb = (long long)K * R * S * C * 4, yb = p.splits > 1 ? (long long)p.M * K * 4 : span_bytes(p.M, ldy, K);
+    DSRL_REQUIRE_31(xb, "conv2d_fwd(x)"); DSRL_REQUIRE_31(wb, "conv2d_fwd(w)"); DSRL_REQUIRE_31(yb, "conv2d_fwd(y)");
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
     ProfScope prof(0, 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), st);
     if (p.splits > 1) {
         a.y = (float*)ws; a.ldy = K; a.bias = nullptr;
@@ -525,6 +581,11 @@ extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, floa
     ConvArgs a{};
     a.x = dy; a.w = wt; a.ldx = lddy; a.N = N; a.H = Ho; a.W = Wo; a.C = Kp; a.K = C; a.R = R; a.S = S; a.Ho = H; a.Wo = W;
     a.stride = stride; a.pad = pad; a.dil = dil; a.M = p.M; a.cchunks = p.cchunks; a.splits = p.splits; a.slab = (long long)p.M * C;
+    {
+        const long long xb = span_bytes((long long)N * Ho * Wo, lddy, Kp), wb = (long long)C * R * S * Kp * 4, yb = p.splits > 1 ? (long long)p.M * C * 4 : span_bytes(p.M, lddx, C);
+        DSRL_REQUIRE_31(xb, "conv2d_dgrad(dy)"); DSRL_REQUIRE_31(wb, "conv2d_dgrad(w)"); DSRL_REQUIRE_31(yb, "conv2d_dgrad(dx)");
+        a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
+    }
     ProfScope prof(0, 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), st);
     if (p.splits > 1) {
         a.y = slabs; a.ldy = C; a.bias = nullptr;
@@ -544,7 +605,7 @@ static WgPlan plan_wgrad(int N, int H, int W, int C, int K, int R, int S, int st
     WgPlan p; p.Ho = out_size(H, R, stride, pad, dil); p.Wo = out_size(W, S, stride, pad, dil);
     p.P = (long long)N * p.Ho * p.Wo;
     // GEMM rows = out channels, columns = in channels
-    p.cfg = pick_cfg(C);
+    p.cfg = pick_cfg_wgrad(K, C);
     int bm, bn; cfg_dims(p.cfg, bm, bn); p.bm = bm; p.bn = bn;
     p.ktiles = (int)ceil_div(K, bm); p.ctiles = (int)ceil_div(C, bn);
     p.tl.n = 0;
@@ -553,9 +614,7 @@ static WgPlan plan_wgrad(int N, int H, int W, int C, int K, int R, int S, int st
             if (valid_count(H, p.Ho, stride, pad, r * dil) > 0 && valid_count(W, p.Wo, stride, pad, s * dil) > 0) p.tl.taps[p.tl.n++] = r * S + s;
     const long long tiles = (long long)p.ktiles * p.ctiles * std::max(1, p.tl.n);
     const long long chunks = ceil_div(p.P, 32);
-    long long sp = tiles < 2 * kNumCU ? ceil_div(2 * kNumCU, tiles) : 1;
-    sp = std::min(sp, std::max<long long>(1, chunks / 4));
-    p.psplits = (int)std::max<long long>(1, std::min<long long>(sp, 64));
+    p.psplits = pick_psplits(tiles, chunks);
     p.ws = p.psplits > 1 ? (size_t)p.psplits * K * R * S * C * sizeof(float) : 0;
     return p;
 }
@@ -585,22 +644,123 @@ extern "C" int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int l
     WgradArgs a{};
     a.x = x; a.dy = dy; a.ldx = ldx; a.lddy = lddy; a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = p.Ho; a.Wo = p.Wo;
     a.stride = stride; a.pad = pad; a.dil = dil; a.P = p.P; a.ctiles = p.ctiles; a.psplits = p.psplits; a.slab = (long long)K * RS * C;
+    {
+        const long long xb = span_bytes((long long)N * H * W, ldx, C), db = span_bytes(p.P, lddy, pad4(K));
+        DSRL_REQUIRE_31(xb, "conv2d_wgrad(x)"); DSRL_REQUIRE_31(db, "conv2d_wgrad(dy)");
+        a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db;
+    }
     a.ntaps = p.tl.n;
     for (int i = 0; i < p.tl.n; ++i) a.taps[i] = p.tl.taps[i];
     a.dw = p.psplits > 1 ? (float*)ws : dw;
     dim3 grid((unsigned)(p.ktiles * p.ctiles), (unsigned)p.tl.n, (unsigned)p.psplits);
     const size_t lds = (size_t)32 * (p.bm + p.bn) * sizeof(float);
     ProfScope prof(1, 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), st);
-    switch (p.cfg) {
-        case T128x128: hipLaunchKernelGGL((conv_wgrad_f32_kernel<2, 2, 2, 2>), grid, dim3(256), lds, st, a); break;
-        case T256x64:  hipLaunchKernelGGL((conv_wgrad_f32_kernel<2, 2, 4, 1>), grid, dim3(256), lds, st, a); break;
-        default:       hipLaunchKernelGGL((conv_wgrad_f32_kernel<2, 1, 4, 1>), grid, dim3(256), lds, st, a); break;
-    }
+#define DSRL_LAUNCH_WGRAD(a_, b_, c_, d_) hipLaunchKernelGGL((conv_wgrad_f32_kernel<a_, b_, c_, d_>), grid, dim3(256), lds, st, a)
+    DSRL_CFG_SWITCH(p.cfg, DSRL_LAUNCH_WGRAD)
+#undef DSRL_LAUNCH_WGRAD
     if (int e = launch_status("conv_wgrad_f32_kernel")) return e;
     if (p.psplits > 1) {
         const long long total = (long long)K * p.tl.n * C;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st,
                            (const float*)ws, p.psplits, a.slab, dw, K, RS, C, p.tl);
+        return launch_status("wgrad_reduce_kernel");
+    }
+    return DSRL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ row-folded conv (stem)
+static int check_rowfold(const void* a, const void* b, const void* c, int ldx, int N, int H, int W, int Cf, int K, int R, int stride, int Ho, int Wo) {
+    DSRL_REQUIRE(a && b && c, DSRL_E_BADARG, "conv2d_rowfold: null pointer");
+    DSRL_REQUIRE(N > 0 && H > 0 && W > 0 && Cf > 0 && K > 0 && R > 0 && R <= 64 && stride > 0 && Ho > 0 && Wo > 0 && ldx > 0, DSRL_E_BADARG, "conv2d_rowfold: bad shape");
+    DSRL_REQUIRE(Cf % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)a % 16) == 0, DSRL_E_UNSUPPORTED, "conv2d_rowfold: Cfold and ldx must be multiples of 4, x 16-byte aligned");
+    DSRL_REQUIRE((long long)(Ho - 1) * stride + R <= H && (long long)(Wo - 1) * stride * ldx + Cf <= (long long)W * ldx, DSRL_E_BADARG,
+                 "conv2d_rowfold: the folded window leaves the (pre-padded) image");
+    return 0;
+}
+extern "C" size_t dsrl_conv2d_rowfold_fwd_workspace_bytes(int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo) {
+    (void)stride;
+    return plan_fwd(N, H, W, Cfold, K, R, 1, Ho, Wo).ws;
+}
+extern "C" int dsrl_conv2d_rowfold_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                                       int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo, int64_t algorithmic_macs,
+                                       void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    if (int e = check_rowfold(x, w, y, ldx, N, H, W, Cfold, K, R, stride, Ho, Wo)) return e;
+    DSRL_REQUIRE(ldy >= K && ((uintptr_t)w % 16) == 0, DSRL_E_BADARG, "conv2d_rowfold_fwd: bad ldy / unaligned filter");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const FwdPlan p = plan_fwd(N, H, W, Cfold, K, R, 1, Ho, Wo);
+    DSRL_REQUIRE(ws_bytes >= p.ws && (p.ws == 0 || ws), DSRL_E_WORKSPACE, "conv2d_rowfold_fwd: workspace %zu < %zu", ws_bytes, p.ws);
+    ConvArgs a{};
+    a.x = x; a.w = w; a.ldx = ldx; a.N = N; a.H = H; a.W = W; a.C = Cfold; a.K = K; a.R = R; a.S = 1; a.Ho = Ho; a.Wo = Wo;
+    a.stride = stride; a.pad = 0; a.dil = 1; a.M = p.M; a.cchunks = p.cchunks; a.splits = p.splits; a.slab = (long long)p.M * K;
+    {
+        const long long xb = (long long)N * H * W * ldx * 4, wb = (long long)K * R * Cfold * 4, yb = p.splits > 1 ? (long long)p.M * K * 4 : span_bytes(p.M, ldy, K);
+        DSRL_REQUIRE_31(xb, "conv2d_rowfold_fwd(x)"); DSRL_REQUIRE_31(wb, "conv2d_rowfold_fwd(w)"); DSRL_REQUIRE_31(yb, "conv2d_rowfold_fwd(y)");
+        a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
+    }
+    ProfScope prof(0, 2.0 * (double)algorithmic_macs, st);
+    if (p.splits > 1) {
+        a.y = (float*)ws; a.ldy = K; a.bias = nullptr;
+        if (int e = launch_igemm<false>(a, p.cfg, st)) return e;
+        const long long total = (long long)p.M * K;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st,
+                           (const float*)ws, p.splits, a.slab, p.M, K, bias, y, ldy);
+        return launch_status("splitk_reduce_kernel");
+    }
+    a.y = y; a.ldy = ldy; a.bias = bias;
+    return launch_igemm<false>(a, p.cfg, st);
+}
+
+namespace dsrl {
+static WgPlan plan_wgrad_rowfold(int N, int Cf, int K, int R, int Ho, int Wo) {
+    WgPlan p; p.Ho = Ho; p.Wo = Wo; p.P = (long long)N * Ho * Wo;
+    p.cfg = pick_cfg_wgrad(K, Cf);
+    cfg_dims(p.cfg, p.bm, p.bn);
+    p.ktiles = (int)ceil_div(K, p.bm); p.ctiles = (int)ceil_div(Cf, p.bn);
+    p.tl.n = R;
+    for (int r = 0; r < R; ++r) p.tl.taps[r] = r;
+    const long long tiles = (long long)p.ktiles * p.ctiles * R, chunks = ceil_div(p.P, 32);
+    p.psplits = pick_psplits(tiles, chunks);
+    p.ws = p.psplits > 1 ? (size_t)p.psplits * K * R * Cf * sizeof(float) : 0;
+    return p;
+}
+}  // namespace dsrl
+extern "C" size_t dsrl_conv2d_rowfold_wgrad_workspace_bytes(int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo) {
+    (void)H; (void)W; (void)stride;
+    return plan_wgrad_rowfold(N, Cfold, K, R, Ho, Wo).ws;
+}
+extern "C" int dsrl_conv2d_rowfold_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
+                                         int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo, int64_t algorithmic_macs,
+                                         void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    if (int e = check_rowfold(x, dy, dw, ldx, N, H, W, Cfold, K, R, stride, Ho, Wo)) return e;
+    DSRL_REQUIRE(lddy % 4 == 0 && lddy >= pad4(K) && ((uintptr_t)dy % 16) == 0, DSRL_E_UNSUPPORTED, "conv2d_rowfold_wgrad: lddy must be a multiple of 4, dy aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const WgPlan p = plan_wgrad_rowfold(N, Cfold, K, R, Ho, Wo);
+    DSRL_REQUIRE(p.P < (1ll << 31), DSRL_E_UNSUPPORTED, "conv2d_rowfold_wgrad: more than 2^31 output pixels");
+    DSRL_REQUIRE(ws_bytes >= p.ws && (p.ws == 0 || ws), DSRL_E_WORKSPACE, "conv2d_rowfold_wgrad: workspace %zu < %zu", ws_bytes, p.ws);
+    WgradArgs a{};
+    a.x = x; a.dy = dy; a.ldx = ldx; a.lddy = lddy; a.N = N; a.H = H; a.W = W; a.C = Cfold; a.K = K; a.R = R; a.S = 1; a.Ho = Ho; a.Wo = Wo;
+    a.stride = stride; a.pad = 0; a.dil = 1; a.P = p.P; a.ctiles = p.ctiles; a.psplits = p.psplits; a.slab = (long long)K * R * Cfold;
+    {
+        const long long xb = (long long)N * H * W * ldx * 4, db = span_bytes(p.P, lddy, pad4(K));
+        DSRL_REQUIRE_31(xb, "conv2d_rowfold_wgrad(x)"); DSRL_REQUIRE_31(db, "conv2d_rowfold_wgrad(dy)");
+        a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db;
+    }
+    a.ntaps = R;
+    for (int r = 0; r < R; ++r) a.taps[r] = r;
+    a.dw = p.psplits > 1 ? (float*)ws : dw;
+    dim3 grid((unsigned)(p.ktiles * p.ctiles), (unsigned)R, (unsigned)p.psplits);
+    const size_t lds = (size_t)32 * (p.bm + p.bn) * sizeof(float);
+    ProfScope prof(1, 2.0 * (double)algorithmic_macs, st);
+#define DSRL_LAUNCH_WGRAD(a_, b_, c_, d_) hipLaunchKernelGGL((conv_wgrad_f32_kernel<a_, b_, c_, d_>), grid, dim3(256), lds, st, a)
+    DSRL_CFG_SWITCH(p.cfg, DSRL_LAUNCH_WGRAD)
+#undef DSRL_LAUNCH_WGRAD
+    if (int e = launch_status("conv_wgrad_f32_kernel")) return e;
+    if (p.psplits > 1) {
+        const long long total = (long long)K * R * Cfold;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st,
+                           (const float*)ws, p.psplits, a.slab, dw, K, R, Cfold, p.tl);
         return launch_status("wgrad_reduce_kernel");
     }
     return DSRL_OK;

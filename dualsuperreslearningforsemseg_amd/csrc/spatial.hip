@@ -387,6 +387,17 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void pad_image_kernel(const float* __restrict__ x, long long sn, long long sc, long long sh, long long sw,
+                                                         float* __restrict__ y, int N, int C, int H, int W, int Cp, int top, int left, int Hp, int Wp) {
+    const long long total = (long long)N * Hp * Wp;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int wp = (int)(e % Wp); const long long t = e / Wp; const int hp = (int)(t % Hp); const long long n = t / Hp;
+        const int h = hp - top, w = wp - left;
+        const bool in = h >= 0 && h < H && w >= 0 && w < W;
+        for (int c = 0; c < Cp; ++c) y[e * Cp + c] = (in && c < C) ? x[n * sn + c * sc + h * sh + w * sw] : 0.f;
+    }
+}
+
 }  // namespace dsrl
 using namespace dsrl;
 
@@ -519,4 +530,12 @@ extern "C" int dsrl_copy2d(const float* src, int ld_src, float* dst, int ld_dst,
                          hipMemcpyDeviceToDevice, st) != hipSuccess)
         return launch_status("hipMemcpy2DAsync");
     return DSRL_OK;
+}
+
+extern "C" int dsrl_pad_image_nhwc(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* y,
+                                   int N, int C, int H, int W, int Cp, int top, int left, int Hp, int Wp, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C && top >= 0 && left >= 0 && Hp >= H + top && Wp >= W + left, "pad_image_nhwc")
+    hipLaunchKernelGGL(pad_image_kernel, dim3(flat_grid((long long)N * Hp * Wp)), dim3(256), 0, st, x, (long long)sn, (long long)sc, (long long)sh, (long long)sw,
+                       y, N, C, H, W, Cp, top, left, Hp, Wp);
+    return launch_status("pad_image_kernel");
 }

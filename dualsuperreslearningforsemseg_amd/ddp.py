@@ -83,6 +83,11 @@ class FlatParams:
         self._pending = [c[2] for c in self.chunks]
         self._works = []
         self._hooks = []
+        # gradient sink: kernels may write a parameter's gradient straight into its arena slot (functional._sink)
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._claimed = set()
+        for p in self.params:
+            p._dsrl_arena = self
         if self.world > 1:
             dist.broadcast(self.p_flat, 0, group=self.pg)          # DDP constructor semantics: rank 0's weights win
             dist.broadcast(self.b_flat, 0, group=self.pg)
@@ -91,23 +96,45 @@ class FlatParams:
 
     # ------------------------------------------------------------------ gradient reduction
     def _make_hook(self, i):
-        ci = self._chunk_of[i]
-
         def hook(_param):
-            self._pending[ci] -= 1
-            if self._pending[ci] == 0:
-                a, b, _ = self.chunks[ci]
-                self._works.append(dist.all_reduce(self.g_flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._on_grad_ready(i)
         return hook
+
+    # ------------------------------------------------------------------ gradient sink protocol
+    def claim(self, p):
+        """First gradient of `p` in this backward pass? Then the producing kernel may overwrite the (zeroed) arena slot."""
+        i = self._index.get(id(p))
+        if i is None or i in self._claimed or p.grad is None or p.grad.data_ptr() != self.g_flat.data_ptr() + 4 * self.offsets[i]:
+            return False
+        self._claimed.add(i)
+        return True
+
+    def written(self, p, stream=None):
+        """The kernel that claimed `p` has been enqueued (on `stream`, default the current one): run the reducer hook autograd
+        would have run. Gradients produced on a side stream are joined before the collective is launched."""
+        if self.world > 1:
+            self._on_grad_ready(self._index[id(p)])
+
+    def _on_grad_ready(self, i):
+        ci = self._chunk_of[i]
+        self._pending[ci] -= 1
+        if self._pending[ci] == 0:
+            a, b, _ = self.chunks[ci]
+            if self.device.type == 'cuda':
+                HF.join_side_streams()      # the chunk may hold weight gradients produced on the side stream
+            self._works.append(dist.all_reduce(self.g_flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def zero_grad(self):
         self.g_flat.zero_()
+        self._claimed.clear()
         self._pending = [c[2] for c in self.chunks]
         self._works = []
 
     def finish_reduction(self):
         """Waits (stream-wise) for the chunk all-reduces launched during backward; chunks whose hooks did not all fire
         (parameters unused in this step) are reduced here so that every rank issues the same collectives."""
+        if self.device.type == 'cuda':
+            HF.join_side_streams()          # weight gradients written on the side stream (functional.overlap_wgrad)
         if self.world == 1:
             return
         for ci, left in enumerate(self._pending):

@@ -4,6 +4,8 @@ Tensors keep the reference's logical NCHW shapes; physically they are torch.chan
 [P][ld] for the kernels), which the wrappers enforce with at most one strided copy at the boundary.  Every op
 raises if its tensors are not on a HIP device: there is no CPU / stock-ATen fallback in this package.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -15,6 +17,27 @@ CL = torch.channels_last
 # ------------------------------------------------------------------------------------------------ helpers
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+# Weight-gradient kernels run on a side HIP stream so that they overlap with the data-gradient kernel of the same layer (both
+# only read dy): the small backbone layers do not fill 256 CUs on their own. ddp.FlatParams joins the stream before it
+# reduces / applies the gradients; without an arena the caller's stream waits right away.
+_side = {}
+overlap_wgrad = os.environ.get('DSRL_OVERLAP_WGRAD', '1') != '0'
+
+
+def side_stream(device):
+    st = _side.get(device)
+    if st is None:
+        st = _side[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_side_streams():
+    cur = torch.cuda.current_stream()
+    for st in _side.values():
+        if st.device == cur.device:
+            cur.wait_stream(st)
 
 
 def _need_gpu(*ts):
@@ -98,6 +121,15 @@ def pm_vec4(t):
     return buf[:, :Cc], cp
 
 
+def _sink(param, like_shape=None):
+    """If `param` is bound to a ddp.FlatParams arena (and has not received a gradient yet in this backward), returns the arena
+    view its gradient kernel may write directly - this skips the temporary + accumulate launch autograd would otherwise need."""
+    owner = getattr(param, '_dsrl_arena', None)
+    if owner is None or not owner.claim(param):
+        return None
+    return param.grad
+
+
 def w_cl(w):
     _need_gpu(w); _f32(w)
     return w.contiguous(memory_format=CL)
@@ -140,6 +172,7 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, dil):
         x, ldx = pm_vec4(x)
+        w_param = w
         w = w_cl(w)
         N, Cc, H, W = x.shape
         K, Cw, R, S = w.shape
@@ -156,6 +189,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.shp = shp
         ctx.has_bias = bias is not None
+        ctx.wparam = w_param if isinstance(w_param, torch.nn.Parameter) else None
         return y
 
     @staticmethod
@@ -167,14 +201,27 @@ class _Conv2d(torch.autograd.Function):
         ldx = _ld_of(x)
         dx = dw = db = None
         st = _stream()
+        if ctx.needs_input_grad[1]:
+            sink = _sink(ctx.wparam) if ctx.wparam is not None and ctx.wparam.is_contiguous(memory_format=CL) else None
+            if sink is not None and overlap_wgrad and ctx.needs_input_grad[0]:
+                cur, side = torch.cuda.current_stream(), side_stream(x.device)
+                side.wait_stream(cur)                                   # dy (and x) are ready on the compute stream
+                with torch.cuda.stream(side):
+                    ws = _ws(query('dsrl_conv2d_wgrad_workspace_bytes', *shp), x)
+                    call('dsrl_conv2d_wgrad', x.data_ptr(), ldx, dy.data_ptr(), lddy, sink.data_ptr(), *shp, ws.data_ptr(), ws.numel(), side.cuda_stream)
+                x.record_stream(side); dy.record_stream(side)
+                ctx.wparam._dsrl_arena.written(ctx.wparam, side)
+            else:
+                dw = sink if sink is not None else torch.empty((K, Cc, R, S), device=x.device, dtype=torch.float32, memory_format=CL)
+                ws = _ws(query('dsrl_conv2d_wgrad_workspace_bytes', *shp), x)
+                call('dsrl_conv2d_wgrad', x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(), *shp, ws.data_ptr(), ws.numel(), st)
+                if sink is not None:
+                    ctx.wparam._dsrl_arena.written(ctx.wparam)
+                    dw = None
         if ctx.needs_input_grad[0]:
             dx = new_cl((N, Cc, H, W), x)
             ws = _ws(query('dsrl_conv2d_dgrad_workspace_bytes', *shp), x)
             call('dsrl_conv2d_dgrad', dy.data_ptr(), lddy, w.data_ptr(), dx.data_ptr(), Cc, *shp, ws.data_ptr(), ws.numel(), st)
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty((K, Cc, R, S), device=x.device, dtype=torch.float32, memory_format=CL)
-            ws = _ws(query('dsrl_conv2d_wgrad_workspace_bytes', *shp), x)
-            call('dsrl_conv2d_wgrad', x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(), *shp, ws.data_ptr(), ws.numel(), st)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             P = dy.shape[0] * dy.shape[2] * dy.shape[3]
             db = torch.empty(K, device=x.device, dtype=torch.float32)
@@ -183,11 +230,57 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+class _StemConv(torch.autograd.Function):
+    """kernel-R x kernel-S, stride-s conv of a few-channel image (the 7x7/2 RGB stem, ResNet101.py:28) as a row-folded
+    implicit GEMM: the image is zero-padded physically to 4 channels and `pad` pixels, and the S (rounded up to 8) horizontal
+    taps x 4 channels of one filter row form one contiguous 32-float K chunk."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        _need_gpu(x, w); _f32(x); _f32(w)
+        N, Cc, H, W = x.shape
+        K, _, R, S = w.shape
+        Sp = (S + 7) & ~7 if S > 4 else 4
+        Cf = Sp * 4
+        Ho, Wo = _out_size(H, R, stride, pad, 1), _out_size(W, S, stride, pad, 1)
+        Hp = max(H + 2 * pad, (Ho - 1) * stride + R)
+        Wp = max(W + 2 * pad, (Wo - 1) * stride + Sp) + 1
+        st = _stream()
+        xp = torch.empty((N, Hp, Wp, 4), device=x.device, dtype=torch.float32)
+        sn, sc, sh, sw = x.stride()
+        call('dsrl_pad_image_nhwc', x.data_ptr(), sn, sc, sh, sw, xp.data_ptr(), N, Cc, H, W, 4, pad, pad, Hp, Wp, st)
+        w2 = torch.zeros((K, R, Sp, 4), device=x.device, dtype=torch.float32)
+        w2[:, :, :S, :Cc] = w.detach().permute(0, 2, 3, 1)
+        y = new_cl((N, K, Ho, Wo), x)
+        macs = query('dsrl_conv2d_inbounds_macs', N, H, W, Cc, K, R, S, stride, pad, 1)
+        shp = (N, Hp, Wp, Cf, K, R, stride, Ho, Wo)
+        ws = _ws(query('dsrl_conv2d_rowfold_fwd_workspace_bytes', *shp), x)
+        call('dsrl_conv2d_rowfold_fwd', xp.data_ptr(), 4, w2.data_ptr(), None, y.data_ptr(), K, *shp, macs, ws.data_ptr(), ws.numel(), st)
+        ctx.save_for_backward(xp)
+        ctx.cfg = (shp, macs, tuple(w.shape), Sp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, = ctx.saved_tensors
+        shp, macs, wshape, Sp = ctx.cfg
+        K, Cc, R, S = wshape
+        if ctx.needs_input_grad[0]:
+            raise DsrlHipError('the image stem has no input-gradient kernel (the reference never differentiates w.r.t. the image)')
+        dy, lddy = pm_vec4(dy)
+        dw2 = torch.empty((K, R, Sp, 4), device=dy.device, dtype=torch.float32)
+        ws = _ws(query('dsrl_conv2d_rowfold_wgrad_workspace_bytes', *shp), dy)
+        call('dsrl_conv2d_rowfold_wgrad', xp.data_ptr(), 4, dy.data_ptr(), lddy, dw2.data_ptr(), *shp, macs, ws.data_ptr(), ws.numel(), _stream())
+        dw = dw2[:, :, :S, :Cc].permute(0, 3, 1, 2)
+        return None, dw, None, None
+
+
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     """nn.Conv2d arithmetic (square stride/padding/dilation) on the MFMA implicit-GEMM kernels."""
+    if x.shape[1] < 4 and bias is None and dilation == 1 and not x.requires_grad:
+        return _StemConv.apply(x, weight, int(stride), int(padding))
     if x.shape[1] % 4 != 0:
-        # 3-channel image stem (ResNet101.py:28): pad input and filter to 4 channels (zeros contribute nothing)
-        padc = 4 - x.shape[1] % 4
+        padc = 4 - x.shape[1] % 4           # generic fallback: pad input and filter channels to a multiple of 4 (zeros contribute nothing)
         x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, padc))
         weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, padc))
     return _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation))
@@ -224,6 +317,7 @@ class _BNAct(torch.autograd.Function):
              res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream), st)
         ctx.save_for_backward(x, y, mean, invstd, gamma)
         ctx.cfg = (bool(training), bool(relu), float(drop_p), residual is not None)
+        ctx.gb = (gamma, beta) if isinstance(gamma, torch.nn.Parameter) and isinstance(beta, torch.nn.Parameter) else None
         return y
 
     @staticmethod
@@ -236,12 +330,20 @@ class _BNAct(torch.autograd.Function):
         P = N * H * W
         dx = new_cl((N, Cc, H, W), x)
         dres = new_cl((N, Cc, H, W), x) if has_res else None
-        dgamma = torch.empty(Cc, device=x.device, dtype=torch.float32)
-        dbeta = torch.empty_like(dgamma)
+        sg = sb = None
+        if ctx.gb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            sg = _sink(ctx.gb[0])
+            sb = _sink(ctx.gb[1]) if sg is not None else None
+        dgamma = sg if sg is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
+        dbeta = sb if sb is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
         ws = _ws(query('dsrl_bn_workspace_bytes', P, Cc), x)
         call('dsrl_bn_bwd', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,
              None if dres is None else dres.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
              dgamma.data_ptr(), dbeta.data_ptr(), int(relu), drop_p, int(training), ws.data_ptr(), ws.numel(), _stream())
+        if sg is not None:
+            ctx.gb[0]._dsrl_arena.written(ctx.gb[0]); dgamma = None
+        if sb is not None:
+            ctx.gb[1]._dsrl_arena.written(ctx.gb[1]); dbeta = None
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, dres
 
 

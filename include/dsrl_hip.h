@@ -64,6 +64,24 @@ int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
 /* in-bounds multiply-accumulates of one forward conv (zero-padding taps excluded): the roofline numerator */
 int64_t dsrl_conv2d_inbounds_macs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 
+/* Row-folded conv for few-channel inputs (the 7x7 stride-2 RGB stem, ResNet101.py:28): the caller pre-pads the image
+ * physically (dsrl_pad_image_nhwc) and folds the S horizontal taps into the channel axis, so that one filter row is ONE
+ * contiguous run of Cfold = S*ldx floats per output pixel: y[n,ho,wo,k] = sum_{r<R} sum_{c<Cfold} x[n, ho*stride + r, wo*stride, c] * w[k][r][c]
+ * (c runs over neighbouring pixels). Requires (Ho-1)*stride + R <= H and (Wo-1)*stride*ldx + Cfold <= W*ldx.
+ * algorithmic_macs is only bookkeeping for the launch timer (the true conv's in-bounds MACs). */
+size_t dsrl_conv2d_rowfold_fwd_workspace_bytes(int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo);
+int dsrl_conv2d_rowfold_fwd(const float* x, int ldx, const float* w, const float* bias /*nullable*/, float* y, int ldy,
+                            int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo, int64_t algorithmic_macs,
+                            void* ws, size_t ws_bytes, dsrl_stream_t stream);
+size_t dsrl_conv2d_rowfold_wgrad_workspace_bytes(int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo);
+/* dw [K][R][Cfold] */
+int dsrl_conv2d_rowfold_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
+                              int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo, int64_t algorithmic_macs,
+                              void* ws, size_t ws_bytes, dsrl_stream_t stream);
+/* y (N,Hp,Wp,Cp) pixel-major, zero except y[n, top+h, left+w, c] = x[n*sn + c*sc + h*sh + w*sw] for c < C */
+int dsrl_pad_image_nhwc(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* y,
+                        int N, int C, int H, int W, int Cp, int top, int left, int Hp, int Wp, dsrl_stream_t stream);
+
 /* column sums: out[c] = sum_p x[p*ld + c]  (conv / convT bias gradients, DSRL.py:50,64-69,78-83) */
 size_t dsrl_colsum_workspace_bytes(int64_t P, int C);
 int dsrl_colsum(const float* x, int ld, int64_t P, int C, float* out, void* ws, size_t ws_bytes, dsrl_stream_t stream);

@@ -386,3 +386,40 @@ def test_full_model_train_steps_run():
     assert all(float(p.grad.abs().sum()) > 0 for p in model.parameters())
     outs = model.eval()(img)
     assert outs[0].shape == (2, 19, 128, 256) and outs[1].shape == (2, 3, 128, 256) and outs[2].shape == (2, 1, 16, 32)
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 32, 64, 8, 7, 2, 3), (1, 3, 37, 51, 16, 7, 2, 3), (2, 3, 16, 24, 8, 3, 1, 1)])
+def test_stem_rowfold_conv_vs_oracle(shape):
+    """The row-folded image-stem path (7x7 stride 2 on RGB, ResNet101.py:28) against the oracle: output and weight gradient."""
+    N, C, H, W, K, R, stride, pad = shape
+    rs = np.random.RandomState(R * H)
+    x = rs.standard_normal((N, C, H, W)).astype(np.float32); w = (rs.standard_normal((K, C, R, R)) * 0.1).astype(np.float32)
+    yo = O.conv2d(x.astype(np.float64), w.astype(np.float64), None, stride, pad, 1)
+    dy = rs.standard_normal(yo.shape).astype(np.float32)
+    _, dwo, _ = O.conv2d_bwd(x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64), stride, pad, 1)
+    wt = dev(w).requires_grad_(True)
+    y = HF.conv2d(dev(x, cl=False), wt, None, stride, pad, 1)         # NCHW image, no grad -> _StemConv
+    assert y.grad_fn is not None and 'StemConv' in type(y.grad_fn).__name__
+    check(host(y), yo, 1e-5, 'y')
+    y.backward(dev(dy))
+    check(host(wt.grad), dwo, 1e-5, 'dw')
+
+
+def test_gradient_sink_matches_autograd_accumulation():
+    """Conv / BN parameter gradients written straight into the FlatParams arena equal the ones autograd accumulates."""
+    from dualsuperreslearningforsemseg_amd.ddp import FlatParams
+    x16, x4, target, org = gen.make_head_inputs(202, 2, 2, 4, gen.SMALL)
+    grads = []
+    for use_arena in (False, True):
+        head, _ = make_head(gen.SMALL, 3, 101, True)
+        flat = FlatParams(head) if use_arena else None
+        if flat is not None:
+            flat.zero_grad()
+        outs = head(dev(x16), dev(x4))
+        hip_losses(outs, dev(target), dev(org), 3)[3].backward()
+        if flat is not None:
+            flat.finish_reduction()              # joins the side stream the weight-gradient kernels ran on
+            assert len(flat._claimed) >= 30
+        grads.append({k: host(p.grad) for k, p in head.named_parameters()})
+    bad = {k: float(np.abs(grads[0][k] - grads[1][k]).max()) for k in grads[0] if not np.array_equal(grads[0][k], grads[1][k])}
+    assert not bad, bad
