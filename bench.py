@@ -60,6 +60,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if os.environ.get('DSRL_ALL_RANKS_ON_GPU0'):                       # rehearsal of the multi-rank path on a one-GPU box
+        local = 0
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f'--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`')
@@ -67,7 +69,11 @@ def main():
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank, device_id=dev)
+        backend = os.environ.get('DSRL_DIST_BACKEND', 'nccl')          # 'nccl' is RCCL on ROCm; 'gloo' only to rehearse N ranks on one GPU
+        if backend == 'nccl':
+            dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank, device_id=dev)
+        else:
+            dist.init_process_group(backend, init_method='env://', world_size=world, rank=rank)
 
     import dualsuperreslearningforsemseg_amd as D
     from dualsuperreslearningforsemseg_amd import _lib, settings
@@ -112,6 +118,11 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
+        # data-parallel invariant: after K identical-seed steps every rank must hold bit-identical parameters
+        chk = torch.stack([flat.p_flat.double().sum(), flat.p_flat.double().abs().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), f'ranks diverged: {lo.tolist()} vs {hi.tolist()}'
 
     roof = None
     if not args.no_prof:

@@ -60,14 +60,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const int c = blockIdx.x * 8 + cl;
     float na = 0.f, ma = 0.f, qa = 0.f;
     if (c < C) {
-        for (int b = sl; b < nbx; b += 32) {
-            const long long o = (long long)b * C + c;
-            const float nb = part[o];
+        float vn[8], vm[8], vq[8];             // nbx <= 256: at most 8 partials per slice, all loads issued before the merge chain
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int b = sl + 32 * j;
+            const bool ok = b < nbx;
+            const long long o = (long long)(ok ? b : 0) * C + c;
+            vn[j] = ok ? part[o] : 0.f; vm[j] = ok ? part[(long long)nbx * C + o] : 0.f; vq[j] = ok ? part[2ll * nbx * C + o] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float nb = vn[j];
             if (nb > 0.f) {
-                const float mb = part[(long long)nbx * C + o], qb = part[2ll * nbx * C + o];
-                const float nt = na + nb, d = mb - ma;
+                const float nt = na + nb, d = vm[j] - ma;
                 ma += d * (nb / nt);
-                qa += qb + d * d * (na * nb / nt);
+                qa += vq[j] + d * d * (na * nb / nt);
                 na = nt;
             }
         }
@@ -159,8 +166,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + cl;
     double a = 0, b = 0;
-    if (c < C)
-        for (int i = sl; i < nbx; i += 32) { a += part[(long long)i * C + c]; b += part[(long long)nbx * C + (long long)i * C + c]; }
+    if (c < C) {
+        float va[8], vb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = sl + 32 * j;
+            const bool ok = i < nbx;
+            va[j] = ok ? part[(long long)i * C + c] : 0.f; vb[j] = ok ? part[(long long)nbx * C + (long long)i * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a += va[j]; b += vb[j]; }
+    }
     sh[0][sl][cl] = a; sh[1][sl][cl] = b;
     __syncthreads();
     if (sl != 0 || c >= C) return;

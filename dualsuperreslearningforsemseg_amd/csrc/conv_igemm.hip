@@ -45,13 +45,14 @@ constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 
 // 4 waves per SIMD (<= 128 registers) for the tiles that stage at most 8 rows per thread: 4 blocks of 36.9 KB LDS per CU
-template <int MR, int NR, int WGM, int WGN, bool DGRAD, int MINW = 2>
+// DBUF: two LDS stages - the next chunk is written while the current one feeds the MFMAs, one barrier per chunk (used when
+// few blocks share a CU); !DBUF: one stage, two barriers, half the LDS (4 blocks per CU on the big grids).
+template <int MR, int NR, int WGM, int WGN, bool DGRAD, int MINW = 2, bool DBUF = false>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArgs a) {
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    constexpr int STAGE = (BM + BN) * LDS_LD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Bs = smem + BM * LDS_LD;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -146,8 +147,11 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
             a_off[i] = ok ? (unsigned)((a_n[i] * a.H + hi) * a.W + wi) * (unsigned)a.ldx * 4u : kOOB;
         }
     };
-    float4 ra[A_IT], rb[B_IT];
-    auto gload = [&](int t, int ch) {
+    // PF register sets: the loads of chunk q+PF are in flight while chunk q feeds the MFMAs (PF = 2 for the small tiles, whose
+    // per-chunk MFMA phase of ~1000 cycles is shorter than the L2/HBM latency of a load)
+    constexpr int PF = (MR * NR <= 2) ? 2 : 1;
+    float4 ra0[A_IT], rb0[B_IT], ra1[PF == 2 ? A_IT : 1], rb1[PF == 2 ? B_IT : 1];
+    auto gload = [&](float4* ra, float4* rb, int t, int ch) {
         const int c = ch * BK + c4 * 4;
         const unsigned coff = c < a.C ? (unsigned)c * 4u : kOOB;          // channel tail of the last chunk reads as zeros
         const unsigned woff = coff + (unsigned)(t * a.C) * 4u;
@@ -157,20 +161,21 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
         for (int i = 0; i < B_IT; ++i) rb[i] = buf_load4(wr, b_off[i] + woff);
     };
 
-    if (q0 < q1) { set_tap(tap); gload(tap, cc); }
     const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
-    for (int q = q0; q < q1; ++q) {
-        // registers -> LDS
+    auto lds_store = [&](const float4* ra, const float4* rb, float* As, float* Bs) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
-        __syncthreads();
-        // next chunk's global loads fly during the MFMAs
-        if (q + 1 < q1) {
-            if (++cc == a.cchunks) { cc = 0; rem_mask &= rem_mask - 1; tap = __builtin_ctzll(rem_mask); set_tap(tap); }
-            gload(tap, cc);
-        }
+    };
+    int issued = q0;           // chunks whose loads have been issued
+    auto issue = [&](float4* ra, float4* rb) {
+        if (issued >= q1) return;
+        if (issued > q0 && ++cc == a.cchunks) { cc = 0; rem_mask &= rem_mask - 1; tap = __builtin_ctzll(rem_mask); set_tap(tap); }
+        gload(ra, rb, tap, cc);
+        ++issued;
+    };
+    auto compute = [&](const float* As, const float* Bs) {
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
             float4 fa[MR], fb[NR];
@@ -190,7 +195,45 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();
+    };
+    if (q0 < q1) set_tap(tap);
+    if (DBUF) {
+        if (q0 < q1) {
+            issue(ra0, rb0);
+            lds_store(ra0, rb0, smem, smem + BM * LDS_LD);
+            issue(ra0, rb0);
+            __syncthreads();
+        }
+        for (int q = q0; q < q1; ++q) {
+            const int cur = (q - q0) & 1;
+            float* nA = smem + (cur ^ 1) * STAGE;
+            if (q + 1 < q1) {
+                lds_store(ra0, rb0, nA, nA + BM * LDS_LD);   // stage q+1 (free since the barrier that ended iteration q-1)
+                issue(ra0, rb0);                              // chunk q+2 flies during this iteration's MFMAs
+            }
+            const float* cA = smem + cur * STAGE;
+            compute(cA, cA + BM * LDS_LD);
+            __syncthreads();
+        }
+    } else {
+        float* As = smem;
+        float* Bs = smem + BM * LDS_LD;
+        issue(ra0, rb0);
+        if (PF == 2) issue(ra1, rb1);
+        for (int q = q0; q < q1; q += PF) {
+            lds_store(ra0, rb0, As, Bs);
+            __syncthreads();
+            issue(ra0, rb0);                                  // chunk q+PF
+            compute(As, Bs);
+            __syncthreads();
+            if (PF == 2 && q + 1 < q1) {
+                lds_store(ra1, rb1, As, Bs);
+                __syncthreads();
+                issue(ra1, rb1);                              // chunk q+3
+                compute(As, Bs);
+                __syncthreads();
+            }
+        }
     }
 
     // ---- epilogue: D[row][col], col = lane&31 (out channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); bounds by the descriptor
@@ -465,15 +508,28 @@ template <bool DGRAD>
 static int launch_igemm(const ConvArgs& a, TileCfg cfg, hipStream_t st) {
     int bm, bn; cfg_dims(cfg, bm, bn);
     dim3 grid((unsigned)ceil_div(a.M, bm), (unsigned)ceil_div(a.K, bn), (unsigned)a.splits);
-    const size_t lds = (size_t)(bm + bn) * LDS_LD * sizeof(float);
-#define DSRL_LAUNCH_IGEMM(a_, b_, c_, d_) hipLaunchKernelGGL((conv_igemm_f32_kernel<a_, b_, c_, d_, DGRAD>), grid, dim3(256), lds, st, a)
+    const size_t lds1 = (size_t)(bm + bn) * LDS_LD * sizeof(float);
+    const long long nblocks = (long long)grid.x * grid.y * grid.z;
+    const bool dbuf = env_int("DSRL_IGEMM_DBUF", (bm + bn <= 192 || nblocks <= 2 * kNumCU) ? 1 : 0) != 0;
+#define DSRL_LAUNCH_IGEMM(a_, b_, c_, d_) hipLaunchKernelGGL((conv_igemm_f32_kernel<a_, b_, c_, d_, DGRAD>), grid, dim3(256), lds1, st, a)
+#define DSRL_LAUNCH_IGEMM_DB(a_, b_, c_, d_) hipLaunchKernelGGL((conv_igemm_f32_kernel<a_, b_, c_, d_, DGRAD, 2, true>), grid, dim3(256), 2 * lds1, st, a)
     // 1024+ tiles of 128x128: the <=128-register build keeps 4 blocks per CU resident (one round instead of 1.33)
-    if (cfg == T128x128 && env_int("DSRL_IGEMM_OCC4", (long long)grid.x * grid.y * grid.z > 3 * kNumCU ? 1 : 0)) {
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 2, 2, 2, DGRAD, 4>), grid, dim3(256), lds, st, a);
+    if (cfg == T128x128 && !dbuf && env_int("DSRL_IGEMM_OCC4", nblocks > 3 * kNumCU ? 1 : 0)) {
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 2, 2, 2, DGRAD, 4>), grid, dim3(256), lds1, st, a);
+    } else if (dbuf) {
+        static bool attr_set[2] = {false, false};
+        if (2 * lds1 > 65536 && !attr_set[DGRAD ? 1 : 0]) {       // > 64 KiB of dynamic LDS needs the opt-in attribute (256x64 / 128x128 tiles)
+            hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<2, 2, 2, 2, DGRAD, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+            hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<2, 2, 4, 1, DGRAD, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+            hipFuncSetAttribute((const void*)conv_igemm_f32_kernel<2, 1, 4, 1, DGRAD, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+            attr_set[DGRAD ? 1 : 0] = true;
+        }
+        DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_IGEMM_DB)
     } else {
         DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_IGEMM)
     }
 #undef DSRL_LAUNCH_IGEMM
+#undef DSRL_LAUNCH_IGEMM_DB
     return launch_status("conv_igemm_f32_kernel");
 }
 

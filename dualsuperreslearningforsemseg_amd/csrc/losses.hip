@@ -43,10 +43,12 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     const double n = block_sum_d(cnt, shd);
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = l; part[2 * blockIdx.x + 1] = n; }
 }
-__global__ void ce_finalize_kernel(const double* __restrict__ part, int nb, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double l = 0, n = 0;
-        for (int i = 0; i < nb; ++i) { l += part[2 * i]; n += part[2 * i + 1]; }
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const double* __restrict__ part, int nb, float* __restrict__ out) {
+    __shared__ double shd[4];
+    double l = 0, n = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) { l += part[2 * i]; n += part[2 * i + 1]; }
+    l = block_sum_d(l, shd); n = block_sum_d(n, shd);
+    if (threadIdx.x == 0) {
         out[0] = (float)(l / n);        // 0/0 = NaN when every pixel is ignored, as torch
         out[1] = (float)n;
     }
@@ -91,12 +93,12 @@ __global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ 
     const double t = block_sum_d(s, shd);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
-__global__ void mse_finalize_kernel(const double* __restrict__ part, int nb, long long n, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0;
-        for (int i = 0; i < nb; ++i) s += part[i];
-        out[0] = (float)(s / (double)n);
-    }
+__global__ __launch_bounds__(256) void mse_finalize_kernel(const double* __restrict__ part, int nb, long long n, float* __restrict__ out) {
+    __shared__ double shd[4];
+    double s = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+    s = block_sum_d(s, shd);
+    if (threadIdx.x == 0) out[0] = (float)(s / (double)n);
 }
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, const float* __restrict__ grad_out,
                                                        float* __restrict__ da) {
@@ -318,7 +320,7 @@ extern "C" int dsrl_ce_fwd(const float* logits, int ld, const uint8_t* target, i
     const int nb = loss_blocks(P);
     hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), (size_t)256 * C * sizeof(float), st, logits, ld, target, (long long)P, C, ignore_index, (double*)ws);
     if (int e = launch_status("ce_fwd_kernel")) return e;
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, loss_out);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, loss_out);
     return launch_status("ce_finalize_kernel");
 }
 extern "C" int dsrl_ce_bwd(const float* logits, int ld, const uint8_t* target, int64_t P, int C, int ignore_index, const float* loss_out,
@@ -340,7 +342,7 @@ extern "C" int dsrl_mse_fwd(const float* a, const float* b, int64_t n, float* lo
     const int nb = loss_blocks(n / 4 + 1);
     hipLaunchKernelGGL(mse_fwd_kernel, dim3(nb), dim3(256), 0, st, a, b, (long long)n, (double*)ws);
     if (int e = launch_status("mse_fwd_kernel")) return e;
-    hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, (long long)n, loss_out);
+    hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, (long long)n, loss_out);
     return launch_status("mse_finalize_kernel");
 }
 extern "C" int dsrl_mse_bwd(const float* a, const float* b, int64_t n, const float* grad_out, float* da, dsrl_stream_t stream) {

@@ -370,12 +370,15 @@ __global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float* __restr
         __syncthreads();
     }
 }
-__global__ void pointwise_dw_finalize_kernel(const float* __restrict__ part, int nblocks, int C, float* __restrict__ dw) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void pointwise_dw_finalize_kernel(const float* __restrict__ part, int nblocks, int C, float* __restrict__ dw) {
+    __shared__ double sh[4];            // one block per channel
+    const int c = blockIdx.x;
     double s = 0;
-    for (int b = 0; b < nblocks; ++b) s += part[(long long)b * C + c];
-    dw[c] = (float)s;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(long long)b * C + c];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dw[c] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
 // ---------------------------------------------------------------------------------------------- NCHW -> pixel-major
@@ -514,7 +517,7 @@ extern "C" int dsrl_pointwise_strided_bwd(const float* x, const float* w, const 
     const int nb = pointwise_blocks(N, H, W, stride);
     hipLaunchKernelGGL(pointwise_bwd_kernel, dim3(nb), dim3(256), 256 * sizeof(float), st, x, w, dy, dx, (float*)ws, accumulate, N, H, W, C, stride, Ho, Wo);
     if (int e = launch_status("pointwise_bwd_kernel")) return e;
-    hipLaunchKernelGGL(pointwise_dw_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, st, (const float*)ws, nb, C, dw);
+    hipLaunchKernelGGL(pointwise_dw_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, (const float*)ws, nb, C, dw);
     return launch_status("pointwise_dw_finalize_kernel");
 }
 

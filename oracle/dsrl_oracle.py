@@ -20,7 +20,7 @@ __all__ = [
     'conv_transpose2d_k2s2_bwd', 'pixel_shuffle', 'pixel_shuffle_bwd', 'avg_pool2d', 'avg_pool2d_bwd',
     'global_avg_pool', 'global_avg_pool_bwd', 'max_pool3x3s2', 'max_pool3x3s2_bwd', 'fa_similarity', 'fa_loss', 'fa_loss_bwd',
     'cross_entropy', 'cross_entropy_bwd', 'mse', 'mse_bwd', 'sgd_step', 'dropout_mask',
-    'Tape', 'Var', 'head_forward', 'total_loss', 'HeadOutputs', 'miou_batch',
+    'Tape', 'Var', 'head_forward', 'total_loss', 'HeadOutputs', 'miou_batch', 'backbone_forward', 'model_forward',
 ]
 
 
@@ -459,6 +459,15 @@ class Tape:
     def gap(self, x):
         return self.node(global_avg_pool(x.v), lambda dy: x.acc(global_avg_pool_bwd(x.v.shape[2:], dy)))
 
+    def maxpool(self, x):
+        y, arg = max_pool3x3s2(x.v)
+        return self.node(y, lambda dy: x.acc(max_pool3x3s2_bwd(x.v.shape[2:], arg, dy)))
+
+    def add(self, a, b):
+        def bw(dy):
+            a.acc(dy); b.acc(dy)
+        return self.node(a.v + b.v, bw)
+
 
 class HeadOutputs:
     """The 4-tuple DSRL.forward returns (DSRL.py:186) plus the tape to back-propagate through."""
@@ -480,7 +489,7 @@ def _cbr(tp, P, R, x, prefix, conv_i, bn_i, training, new_running, stride=1, pad
 
 
 def head_forward(params, backbone_features, lowlevel_features, stage=3, bn_training=False, dropout_seed=None,
-                 aspp_rate=1):
+                 aspp_rate=1, tape=None, leaves=None, new_running=None):
     """Replays DSRL.forward lines DSRL.py:162-184 on given backbone outputs.
 
     params: dict keyed by the reference's state_dict names (non-backbone entries; numpy arrays).
@@ -488,15 +497,20 @@ def head_forward(params, backbone_features, lowlevel_features, stage=3, bn_train
     Returns HeadOutputs; call `.tape.backward()` after seeding `.SSSR.g` etc. to get gradients in
     `.params[name].g` and `.inputs[i].g`.
     """
-    tp = Tape()
+    tp = tape if tape is not None else Tape()
     out = HeadOutputs(); out.tape = tp
-    P = {k: tp.leaf(v, k) for k, v in params.items() if not (k.endswith('running_mean') or k.endswith('running_var')
-                                                             or k.endswith('num_batches_tracked'))}
-    R = {k: np.asarray(v) for k, v in params.items() if k.endswith('running_mean') or k.endswith('running_var')}
+    if leaves is not None:
+        P, R = leaves
+    else:
+        P = {k: tp.leaf(v, k) for k, v in params.items() if not (k.endswith('running_mean') or k.endswith('running_var')
+                                                                 or k.endswith('num_batches_tracked'))}
+        R = {k: np.asarray(v) for k, v in params.items() if k.endswith('running_mean') or k.endswith('running_var')}
     out.params = P
-    x16 = tp.leaf(backbone_features, 'backbone_features')
-    x4 = tp.leaf(lowlevel_features, 'lowlevel_features')
+    x16 = backbone_features if isinstance(backbone_features, Var) else tp.leaf(backbone_features, 'backbone_features')
+    x4 = lowlevel_features if isinstance(lowlevel_features, Var) else tp.leaf(lowlevel_features, 'lowlevel_features')
     out.inputs = (x16, x4)
+    if new_running is not None:
+        out.new_running = new_running
     nr = out.new_running
     hw16 = x16.v.shape[2:]
 
@@ -538,6 +552,51 @@ def head_forward(params, backbone_features, lowlevel_features, stage=3, bn_train
         if stage > 2:                                                   # DSRL.py:179-184
             out.SSSR_ft = _cbr(tp, P, R, out.SSSR, 'SSSR_feature_transformer', 0, 1, bn_training, nr, 8, 0, 1)
             out.SISR_ft = _cbr(tp, P, R, out.SISR, 'SISR_feature_transformer', 0, 1, bn_training, nr, 8, 0, 1)
+    return out
+
+
+def backbone_forward(tp, P, R, x, bn_training, new_running, prefix='feature_extractor.backbone'):
+    """ResNet-101, output stride 16 (ResNet101.py:91-104 with torchvision's Bottleneck: 1x1 -> 3x3(stride, dilation) -> 1x1,
+    expansion 4, stride on the 3x3; layers [3,4,23,3], replace_stride_with_dilation=[F,F,T]).  Returns (layer4, layer1)."""
+    def cbr(x, conv, bn, stride=1, pad=0, dil=1, relu=True):
+        z = tp.conv(x, P[f'{prefix}.{conv}.weight'], None, stride, pad, dil)
+        z = tp.bn(z, P[f'{prefix}.{bn}.weight'], P[f'{prefix}.{bn}.bias'], R[f'{prefix}.{bn}.running_mean'], R[f'{prefix}.{bn}.running_var'],
+                  bn_training, new_running, f'{prefix}.{bn}')
+        return tp.relu(z) if relu else z
+
+    x = cbr(x, 'conv1', 'bn1', 2, 3, 1)
+    x = tp.maxpool(x)
+    low = None
+    dilation = 1
+    for li, (blocks, stride, dilate) in enumerate([(3, 1, False), (4, 2, False), (23, 2, False), (3, 2, True)], start=1):
+        prev_dil = dilation
+        if dilate:
+            dilation *= stride; stride = 1
+        for b in range(blocks):
+            name = f'layer{li}.{b}'
+            st = stride if b == 0 else 1
+            dl = prev_dil if b == 0 else dilation
+            identity = x
+            if f'{prefix}.{name}.downsample.0.weight' in P:
+                identity = cbr(x, f'{name}.downsample.0', f'{name}.downsample.1', st, 0, 1, relu=False)
+            out = cbr(x, f'{name}.conv1', f'{name}.bn1')
+            out = cbr(out, f'{name}.conv2', f'{name}.bn2', st, dl, dl)
+            out = cbr(out, f'{name}.conv3', f'{name}.bn3', relu=False)
+            x = tp.relu(tp.add(out, identity))
+        if li == 1:
+            low = x
+    return x, low
+
+
+def model_forward(params, image, stage=3, bn_training=False, dropout_seed=None):
+    """Whole DSRL.forward (DSRL.py:158-186): ResNet-101 backbone + head, on an NCHW image."""
+    tp = Tape()
+    P = {k: tp.leaf(v, k) for k, v in params.items() if not (k.endswith('running_mean') or k.endswith('running_var') or k.endswith('num_batches_tracked'))}
+    R = {k: np.asarray(v) for k, v in params.items() if k.endswith('running_mean') or k.endswith('running_var')}
+    x = tp.leaf(image, 'image')
+    nr = {}
+    x16, x4 = backbone_forward(tp, P, R, x, bn_training, nr)
+    out = head_forward(params, x16, x4, stage, bn_training, dropout_seed, tape=tp, leaves=(P, R), new_running=nr)
     return out
 
 
