@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
     };
     // PF register sets: the loads of chunk q+PF are in flight while chunk q feeds the MFMAs (PF = 2 for the small tiles, whose
     // per-chunk MFMA phase of ~1000 cycles is shorter than the L2/HBM latency of a load)
-    constexpr int PF = (MR * NR <= 2) ? 2 : 1;
+    constexpr int PF = 1;      // measured on MI355X: a second prefetch stage (PF = 2) buys nothing on any layer of the step
     float4 ra0[A_IT], rb0[B_IT], ra1[PF == 2 ? A_IT : 1], rb1[PF == 2 ? B_IT : 1];
     auto gload = [&](float4* ra, float4* rb, int t, int ch) {
         const int c = ch * BK + c4 * 4;
@@ -359,15 +359,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs a) 
             rb[i] = buf_load4(xr, off + b_coff);
         }
     };
-    if (ch0 < ch1) gload(ch0);
+    // a 32-pixel chunk whose pixels all read zero padding for this tap contributes nothing: skip it (block-uniform test)
+    auto chunk_live = [&](long long ch) -> bool {
+        const int pf = (int)ch * BP, pl = min(pf + BP, Pi) - 1;
+        const int nf = pf / HoWo, nl = pl / HoWo;
+        if (nf != nl) return true;
+        const int hf = (pf - nf * HoWo) / a.Wo, hl = (pl - nl * HoWo) / a.Wo;
+        if (hl * a.stride + dh < 0 || hf * a.stride + dh >= a.H) return false;
+        if (hf == hl) {
+            const int wf = pf - nf * HoWo - hf * a.Wo, wl = pl - nl * HoWo - hl * a.Wo;
+            if (wl * a.stride + dw_ < 0 || wf * a.stride + dw_ >= a.W) return false;
+        }
+        return true;
+    };
+    auto next_live = [&](long long ch) { while (ch < ch1 && !chunk_live(ch)) ++ch; return ch; };
+    long long ch = next_live(ch0);
+    if (ch < ch1) gload(ch);
     const int fi = lane & 31, fh = lane >> 5;
-    for (long long ch = ch0; ch < ch1; ++ch) {
+    while (ch < ch1) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) *reinterpret_cast<float4*>(&As[(a_row + i * A_RP) * BM + a_col]) = ra[i];
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(&Bs[(b_row + i * B_RP) * BN + b_col]) = rb[i];
         __syncthreads();
-        if (ch + 1 < ch1) gload(ch + 1);
+        const long long nxt = next_live(ch + 1);
+        if (nxt < ch1) gload(nxt);
 #pragma unroll
         for (int st = 0; st < BP / 2; ++st) {
             float fa[MR], fb[NR];
@@ -381,6 +397,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs a) 
                 for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
+        ch = nxt;
     }
     float* out = a.dw + (a.psplits > 1 ? (long long)blockIdx.z * a.slab : 0ll);
     const int RS = a.R * a.S;
@@ -501,7 +518,7 @@ static int pick_splits(long long tiles, int nq) {
     if (forced > 0) return std::max(1, std::min(forced, std::max(1, nq)));
     if (tiles >= 3 * kNumCU) return 1;
     const long long cap = std::min<long long>(8, ceil_div(6 * kNumCU, std::max<long long>(tiles, 1)));
-    return (int)std::max<long long>(1, std::min<long long>(nq / 48, cap));
+    return (int)std::max<long long>(1, std::min<long long>(nq / 24, cap));
 }
 
 template <bool DGRAD>
@@ -510,7 +527,7 @@ static int launch_igemm(const ConvArgs& a, TileCfg cfg, hipStream_t st) {
     dim3 grid((unsigned)ceil_div(a.M, bm), (unsigned)ceil_div(a.K, bn), (unsigned)a.splits);
     const size_t lds1 = (size_t)(bm + bn) * LDS_LD * sizeof(float);
     const long long nblocks = (long long)grid.x * grid.y * grid.z;
-    const bool dbuf = env_int("DSRL_IGEMM_DBUF", (bm + bn <= 192 || nblocks <= 2 * kNumCU) ? 1 : 0) != 0;
+    const bool dbuf = env_int("DSRL_IGEMM_DBUF", 0) != 0;     // measured: no gain from the two-stage LDS variant; kept selectable
 #define DSRL_LAUNCH_IGEMM(a_, b_, c_, d_) hipLaunchKernelGGL((conv_igemm_f32_kernel<a_, b_, c_, d_, DGRAD>), grid, dim3(256), lds1, st, a)
 #define DSRL_LAUNCH_IGEMM_DB(a_, b_, c_, d_) hipLaunchKernelGGL((conv_igemm_f32_kernel<a_, b_, c_, d_, DGRAD, 2, true>), grid, dim3(256), 2 * lds1, st, a)
     // 1024+ tiles of 128x128: the <=128-register build keeps 4 blocks per CU resident (one round instead of 1.33)
