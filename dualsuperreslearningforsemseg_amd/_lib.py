@@ -29,7 +29,9 @@ PROTOTYPES = {
     'dsrl_conv2d_fwd_workspace_bytes': (sz, _conv_shape),
     'dsrl_conv2d_fwd': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv2d_dgrad_workspace_bytes': (sz, _conv_shape),
-    'dsrl_conv2d_dgrad': (i32, [fp, i32, fp, fp, i32] + _conv_shape + [fp, sz, stream_t]),
+    'dsrl_conv2d_transposed_filter_floats': (sz, [i32] * 4),
+    'dsrl_conv2d_transpose_filter': (i32, [fp, fp, i32, i32, i32, i32, stream_t]),
+    'dsrl_conv2d_dgrad': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv2d_wgrad_workspace_bytes': (sz, _conv_shape),
     'dsrl_conv2d_wgrad': (i32, [fp, i32, fp, i32, fp] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv2d_inbounds_macs': (i64, _conv_shape),
@@ -51,7 +53,7 @@ PROTOTYPES = {
     'dsrl_bilinear_ac_bwd': (i32, [fp, i32, fp, i32, i32, i32, i32, i32, i32, i32, stream_t]),
     'dsrl_global_avgpool_fwd': (i32, [fp, i32, fp, i32, i32, i32, stream_t]),
     'dsrl_global_avgpool_bwd': (i32, [fp, fp, i32, i32, i32, i32, stream_t]),
-    'dsrl_maxpool3x3s2_fwd': (i32, [fp, fp, i32, i32, i32, i32, stream_t]),
+    'dsrl_maxpool3x3s2_fwd': (i32, [fp, fp, fp, i32, i32, i32, i32, stream_t]),
     'dsrl_maxpool3x3s2_bwd': (i32, [fp, fp, fp, i32, i32, i32, i32, stream_t]),
     'dsrl_convt2x2_fwd': (i32, [fp, fp, fp, fp, i32, i32, i32, i32, i32, stream_t]),
     'dsrl_convt2x2_bwd_workspace_bytes': (sz, [i32] * 5),

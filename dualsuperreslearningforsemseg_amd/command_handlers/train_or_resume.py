@@ -78,6 +78,8 @@ class TrainStep:
         return ce, ms, fa, ce + ms + fa                                                    # :438
 
     def __call__(self, input_image, input_org, target, lr, momentum, weight_decay, do_train=True):
+        import time
+        t_host0 = time.perf_counter()
         flat = self.flat
         if do_train:
             flat.zero_grad()                                                               # optimizer.zero_grad(), :418
@@ -90,6 +92,7 @@ class TrainStep:
             if do_train:
                 total.backward()                                                           # :444 (chunked RCCL all-reduce overlaps)
                 flat.sgd_step(lr, momentum, weight_decay)                                  # :445
+        self.host_enqueue_s = time.perf_counter() - t_host0                   # time the host needed to enqueue the whole step
         vals = t.cat([t.stack([ce, ms, fa, total]).detach().float(), self.flag.float()]).cpu()   # ONE device->host read
         if vals[4] != 0:
             raise AssertionError("network output contains 'NaN' values and so cannot continue.")

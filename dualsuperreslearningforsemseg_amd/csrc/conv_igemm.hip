@@ -419,17 +419,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs a) 
 }
 
 struct TapList { int taps[64]; int n; };
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int psplits, long long slab, float* __restrict__ dw,
+// dw[k][tap][c] = sum_z slab[z][k][tap][c] over the active taps; C % 4 == 0, one float4 per thread, slabs unrolled by 4
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int psplits, long long slab, float* __restrict__ dw,
                                     int K, int RS, int C, TapList tl) {
-    const long long total = (long long)K * tl.n * C;
+    const int C4 = C >> 2;
+    const long long total = (long long)K * tl.n * C4;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C);
-        const long long t = e / C;
+        const int c4 = (int)(e % C4);
+        const long long t = e / C4;
         const int ti = (int)(t % tl.n), k = (int)(t / tl.n);
-        const long long idx = ((long long)k * RS + tl.taps[ti]) * C + c;
-        float s = 0.f;
-        for (int zz = 0; zz < psplits; ++zz) s += slabs[zz * slab + idx];
-        dw[idx] = s;
+        const long long idx = ((long long)k * RS + tl.taps[ti]) * C + 4 * c4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int zz = 0;
+        for (; zz + 4 <= psplits; zz += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(slabs + (zz + 0) * slab + idx), b = *reinterpret_cast<const float4*>(slabs + (zz + 1) * slab + idx);
+            const float4 c = *reinterpret_cast<const float4*>(slabs + (zz + 2) * slab + idx), d = *reinterpret_cast<const float4*>(slabs + (zz + 3) * slab + idx);
+            s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y); s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+        }
+        for (; zz < psplits; ++zz) {
+            const float4 a = *reinterpret_cast<const float4*>(slabs + zz * slab + idx);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        *reinterpret_cast<float4*>(dw + idx) = s;
     }
 }
 
@@ -632,7 +643,17 @@ extern "C" size_t dsrl_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, 
     return dgrad_wt_bytes(C, K, R, S) + plan_fwd(N, Ho, Wo, pad4(K), C, R, S, H, W).ws;
 }
 
-extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx,
+extern "C" size_t dsrl_conv2d_transposed_filter_floats(int C, int K, int R, int S) { return (size_t)C * R * S * pad4(K); }
+extern "C" int dsrl_conv2d_transpose_filter(const float* w, float* wt, int C, int K, int R, int S, dsrl_stream_t stream) {
+    DSRL_REQUIRE(w && wt && C > 0 && K > 0 && R > 0 && S > 0, DSRL_E_BADARG, "conv2d_transpose_filter: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const int Kp = pad4(K);
+    hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)ceil_div(C, 32), (unsigned)ceil_div(Kp, 32), (unsigned)(R * S)), dim3(256), 0, st, w, wt, K, Kp, R * S, C);
+    return launch_status("weight_transpose_kernel");
+}
+
+extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
                                  int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                                  void* ws, size_t ws_bytes, dsrl_stream_t stream) {
     if (int e = check_conv(dy, w, dx, N, H, W, C, K, R, S, stride, pad, dil)) return e;
@@ -646,11 +667,14 @@ extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, floa
     const FwdPlan p = plan_fwd(N, Ho, Wo, Kp, C, R, S, H, W);
     const size_t wtb = dgrad_wt_bytes(C, K, R, S);
     DSRL_REQUIRE(ws && ws_bytes >= wtb + p.ws, DSRL_E_WORKSPACE, "conv2d_dgrad: workspace %zu < %zu", ws_bytes, wtb + p.ws);
-    float* wt = (float*)ws;
+    const float* wt = wt_in;
     float* slabs = (float*)((char*)ws + wtb);
-    hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)ceil_div(C, 32), (unsigned)ceil_div(Kp, 32), (unsigned)(R * S)), dim3(256), 0, st,
-                       w, wt, K, Kp, R * S, C);
-    if (int e = launch_status("weight_transpose_kernel")) return e;
+    if (wt == nullptr) {
+        hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)ceil_div(C, 32), (unsigned)ceil_div(Kp, 32), (unsigned)(R * S)), dim3(256), 0, st,
+                           w, (float*)ws, K, Kp, R * S, C);
+        if (int e = launch_status("weight_transpose_kernel")) return e;
+        wt = (const float*)ws;
+    }
     ConvArgs a{};
     a.x = dy; a.w = wt; a.ldx = lddy; a.N = N; a.H = Ho; a.W = Wo; a.C = Kp; a.K = C; a.R = R; a.S = S; a.Ho = H; a.Wo = W;
     a.stride = stride; a.pad = pad; a.dil = dil; a.M = p.M; a.cchunks = p.cchunks; a.splits = p.splits; a.slab = (long long)p.M * C;
@@ -733,7 +757,7 @@ extern "C" int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int l
 #undef DSRL_LAUNCH_WGRAD
     if (int e = launch_status("conv_wgrad_f32_kernel")) return e;
     if (p.psplits > 1) {
-        const long long total = (long long)K * p.tl.n * C;
+        const long long total = (long long)K * p.tl.n * (C / 4);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st,
                            (const float*)ws, p.psplits, a.slab, dw, K, RS, C, p.tl);
         return launch_status("wgrad_reduce_kernel");
@@ -831,7 +855,7 @@ extern "C" int dsrl_conv2d_rowfold_wgrad(const float* x, int ldx, const float* d
 #undef DSRL_LAUNCH_WGRAD
     if (int e = launch_status("conv_wgrad_f32_kernel")) return e;
     if (p.psplits > 1) {
-        const long long total = (long long)K * R * Cfold;
+        const long long total = (long long)K * R * (Cfold / 4);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st,
                            (const float*)ws, p.psplits, a.slab, dw, K, R, Cfold, p.tl);
         return launch_status("wgrad_reduce_kernel");

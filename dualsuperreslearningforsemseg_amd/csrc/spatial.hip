@@ -78,18 +78,19 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------- pools
+// one block = 64 channels x 4 pixel slots of one image (N * C/64 blocks)
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int HW, int C) {
-    __shared__ float sh[256];
-    const ChanMap m = chan_map(C, blockIdx.y);
-    const int n = blockIdx.x;
+    __shared__ float sh[4][64];
+    const int n = blockIdx.x, cl = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
     float s = 0.f;
-    if (m.c >= 0) for (int p = m.slot; p < HW; p += m.G) s += x[((long long)n * HW + p) * ldx + m.c];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (m.c >= 0 && m.slot == 0) {
-        for (int g = 1; g < m.G; ++g) s += sh[g * m.cg + (m.c - m.cg0)];
-        y[(long long)n * C + m.c] = s / (float)HW;
+    if (c < C) {
+#pragma unroll 4
+        for (int p = slot; p < HW; p += 4) s += x[((long long)n * HW + p) * ldx + c];
     }
+    sh[slot][cl] = s;
+    __syncthreads();
+    if (slot == 0 && c < C) y[(long long)n * C + c] = (sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]) / (float)HW;
 }
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int lddx, int N, int HW, int C) {
     const long long total = (long long)N * HW * C;
@@ -100,14 +101,15 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
+                                                           int N, int H, int W, int C, int Ho, int Wo) {
     const long long total = (long long)N * Ho * Wo * C;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
         long long pix = e / C;
         const int wo = (int)(pix % Wo); pix /= Wo;
         const int ho = (int)(pix % Ho); const int n = (int)(pix / Ho);
-        float best = -INFINITY;
+        float best = -INFINITY; int bi = 0;
         for (int r = 0; r < 3; ++r) {
             const int h = 2 * ho - 1 + r;
             if (h < 0 || h >= H) continue;
@@ -115,14 +117,15 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
                 const int w = 2 * wo - 1 + s;
                 if (w < 0 || w >= W) continue;
                 const float v = x[((long long)(n * H + h) * W + w) * C + c];
-                if (v > best || v != v) best = v;
+                if (v > best || v != v) { best = v; bi = r * 3 + s; }       // first maximum in scan order (torch max_pool2d)
             }
         }
         y[e] = best;
+        if (idx) idx[e] = (unsigned char)bi;
     }
 }
-// the gradient of a window goes to its first maximum in scan order (torch max_pool2d)
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+// the gradient of a window goes to the tap its forward pass recorded
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ idx, const float* __restrict__ dy, float* __restrict__ dx,
                                                            int N, int H, int W, int C, int Ho, int Wo) {
     const long long total = (long long)N * H * W * C;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -133,18 +136,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         float acc = 0.f;
         for (int ho = max(0, h / 2); ho <= min(Ho - 1, (h + 1) / 2); ++ho)
             for (int wo = max(0, w / 2); wo <= min(Wo - 1, (w + 1) / 2); ++wo) {
-                float best = -INFINITY; int bh = -1, bw = -1;
-                for (int r = 0; r < 3; ++r) {
-                    const int hh = 2 * ho - 1 + r;
-                    if (hh < 0 || hh >= H) continue;
-                    for (int s = 0; s < 3; ++s) {
-                        const int ww = 2 * wo - 1 + s;
-                        if (ww < 0 || ww >= W) continue;
-                        const float v = x[((long long)(n * H + hh) * W + ww) * C + c];
-                        if (v > best || v != v) { best = v; bh = hh; bw = ww; }
-                    }
-                }
-                if (bh == h && bw == w) acc += dy[((long long)(n * Ho + ho) * Wo + wo) * C + c];
+                const long long o = ((long long)(n * Ho + ho) * Wo + wo) * C + c;
+                const int tap = (h - (2 * ho - 1)) * 3 + (w - (2 * wo - 1));
+                if (idx[o] == tap) acc += dy[o];
             }
         dx[e] = acc;
     }
@@ -423,7 +417,7 @@ extern "C" int dsrl_bilinear_ac_bwd(const float* dy, int lddy, float* dx, int ld
 }
 extern "C" int dsrl_global_avgpool_fwd(const float* x, int ldx, float* y, int N, int HW, int C, dsrl_stream_t stream) {
     DSRL_PROLOGUE(x && y && N > 0 && HW > 0 && C > 0 && ldx >= C, "global_avgpool_fwd")
-    hipLaunchKernelGGL(gap_fwd_kernel, dim3(N, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ldx, y, HW, C);
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(N, (unsigned)ceil_div(C, 64)), dim3(256), 0, st, x, ldx, y, HW, C);
     return launch_status("gap_fwd_kernel");
 }
 extern "C" int dsrl_global_avgpool_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, dsrl_stream_t stream) {
@@ -431,16 +425,16 @@ extern "C" int dsrl_global_avgpool_bwd(const float* dy, float* dx, int lddx, int
     hipLaunchKernelGGL(gap_bwd_kernel, dim3(flat_grid((long long)N * HW * C)), dim3(256), 0, st, dy, dx, lddx, N, HW, C);
     return launch_status("gap_bwd_kernel");
 }
-extern "C" int dsrl_maxpool3x3s2_fwd(const float* x, float* y, int N, int H, int W, int C, dsrl_stream_t stream) {
+extern "C" int dsrl_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, dsrl_stream_t stream) {
     DSRL_PROLOGUE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "maxpool3x3s2_fwd")
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(flat_grid((long long)N * Ho * Wo * C)), dim3(256), 0, st, x, y, N, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(flat_grid((long long)N * Ho * Wo * C)), dim3(256), 0, st, x, y, argmax, N, H, W, C, Ho, Wo);
     return launch_status("maxpool_fwd_kernel");
 }
-extern "C" int dsrl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, dsrl_stream_t stream) {
-    DSRL_PROLOGUE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool3x3s2_bwd")
+extern "C" int dsrl_maxpool3x3s2_bwd(const uint8_t* argmax, const float* dy, float* dx, int N, int H, int W, int C, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(argmax && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool3x3s2_bwd")
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(flat_grid((long long)N * H * W * C)), dim3(256), 0, st, x, dy, dx, N, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(flat_grid((long long)N * H * W * C)), dim3(256), 0, st, argmax, dy, dx, N, H, W, C, Ho, Wo);
     return launch_status("maxpool_bwd_kernel");
 }
 

@@ -24,6 +24,9 @@ def _stream():
 # reduces / applies the gradients; without an arena the caller's stream waits right away.
 _side = {}
 overlap_wgrad = os.environ.get('DSRL_OVERLAP_WGRAD', '1') != '0'     # measured: +10-13 % step throughput on one MI355X
+# building dgrad's transposed filters during the forward pass on the side stream: measured SLOWER (two-stream allocator / event
+# overhead on the host outweighs the 0.5 ms of transposes it hides) - kept selectable
+pretranspose_filters = os.environ.get('DSRL_PRETRANSPOSE', '0') != '0'
 
 
 def side_stream(device):
@@ -130,9 +133,15 @@ def _sink(param, like_shape=None):
     return param.grad
 
 
+def _is_krsc(w):
+    """Is the (K,C,R,S) filter physically [K][R][S][C]?  (torch does not call plain-strided 1x1 filters channels_last although the
+    two layouts coincide for them)"""
+    return w.is_contiguous(memory_format=CL) or (w.shape[2] == 1 and w.shape[3] == 1 and w.is_contiguous())
+
+
 def w_cl(w):
     _need_gpu(w); _f32(w)
-    return w.contiguous(memory_format=CL)
+    return w if _is_krsc(w) else w.contiguous(memory_format=CL)
 
 
 def _out_size(n, k, stride, pad, dil):
@@ -190,6 +199,18 @@ class _Conv2d(torch.autograd.Function):
         ctx.shp = shp
         ctx.has_bias = bias is not None
         ctx.wparam = w_param if isinstance(w_param, torch.nn.Parameter) else None
+        ctx.wt = None
+        if pretranspose_filters and ctx.needs_input_grad[0]:
+            # the data-gradient kernel reads the filter transposed: build that copy now, on the side stream, off the critical path
+            cur, side = torch.cuda.current_stream(), side_stream(x.device)
+            side.wait_stream(cur)                                   # the weights (last SGD update) are ready on the compute stream
+            with torch.cuda.stream(side):
+                wt = torch.empty(query('dsrl_conv2d_transposed_filter_floats', Cc, K, R, S), device=x.device, dtype=torch.float32)
+                call('dsrl_conv2d_transpose_filter', w.data_ptr(), wt.data_ptr(), Cc, K, R, S, side.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            w.record_stream(side)
+            ctx.wt = (wt, ev)
         return y
 
     @staticmethod
@@ -202,7 +223,7 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = db = None
         st = _stream()
         if ctx.needs_input_grad[1]:
-            sink = _sink(ctx.wparam) if ctx.wparam is not None and ctx.wparam.is_contiguous(memory_format=CL) else None
+            sink = _sink(ctx.wparam) if ctx.wparam is not None and _is_krsc(ctx.wparam) else None
             if sink is not None and overlap_wgrad and ctx.needs_input_grad[0]:
                 cur, side = torch.cuda.current_stream(), side_stream(x.device)
                 side.wait_stream(cur)                                   # dy (and x) are ready on the compute stream
@@ -221,7 +242,13 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = new_cl((N, Cc, H, W), x)
             ws = _ws(query('dsrl_conv2d_dgrad_workspace_bytes', *shp), x)
-            call('dsrl_conv2d_dgrad', dy.data_ptr(), lddy, w.data_ptr(), dx.data_ptr(), Cc, *shp, ws.data_ptr(), ws.numel(), st)
+            wt_ptr = None
+            if ctx.wt is not None:
+                wt, ev = ctx.wt
+                torch.cuda.current_stream().wait_event(ev)
+                wt.record_stream(torch.cuda.current_stream())
+                wt_ptr = wt.data_ptr()
+            call('dsrl_conv2d_dgrad', dy.data_ptr(), lddy, w.data_ptr(), wt_ptr, dx.data_ptr(), Cc, *shp, ws.data_ptr(), ws.numel(), st)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             P = dy.shape[0] * dy.shape[2] * dy.shape[3]
             db = torch.empty(K, device=x.device, dtype=torch.float32)
@@ -436,17 +463,19 @@ class _MaxPool3x3s2(torch.autograd.Function):
         x = pm_dense(x)
         N, Cc, H, W = x.shape
         y = new_cl((N, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1), x)
-        call('dsrl_maxpool3x3s2_fwd', x.data_ptr(), y.data_ptr(), N, H, W, Cc, _stream())
-        ctx.save_for_backward(x)
+        idx = torch.empty(y.numel(), device=x.device, dtype=torch.uint8)
+        call('dsrl_maxpool3x3s2_fwd', x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, Cc, _stream())
+        ctx.save_for_backward(idx)
+        ctx.shp = (N, Cc, H, W)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, = ctx.saved_tensors
-        N, Cc, H, W = x.shape
+        idx, = ctx.saved_tensors
+        N, Cc, H, W = ctx.shp
         dy = pm_dense(dy)
-        dx = new_cl((N, Cc, H, W), x)
-        call('dsrl_maxpool3x3s2_bwd', x.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, H, W, Cc, _stream())
+        dx = new_cl((N, Cc, H, W), dy)
+        call('dsrl_maxpool3x3s2_bwd', idx.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, H, W, Cc, _stream())
         return dx
 
 

@@ -51,9 +51,12 @@ size_t dsrl_conv2d_fwd_workspace_bytes(int N, int H, int W, int C, int K, int R,
 int dsrl_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias /*nullable*/, float* y, int ldy,
                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                     void* ws, size_t ws_bytes, dsrl_stream_t stream);
-/* dx (N,H,W,C) from dy (N,Ho,Wo,K) */
+/* dx (N,H,W,C) from dy (N,Ho,Wo,K). The kernel reads the filter as wt[c][tap][k] (k padded to a multiple of 4): pass `wt` from
+ * dsrl_conv2d_transpose_filter (e.g. built during the forward pass on another stream) or NULL to have it built here in `ws`. */
+size_t dsrl_conv2d_transposed_filter_floats(int C, int K, int R, int S);
+int dsrl_conv2d_transpose_filter(const float* w, float* wt, int C, int K, int R, int S, dsrl_stream_t stream);
 size_t dsrl_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
-int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx,
+int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, const float* wt /*nullable*/, float* dx, int lddx,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                       void* ws, size_t ws_bytes, dsrl_stream_t stream);
 /* dw [K][R][S][C] from x and dy */
@@ -124,8 +127,9 @@ int dsrl_bilinear_ac_bwd(const float* dy, int lddy, float* dx, int lddx, int N, 
 int dsrl_global_avgpool_fwd(const float* x, int ldx, float* y, int N, int HW, int C, dsrl_stream_t stream);
 int dsrl_global_avgpool_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, dsrl_stream_t stream);
 /* nn.MaxPool2d(3, stride 2, pad 1) (ResNet101.py:32) */
-int dsrl_maxpool3x3s2_fwd(const float* x, float* y, int N, int H, int W, int C, dsrl_stream_t stream);
-int dsrl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, dsrl_stream_t stream);
+/* argmax (nullable in fwd): per output element the winning tap r*3+s (first maximum in scan order), consumed by the backward */
+int dsrl_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, dsrl_stream_t stream);
+int dsrl_maxpool3x3s2_bwd(const uint8_t* argmax, const float* dy, float* dx, int N, int H, int W, int C, dsrl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ConvTranspose2d(kernel 2, stride 2, pad 0) (DSRL.py:55-60, 64-69); w is (Cin,Cout,2,2) contiguous

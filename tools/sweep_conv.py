@@ -33,7 +33,7 @@ def run(N, C, H, W, K, R, stride, pad, dil, what):
     if what == 'fwd':
         f = lambda: _lib.check(lib.dsrl_conv2d_fwd(x.data_ptr(), C, w.data_ptr(), None, y.data_ptr(), K, *shp, ws.data_ptr(), ws.numel(), st), 'fwd')
     elif what == 'dgrad':
-        f = lambda: _lib.check(lib.dsrl_conv2d_dgrad(y.data_ptr(), K, w.data_ptr(), dx.data_ptr(), C, *shp, ws.data_ptr(), ws.numel(), st), 'dgrad')
+        f = lambda: _lib.check(lib.dsrl_conv2d_dgrad(y.data_ptr(), K, w.data_ptr(), None, dx.data_ptr(), C, *shp, ws.data_ptr(), ws.numel(), st), 'dgrad')
     else:
         f = lambda: _lib.check(lib.dsrl_conv2d_wgrad(x.data_ptr(), C, y.data_ptr(), K, dw.data_ptr(), *shp, ws.data_ptr(), ws.numel(), st), 'wgrad')
     ms = t_ms(f)
