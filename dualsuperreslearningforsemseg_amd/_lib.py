@@ -50,7 +50,8 @@ PROTOTYPES = {
     'dsrl_dropout_fwd': (i32, [fp, i32, fp, i32, i64, i32, f32, u64, u32, stream_t]),
     'dsrl_dropout_bwd': (i32, [fp, i32, fp, i32, i64, i32, f32, u64, u32, stream_t]),
     'dsrl_bilinear_ac_fwd': (i32, [fp, i32, fp, i32, i32, i32, i32, i32, i32, i32, stream_t]),
-    'dsrl_bilinear_ac_bwd': (i32, [fp, i32, fp, i32, i32, i32, i32, i32, i32, i32, stream_t]),
+    'dsrl_bilinear_ac_bwd_workspace_bytes': (sz, [i32] * 6),
+    'dsrl_bilinear_ac_bwd': (i32, [fp, i32, fp, i32, i32, i32, i32, i32, i32, i32, fp, sz, stream_t]),
     'dsrl_global_avgpool_fwd': (i32, [fp, i32, fp, i32, i32, i32, stream_t]),
     'dsrl_global_avgpool_bwd': (i32, [fp, fp, i32, i32, i32, i32, stream_t]),
     'dsrl_maxpool3x3s2_fwd': (i32, [fp, fp, fp, i32, i32, i32, i32, stream_t]),

@@ -50,28 +50,39 @@ __device__ inline void ac_range(int src, float scale, int n_out, int& lo, int& h
     hi = min(n_out - 1, (int)ceilf((float)(src + 1) / scale) + 1);
 }
 
-// gather form of the backward: deterministic, no atomics
-__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
-                                                            int N, int H, int W, int C, int Ho, int Wo, float sh, float sw) {
+// gather form of the backward (deterministic, no atomics), separable: first along W into tmp (N,Ho,W,C), then along H
+__global__ __launch_bounds__(256) void bilinear_bwd_w_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ tmp,
+                                                              int N, int W, int C, int Ho, int Wo, float sw) {
+    const long long total = (long long)N * Ho * W * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long long pix = e / C;
+        const int w = (int)(pix % W); const long long row = pix / W;      // row = n*Ho + ho
+        int wlo, whi;
+        ac_range(w, sw, Wo, wlo, whi);
+        const float* r = dy + row * Wo * lddy + c;
+        float acc = 0.f;
+        for (int wo = wlo; wo <= whi; ++wo) {
+            const float ww = ac_weight(wo, sw, W, w);
+            if (ww != 0.f) acc += ww * r[(long long)wo * lddy];
+        }
+        tmp[e] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void bilinear_bwd_h_kernel(const float* __restrict__ tmp, float* __restrict__ dx, int lddx,
+                                                              int N, int H, int W, int C, int Ho, float sh) {
     const long long total = (long long)N * H * W * C;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
         long long pix = e / C;
         const int w = (int)(pix % W); pix /= W;
         const int h = (int)(pix % H); const int n = (int)(pix / H);
-        int hlo, hhi, wlo, whi;
-        ac_range(h, sh, Ho, hlo, hhi); ac_range(w, sw, Wo, wlo, whi);
+        int hlo, hhi;
+        ac_range(h, sh, Ho, hlo, hhi);
         float acc = 0.f;
         for (int ho = hlo; ho <= hhi; ++ho) {
             const float wh = ac_weight(ho, sh, H, h);
-            if (wh == 0.f) continue;
-            float row = 0.f;
-            const float* r = dy + ((long long)(n * Ho + ho) * Wo) * lddy + c;
-            for (int wo = wlo; wo <= whi; ++wo) {
-                const float ww = ac_weight(wo, sw, W, w);
-                if (ww != 0.f) row += ww * r[(long long)wo * lddy];
-            }
-            acc += wh * row;
+            if (wh != 0.f) acc += wh * tmp[(((long long)n * Ho + ho) * W + w) * C + c];
         }
         dx[((long long)(n * H + h) * W + w) * lddx + c] = acc;
     }
@@ -410,10 +421,15 @@ extern "C" int dsrl_bilinear_ac_fwd(const float* x, int ldx, float* y, int ldy, 
     hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(flat_grid((long long)N * Ho * Wo * C)), dim3(256), 0, st, x, ldx, y, ldy, N, H, W, C, Ho, Wo, ac_scale(H, Ho), ac_scale(W, Wo));
     return launch_status("bilinear_fwd_kernel");
 }
-extern "C" int dsrl_bilinear_ac_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int Ho, int Wo, dsrl_stream_t stream) {
-    DSRL_PROLOGUE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && lddy >= C && lddx >= C, "bilinear_ac_bwd")
-    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(flat_grid((long long)N * H * W * C)), dim3(256), 0, st, dy, lddy, dx, lddx, N, H, W, C, Ho, Wo, ac_scale(H, Ho), ac_scale(W, Wo));
-    return launch_status("bilinear_bwd_kernel");
+extern "C" size_t dsrl_bilinear_ac_bwd_workspace_bytes(int N, int H, int W, int C, int Ho, int Wo) { (void)H; (void)Wo; return (size_t)N * Ho * W * C * sizeof(float); }
+extern "C" int dsrl_bilinear_ac_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int Ho, int Wo,
+                                    void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(dy && dx && ws && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && lddy >= C && lddx >= C, "bilinear_ac_bwd")
+    DSRL_REQUIRE(ws_bytes >= dsrl_bilinear_ac_bwd_workspace_bytes(N, H, W, C, Ho, Wo), DSRL_E_WORKSPACE, "bilinear_ac_bwd: workspace too small");
+    hipLaunchKernelGGL(bilinear_bwd_w_kernel, dim3(flat_grid((long long)N * Ho * W * C)), dim3(256), 0, st, dy, lddy, (float*)ws, N, W, C, Ho, Wo, ac_scale(W, Wo));
+    if (int e = launch_status("bilinear_bwd_w_kernel")) return e;
+    hipLaunchKernelGGL(bilinear_bwd_h_kernel, dim3(flat_grid((long long)N * H * W * C)), dim3(256), 0, st, (const float*)ws, dx, lddx, N, H, W, C, Ho, ac_scale(H, Ho));
+    return launch_status("bilinear_bwd_h_kernel");
 }
 extern "C" int dsrl_global_avgpool_fwd(const float* x, int ldx, float* y, int N, int HW, int C, dsrl_stream_t stream) {
     DSRL_PROLOGUE(x && y && N > 0 && HW > 0 && C > 0 && ldx >= C, "global_avgpool_fwd")

@@ -60,8 +60,35 @@ def new_cl(shape, like):
     return torch.empty(shape, device=like.device, dtype=torch.float32, memory_format=CL)
 
 
+# Workspaces: kernels of one stream run one after the other and each is done with its scratch when the next starts, so ONE
+# growing buffer per (device, stream) serves every call on that stream (saves ~700 allocator round trips per step).
+_ws_pool = {}
+
+
+_use_ws_pool = os.environ.get('DSRL_WS_POOL', '0') != '0'       # measured: no difference; the caching allocator is already cheap
+
+
 def _ws(nbytes, like):
-    return torch.empty(max(int(nbytes), 256), device=like.device, dtype=torch.uint8)
+    nbytes = max(int(nbytes), 256)
+    if not _use_ws_pool:
+        return torch.empty(nbytes, device=like.device, dtype=torch.uint8)
+    key = (like.device, torch.cuda.current_stream(like.device).cuda_stream)
+    buf = _ws_pool.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _ws_pool[key] = torch.empty(max(nbytes, 64 << 20) * (2 if buf is not None else 1), device=like.device, dtype=torch.uint8)
+    return buf
+
+
+_query_cache = {}
+
+
+def cquery(name, *args):
+    """workspace-size style queries are pure functions of the shape: memoise them"""
+    key = (name, args)
+    v = _query_cache.get(key)
+    if v is None:
+        v = _query_cache[key] = query(name, *args)
+    return v
 
 
 def _ld_of(t):
@@ -190,7 +217,7 @@ class _Conv2d(torch.autograd.Function):
         Ho, Wo = _out_size(H, R, stride, pad, dil), _out_size(W, S, stride, pad, dil)
         y = new_cl((N, K, Ho, Wo), x)
         shp = (N, H, W, Cc, K, R, S, stride, pad, dil)
-        ws = _ws(query('dsrl_conv2d_fwd_workspace_bytes', *shp), x)
+        ws = _ws(cquery('dsrl_conv2d_fwd_workspace_bytes', *shp), x)
         if bias is not None:
             _need_gpu(bias)
         call('dsrl_conv2d_fwd', x.data_ptr(), ldx, w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), K,
@@ -205,7 +232,7 @@ class _Conv2d(torch.autograd.Function):
             cur, side = torch.cuda.current_stream(), side_stream(x.device)
             side.wait_stream(cur)                                   # the weights (last SGD update) are ready on the compute stream
             with torch.cuda.stream(side):
-                wt = torch.empty(query('dsrl_conv2d_transposed_filter_floats', Cc, K, R, S), device=x.device, dtype=torch.float32)
+                wt = torch.empty(cquery('dsrl_conv2d_transposed_filter_floats', Cc, K, R, S), device=x.device, dtype=torch.float32)
                 call('dsrl_conv2d_transpose_filter', w.data_ptr(), wt.data_ptr(), Cc, K, R, S, side.cuda_stream)
                 ev = torch.cuda.Event()
                 ev.record(side)
@@ -228,20 +255,20 @@ class _Conv2d(torch.autograd.Function):
                 cur, side = torch.cuda.current_stream(), side_stream(x.device)
                 side.wait_stream(cur)                                   # dy (and x) are ready on the compute stream
                 with torch.cuda.stream(side):
-                    ws = _ws(query('dsrl_conv2d_wgrad_workspace_bytes', *shp), x)
+                    ws = _ws(cquery('dsrl_conv2d_wgrad_workspace_bytes', *shp), x)
                     call('dsrl_conv2d_wgrad', x.data_ptr(), ldx, dy.data_ptr(), lddy, sink.data_ptr(), *shp, ws.data_ptr(), ws.numel(), side.cuda_stream)
                 x.record_stream(side); dy.record_stream(side)
                 ctx.wparam._dsrl_arena.written(ctx.wparam, side)
             else:
                 dw = sink if sink is not None else torch.empty((K, Cc, R, S), device=x.device, dtype=torch.float32, memory_format=CL)
-                ws = _ws(query('dsrl_conv2d_wgrad_workspace_bytes', *shp), x)
+                ws = _ws(cquery('dsrl_conv2d_wgrad_workspace_bytes', *shp), x)
                 call('dsrl_conv2d_wgrad', x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(), *shp, ws.data_ptr(), ws.numel(), st)
                 if sink is not None:
                     ctx.wparam._dsrl_arena.written(ctx.wparam)
                     dw = None
         if ctx.needs_input_grad[0]:
             dx = new_cl((N, Cc, H, W), x)
-            ws = _ws(query('dsrl_conv2d_dgrad_workspace_bytes', *shp), x)
+            ws = _ws(cquery('dsrl_conv2d_dgrad_workspace_bytes', *shp), x)
             wt_ptr = None
             if ctx.wt is not None:
                 wt, ev = ctx.wt
@@ -252,7 +279,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             P = dy.shape[0] * dy.shape[2] * dy.shape[3]
             db = torch.empty(K, device=x.device, dtype=torch.float32)
-            ws = _ws(query('dsrl_colsum_workspace_bytes', P, K), x)
+            ws = _ws(cquery('dsrl_colsum_workspace_bytes', P, K), x)
             call('dsrl_colsum', dy.data_ptr(), lddy, P, K, db.data_ptr(), ws.data_ptr(), ws.numel(), st)
         return dx, dw, db, None, None, None
 
@@ -279,9 +306,9 @@ class _StemConv(torch.autograd.Function):
         w2 = torch.zeros((K, R, Sp, 4), device=x.device, dtype=torch.float32)
         w2[:, :, :S, :Cc] = w.detach().permute(0, 2, 3, 1)
         y = new_cl((N, K, Ho, Wo), x)
-        macs = query('dsrl_conv2d_inbounds_macs', N, H, W, Cc, K, R, S, stride, pad, 1)
+        macs = cquery('dsrl_conv2d_inbounds_macs', N, H, W, Cc, K, R, S, stride, pad, 1)
         shp = (N, Hp, Wp, Cf, K, R, stride, Ho, Wo)
-        ws = _ws(query('dsrl_conv2d_rowfold_fwd_workspace_bytes', *shp), x)
+        ws = _ws(cquery('dsrl_conv2d_rowfold_fwd_workspace_bytes', *shp), x)
         call('dsrl_conv2d_rowfold_fwd', xp.data_ptr(), 4, w2.data_ptr(), None, y.data_ptr(), K, *shp, macs, ws.data_ptr(), ws.numel(), st)
         ctx.save_for_backward(xp)
         ctx.cfg = (shp, macs, tuple(w.shape), Sp)
@@ -296,7 +323,7 @@ class _StemConv(torch.autograd.Function):
             raise DsrlHipError('the image stem has no input-gradient kernel (the reference never differentiates w.r.t. the image)')
         dy, lddy = pm_vec4(dy)
         dw2 = torch.empty((K, R, Sp, 4), device=dy.device, dtype=torch.float32)
-        ws = _ws(query('dsrl_conv2d_rowfold_wgrad_workspace_bytes', *shp), dy)
+        ws = _ws(cquery('dsrl_conv2d_rowfold_wgrad_workspace_bytes', *shp), dy)
         call('dsrl_conv2d_rowfold_wgrad', xp.data_ptr(), 4, dy.data_ptr(), lddy, dw2.data_ptr(), *shp, macs, ws.data_ptr(), ws.numel(), _stream())
         dw = dw2[:, :, :S, :Cc].permute(0, 3, 1, 2)
         return None, dw, None, None
@@ -322,7 +349,7 @@ class _BNAct(torch.autograd.Function):
         N, Cc, H, W = x.shape
         P = N * H * W
         st = _stream()
-        ws = _ws(query('dsrl_bn_workspace_bytes', P, Cc), x)
+        ws = _ws(cquery('dsrl_bn_workspace_bytes', P, Cc), x)
         if training:
             if P <= 1:
                 raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
@@ -363,7 +390,7 @@ class _BNAct(torch.autograd.Function):
             sb = _sink(ctx.gb[1]) if sg is not None else None
         dgamma = sg if sg is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
         dbeta = sb if sb is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
-        ws = _ws(query('dsrl_bn_workspace_bytes', P, Cc), x)
+        ws = _ws(cquery('dsrl_bn_workspace_bytes', P, Cc), x)
         call('dsrl_bn_bwd', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,
              None if dres is None else dres.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
              dgamma.data_ptr(), dbeta.data_ptr(), int(relu), drop_p, int(training), ws.data_ptr(), ws.numel(), _stream())
@@ -426,7 +453,8 @@ class _UpsampleAC(torch.autograd.Function):
         N, Cc, H, W, Ho, Wo = ctx.shp
         dy, ld = pm(dy)
         dx = new_cl((N, Cc, H, W), dy)
-        call('dsrl_bilinear_ac_bwd', dy.data_ptr(), ld, dx.data_ptr(), Cc, N, H, W, Cc, Ho, Wo, _stream())
+        ws = _ws(cquery('dsrl_bilinear_ac_bwd_workspace_bytes', N, H, W, Cc, Ho, Wo), dy)
+        call('dsrl_bilinear_ac_bwd', dy.data_ptr(), ld, dx.data_ptr(), Cc, N, H, W, Cc, Ho, Wo, ws.data_ptr(), ws.numel(), _stream())
         return dx, None, None
 
 
@@ -537,7 +565,7 @@ class _ConvT2x2(torch.autograd.Function):
         dx = new_cl((N, Ci, H, W), x)
         dw = torch.empty_like(w)
         db = torch.empty(Co, device=x.device, dtype=torch.float32) if ctx.has_bias else None
-        ws = _ws(query('dsrl_convt2x2_bwd_workspace_bytes', N, H, W, Ci, Co), x)
+        ws = _ws(cquery('dsrl_convt2x2_bwd_workspace_bytes', N, H, W, Ci, Co), x)
         call('dsrl_convt2x2_bwd', x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(),
              N, H, W, Ci, Co, ws.data_ptr(), ws.numel(), _stream())
         return dx, dw, db
@@ -597,7 +625,7 @@ class _PointwiseStrided(torch.autograd.Function):
         dy = dy.contiguous()
         dx = new_cl((N, Cc, H, W), x)
         dw = torch.empty(Cc, device=x.device, dtype=torch.float32)
-        ws = _ws(query('dsrl_pointwise_strided_bwd_workspace_bytes', N, H, W, Cc, ctx.stride), x)
+        ws = _ws(cquery('dsrl_pointwise_strided_bwd_workspace_bytes', N, H, W, Cc, ctx.stride), x)
         call('dsrl_pointwise_strided_bwd', x.data_ptr(), wf.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), 0,
              N, H, W, Cc, ctx.stride, ws.data_ptr(), ws.numel(), _stream())
         return dx, dw.view(ctx.wshape), None
@@ -621,7 +649,7 @@ class _CrossEntropy(torch.autograd.Function):
         if target.numel() != P:
             raise DsrlHipError(f'cross_entropy: target has {target.numel()} pixels, logits {P}')
         out = torch.empty(2, device=logits.device, dtype=torch.float32)
-        ws = _ws(query('dsrl_ce_workspace_bytes', P), logits)
+        ws = _ws(cquery('dsrl_ce_workspace_bytes', P), logits)
         call('dsrl_ce_fwd', logits.data_ptr(), ld, target.data_ptr(), P, Cc, int(ignore_index), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
         ctx.save_for_backward(logits, target, out)
         ctx.ignore_index = int(ignore_index)
@@ -653,7 +681,7 @@ class _MSE(torch.autograd.Function):
             raise DsrlHipError(f'mse: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}')
         n = a.numel()
         out = torch.empty(1, device=a.device, dtype=torch.float32)
-        ws = _ws(query('dsrl_mse_workspace_bytes', n), a)
+        ws = _ws(cquery('dsrl_mse_workspace_bytes', n), a)
         call('dsrl_mse_fwd', a.data_ptr(), b.data_ptr(), n, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
         ctx.save_for_backward(a, b)
         return out[0].clone()
@@ -684,8 +712,8 @@ class _FALoss(torch.autograd.Function):
         red = _RED[reduction]
         n = (W // k) ** 2
         out = torch.empty((B, Cc, n * n) if red == 2 else (1,), device=fm1.device, dtype=torch.float32)
-        saved = torch.empty(query('dsrl_fa_saved_floats', B, Cc, H, W, k), device=fm1.device, dtype=torch.float32)
-        ws = _ws(query('dsrl_fa_workspace_bytes', B, Cc, H, W, k), fm1)
+        saved = torch.empty(cquery('dsrl_fa_saved_floats', B, Cc, H, W, k), device=fm1.device, dtype=torch.float32)
+        ws = _ws(cquery('dsrl_fa_workspace_bytes', B, Cc, H, W, k), fm1)
         sb, sc, sh, sw = fm1.stride()
         call('dsrl_fa_fwd', fm1.data_ptr(), fm2.data_ptr(), B, Cc, H, W, sb, sc, sh, sw, k, red, out.data_ptr(), saved.data_ptr(),
              ws.data_ptr(), ws.numel(), _stream())
@@ -732,4 +760,4 @@ def nan_check_(flag, *tensors):
 
 
 def conv2d_inbounds_macs(N, H, W, Cc, K, R, S, stride, pad, dil):
-    return query('dsrl_conv2d_inbounds_macs', N, H, W, Cc, K, R, S, stride, pad, dil)
+    return cquery('dsrl_conv2d_inbounds_macs', N, H, W, Cc, K, R, S, stride, pad, dil)

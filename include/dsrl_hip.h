@@ -122,7 +122,9 @@ int dsrl_dropout_bwd(const float* dy, int lddy, float* dx, int lddx, int64_t P, 
  * bilinear resize, align_corners=True (ASPP.py:41, DSRL.py:53, DSRL.py:163) and pools
  * ---------------------------------------------------------------------------------------------- */
 int dsrl_bilinear_ac_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int Ho, int Wo, dsrl_stream_t stream);
-int dsrl_bilinear_ac_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int Ho, int Wo, dsrl_stream_t stream);
+size_t dsrl_bilinear_ac_bwd_workspace_bytes(int N, int H, int W, int C, int Ho, int Wo);
+int dsrl_bilinear_ac_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int Ho, int Wo,
+                         void* ws, size_t ws_bytes, dsrl_stream_t stream);
 /* nn.AdaptiveAvgPool2d((1,1)) (ASPP.py:22,38) */
 int dsrl_global_avgpool_fwd(const float* x, int ldx, float* y, int N, int HW, int C, dsrl_stream_t stream);
 int dsrl_global_avgpool_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, dsrl_stream_t stream);
