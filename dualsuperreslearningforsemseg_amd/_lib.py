@@ -76,6 +76,8 @@ PROTOTYPES = {
     'dsrl_fa_workspace_bytes': (sz, [i32] * 5),
     'dsrl_fa_fwd': (i32, [fp, fp, i32, i32, i32, i32, i64, i64, i64, i64, i32, i32, fp, fp, fp, sz, stream_t]),
     'dsrl_fa_bwd': (i32, [fp, fp, i32, i32, i32, i32, i64, i64, i64, i64, i32, i32, fp, fp, fp, fp, fp, sz, stream_t]),
+    'dsrl_seg_metrics': (i32, [fp, i32, fp, i64, i32, i32, fp, stream_t]),
+    'dsrl_prepare_batch': (i32, [fp, fp, fp, C.POINTER(f32), C.POINTER(f32), fp, fp, fp, i32, i32, i32, i32, i32, stream_t]),
     'dsrl_sgd_step': (i32, [fp, fp, fp, i64, f32, f32, f32, f32, stream_t]),
     'dsrl_nan_check': (i32, [fp, i64, fp, stream_t]),
     'dsrl_prof_enable': (i32, [i32]),

@@ -198,24 +198,16 @@ def _do_train_val(do_train, epoch, model, step, data_loader, lr, momentum, weigh
         for m in model.modules():
             if isinstance(m, t.nn.modules.batchnorm._BatchNorm):
                 m.eval()                                                                   # :379-382
-    sums, n = [0., 0., 0., 0.], 0
+    from ..metrices import Accuracy, AverageMeter, mIoU
+    meters = [AverageMeter() for _ in range(4)]                                            # CE, MSE, FA, Total (:385-388)
     nc = model.SSSR_decoder['cls_conv'].out_channels
-    inter = t.zeros(nc, dtype=t.float64); union = t.zeros(nc, dtype=t.float64); correct = total = 0
+    miou, mean_accuracy = mIoU(num_classes=nc, ignore_index=step.ignore), Accuracy(num_classes=nc, ignore_index=step.ignore)
     for (input_image, input_org), (target, _) in data_loader:
         vals, outs = step(input_image, input_org, target, lr, momentum, weights_decay, do_train)
-        b = input_image.shape[0]
-        for i in range(4):
-            sums[i] += vals[i] * b                                                         # AverageMeter.update(value, batch), :457-460
-        n += b
+        for mtr, v in zip(meters, vals):
+            mtr.update(v, input_image.shape[0])                                            # AverageMeter.update(value, batch), :457-460
         if not do_train and is_master_rank:
-            pred = t.argmax(outs[0], dim=1)                                                # :476
-            valid = target != step.ignore
-            tg = target.long()
-            for c in range(nc):                                                            # metrices/mIoU.py:15-41 (sum-intersection / sum-union)
-                p_, t_ = (pred == c) & valid, (tg == c) & valid
-                inter[c] += float((p_ & t_).sum()); union[c] += float((p_ | t_).sum())
-            correct += float(((pred == tg) & valid).sum()); total += float(valid.sum())
-    means = [s / max(n, 1) for s in sums]
-    miou = float(100.0 * inter.sum() / max(float(union.sum()), 1.0)) if not do_train else 0.0
-    acc = 100.0 * correct / max(total, 1.0) if not do_train else 0.0
-    return means + [miou, acc]
+            miou.update_from_logits(outs[0], target)                                       # argmax + histograms on the device (:476-480)
+            mean_accuracy.update_from_logits(outs[0], target)
+    return [m() for m in meters] + [miou() if not do_train else 0.0, mean_accuracy() if not do_train else 0.0]
+

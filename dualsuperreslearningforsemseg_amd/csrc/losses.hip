@@ -305,6 +305,70 @@ __global__ __launch_bounds__(256) void nan_check_kernel(const float* __restrict_
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// ---------------------------------------------------------------------------------------------- validation metrics
+__global__ __launch_bounds__(256) void seg_metrics_kernel(const float* __restrict__ logits, int ld, const unsigned char* __restrict__ target, long long P, int C,
+                                                           int ignore_index, unsigned long long* __restrict__ counts) {
+    extern __shared__ float tile[];                     // [256][C] logits, then 3*C+2 unsigned counters
+    __shared__ unsigned hist[3 * 64 + 2];
+    for (int t = threadIdx.x; t < 3 * C + 2; t += 256) hist[t] = 0u;
+    for (long long p0 = (long long)blockIdx.x * 256; p0 < P; p0 += (long long)gridDim.x * 256) {
+        const int np = (int)min(256ll, P - p0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < np * C; t += 256) { const int r = t / C, c = t - r * C; tile[t] = logits[(p0 + r) * ld + c]; }
+        __syncthreads();
+        if ((int)threadIdx.x < np) {
+            const int tg = target[p0 + threadIdx.x];
+            if (tg != ignore_index && tg < C) {
+                const float* v = tile + threadIdx.x * C;
+                int best = 0; float bv = v[0];
+                for (int c = 1; c < C; ++c) if (v[c] > bv) { bv = v[c]; best = c; }     // first maximum, as torch.argmax
+                atomicAdd(&hist[best], 1u);
+                atomicAdd(&hist[2 * C + tg], 1u);
+                atomicAdd(&hist[3 * C + 1], 1u);
+                if (best == tg) { atomicAdd(&hist[C + tg], 1u); atomicAdd(&hist[3 * C], 1u); }
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 3 * C + 2; t += 256) if (hist[t]) atomicAdd(&counts[t], (unsigned long long)hist[t]);
+}
+
+// ---------------------------------------------------------------------------------------------- batch preparation
+__device__ inline void ac_src_f(int dst, float scale, int n_in, int& i0, int& ip, float& l1) {
+    const float r = scale * (float)dst;
+    i0 = min((int)r, n_in - 1); ip = (i0 < n_in - 1) ? 1 : 0; l1 = r - (float)i0;
+}
+__global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char* __restrict__ rgb, float* __restrict__ out, int N, int Hs, int Ws, int Ho, int Wo, int Cout,
+                                                             float sh, float sw, float m0, float m1, float m2, float i0s, float i1s, float i2s) {
+    const long long total = (long long)N * Ho * Wo;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int wo = (int)(e % Wo); const long long t = e / Wo; const int ho = (int)(t % Ho); const long long n = t / Ho;
+        int h0, hp, w0, wp; float lh, lw;
+        ac_src_f(ho, sh, Hs, h0, hp, lh); ac_src_f(wo, sw, Ws, w0, wp, lw);
+        const unsigned char* b = rgb + ((n * Hs + h0) * Ws + w0) * 3;
+        const long long dw_ = (long long)wp * 3, dh_ = (long long)hp * Ws * 3;
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x00 = b[c], x01 = b[dw_ + c], x10 = b[dh_ + c], x11 = b[dh_ + dw_ + c];
+            v[c] = (1.f - lh) * ((1.f - lw) * x00 + lw * x01) + lh * ((1.f - lw) * x10 + lw * x11);
+        }
+        float* o = out + e * Cout;
+        o[0] = (v[0] * (1.f / 255.f) - m0) * i0s; o[1] = (v[1] * (1.f / 255.f) - m1) * i1s; o[2] = (v[2] * (1.f / 255.f) - m2) * i2s;
+        if (Cout == 4) o[3] = 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void prepare_target_kernel(const unsigned char* __restrict__ labels, const unsigned char* __restrict__ lut, unsigned char* __restrict__ target,
+                                                              int N, int Hs, int Ws, int Ho, int Wo) {
+    const long long total = (long long)N * Ho * Wo;
+    const float sh = (float)Hs / (float)Ho, sw = (float)Ws / (float)Wo;             // torch 'nearest': src = floor(dst * in/out)
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int wo = (int)(e % Wo); const long long t = e / Wo; const int ho = (int)(t % Ho); const long long n = t / Ho;
+        const int hs = min((int)floorf((float)ho * sh), Hs - 1), ws = min((int)floorf((float)wo * sw), Ws - 1);
+        target[e] = lut[labels[(n * Hs + hs) * Ws + ws]];
+    }
+}
+
 static int loss_blocks(long long work) { return (int)std::max<long long>(1, std::min<long long>(1024, ceil_div(work, 256))); }
 
 }  // namespace dsrl
@@ -411,4 +475,39 @@ extern "C" int dsrl_nan_check(const float* x, int64_t n, int* flag, dsrl_stream_
     if (int e = bind_stream_device(st)) return e;
     hipLaunchKernelGGL(nan_check_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 2048), 4096)), dim3(256), 0, st, x, (long long)n, flag);
     return launch_status("nan_check_kernel");
+}
+
+extern "C" int dsrl_seg_metrics(const float* logits, int ld, const uint8_t* target, int64_t P, int C, int ignore_index,
+                                unsigned long long* counts, dsrl_stream_t stream) {
+    DSRL_REQUIRE(logits && target && counts && P > 0 && C > 0 && C <= 60 && ld >= C, DSRL_E_BADARG, "seg_metrics: bad arguments (C=%d)", C);
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(seg_metrics_kernel, dim3(loss_blocks(P)), dim3(256), (size_t)256 * C * sizeof(float), st, logits, ld, target, (long long)P, C, ignore_index, counts);
+    return launch_status("seg_metrics_kernel");
+}
+
+extern "C" int dsrl_prepare_batch(const uint8_t* rgb, const uint8_t* labels, const uint8_t* lut, const float* mean, const float* std_,
+                                  float* img_in, float* img_org, uint8_t* target, int N, int Hs, int Ws, int H, int W, dsrl_stream_t stream) {
+    DSRL_REQUIRE(rgb && mean && std_ && N > 0 && Hs > 0 && Ws > 0 && H > 0 && W > 0, DSRL_E_BADARG, "prepare_batch: bad arguments");
+    DSRL_REQUIRE((labels == nullptr) == (target == nullptr) && (labels == nullptr || lut != nullptr), DSRL_E_BADARG, "prepare_batch: labels, lut and target go together");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    auto sc = [](int n_in, int n_out) { return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f; };
+    const float m0 = mean[0], m1 = mean[1], m2 = mean[2], i0 = 1.f / std_[0], i1 = 1.f / std_[1], i2 = 1.f / std_[2];
+    if (img_in) {
+        hipLaunchKernelGGL(prepare_image_kernel, dim3((unsigned)std::min<long long>(ceil_div((long long)N * H * W, 256), 4096)), dim3(256), 0, st,
+                           rgb, img_in, N, Hs, Ws, H, W, 4, sc(Hs, H), sc(Ws, W), m0, m1, m2, i0, i1, i2);
+        if (int e = launch_status("prepare_image_kernel")) return e;
+    }
+    if (img_org) {
+        hipLaunchKernelGGL(prepare_image_kernel, dim3((unsigned)std::min<long long>(ceil_div((long long)N * 4 * H * W, 256), 4096)), dim3(256), 0, st,
+                           rgb, img_org, N, Hs, Ws, 2 * H, 2 * W, 3, sc(Hs, 2 * H), sc(Ws, 2 * W), m0, m1, m2, i0, i1, i2);
+        if (int e = launch_status("prepare_image_kernel")) return e;
+    }
+    if (target) {
+        hipLaunchKernelGGL(prepare_target_kernel, dim3((unsigned)std::min<long long>(ceil_div((long long)N * 4 * H * W, 256), 4096)), dim3(256), 0, st,
+                           labels, lut, target, N, Hs, Ws, 2 * H, 2 * W);
+        return launch_status("prepare_target_kernel");
+    }
+    return DSRL_OK;
 }

@@ -186,6 +186,22 @@ int dsrl_fa_bwd(const float* fm1, const float* fm2, int B, int C, int H, int W, 
                 void* ws, size_t ws_bytes, dsrl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * callers / data formats either side of the path
+ * ---------------------------------------------------------------------------------------------- */
+/* Validation metrics (metrices/mIoU.py:15-41, metrices/Accuracy.py:13-30) straight from the logits: pred = argmax_c logits,
+ * counts[0..C) += area_pred, [C..2C) += area_inter, [2C..3C) += area_target, counts[3C] += correct, counts[3C+1] += valid
+ * (pixels whose target is the ignore label are excluded everywhere). 64-bit integer atomics: exact and order independent. */
+int dsrl_seg_metrics(const float* logits, int ld, const uint8_t* target, int64_t P, int C, int ignore_index,
+                     unsigned long long* counts, dsrl_stream_t stream);
+/* Deterministic tail of the training input pipeline (JointImageAndLabelTensor.py:9-16 label remap, JointNormalize.py:11,
+ * JointScaledImage.py:27-32): from a decoded RGB uint8 crop (N,Hs,Ws,3) and its label-id map (N,Hs,Ws):
+ *   img_in  (N,H,W,4)   = align-corners bilinear resize of ((u8/255 - mean)/std) to the model input size, 4th channel 0
+ *                         (pixel-major, padded to the 4 channels the stem kernel wants), img_org (N,2H,2W,3) the same at the output size,
+ *   target  (N,2H,2W)   = nearest resize of lut[label]                                                                        */
+int dsrl_prepare_batch(const uint8_t* rgb, const uint8_t* labels, const uint8_t* lut /*256*/, const float* mean /*3*/, const float* std /*3*/,
+                       float* img_in, float* img_org, uint8_t* target, int N, int Hs, int Ws, int H, int W, dsrl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * optimiser + bookkeeping on the flat parameter arena (train_or_resume.py:63-66, 445, 426-433)
  * ---------------------------------------------------------------------------------------------- */
 /* torch.optim.SGD(momentum, weight_decay): d = g*grad_scale + wd*p; buf = mom*buf + d; p -= lr*buf */

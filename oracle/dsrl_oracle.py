@@ -20,7 +20,7 @@ __all__ = [
     'conv_transpose2d_k2s2_bwd', 'pixel_shuffle', 'pixel_shuffle_bwd', 'avg_pool2d', 'avg_pool2d_bwd',
     'global_avg_pool', 'global_avg_pool_bwd', 'max_pool3x3s2', 'max_pool3x3s2_bwd', 'fa_similarity', 'fa_loss', 'fa_loss_bwd',
     'cross_entropy', 'cross_entropy_bwd', 'mse', 'mse_bwd', 'sgd_step', 'dropout_mask',
-    'Tape', 'Var', 'head_forward', 'total_loss', 'HeadOutputs', 'miou_batch', 'backbone_forward', 'model_forward',
+    'Tape', 'Var', 'head_forward', 'total_loss', 'HeadOutputs', 'miou_batch', 'backbone_forward', 'model_forward', 'seg_metrics_batch', 'prepare_batch',
 ]
 
 
@@ -355,6 +355,36 @@ def miou_batch(pred, target, num_classes=19, ignore_index=255):
     with np.errstate(divide='ignore', invalid='ignore'):
         iou = inter / union
     return 100.0 * inter.sum() / max(union.sum(), 1), 100.0 * np.nanmean(iou)
+
+
+def seg_metrics_batch(pred, target, num_classes=19, ignore_index=255):
+    """One update() of metrices/mIoU.py:15-41 and metrices/Accuracy.py:13-30: (nan-mean IoU over classes, correct/valid)."""
+    valid = target != ignore_index
+    p1 = (pred.astype(np.int64) + 1) * valid                     # mIoU.py:22-25
+    t1 = np.where(valid, target.astype(np.int64) + 1, 0)          # uint8 255+1 wraps to 0 in the reference: outside the histogram range
+    inter = p1 * (p1 == t1)
+    bins = dict(bins=num_classes, range=(1, num_classes))
+    area_pred = np.histogram(p1, **bins)[0]; area_inter = np.histogram(inter, **bins)[0]; area_target = np.histogram(t1, **bins)[0]
+    union = area_pred + area_target - area_inter
+    with np.errstate(divide='ignore', invalid='ignore'):
+        miou = np.nanmean(area_inter / union)
+    return miou, ((pred == target) * valid).sum() / valid.sum()
+
+
+def prepare_batch(rgb_u8, labels_u8, label_mapping, mean, std, model_input_size, ignore_label=255, dtype=np.float64):
+    """ToTensor + Normalize (JointNormalize.py:11), label-id remap (JointImageAndLabelTensor.py:9-16) and the dual-scale resize of
+    JointScaledImage.py:27-32 on a decoded (N,Hs,Ws,3) uint8 crop. Returns img_in (N,3,H,W), img_org (N,3,2H,2W), target (N,2H,2W)."""
+    H, W = model_input_size
+    x = (np.transpose(rgb_u8, (0, 3, 1, 2)).astype(dtype) / 255.0 - np.asarray(mean, dtype).reshape(1, 3, 1, 1)) / np.asarray(std, dtype).reshape(1, 3, 1, 1)
+    lut = np.full(256, ignore_label, np.uint8)
+    for k, v in label_mapping.items():
+        if 0 <= k < 256:
+            lut[k] = v
+    seg = lut[labels_u8]
+    Hs, Ws = labels_u8.shape[1:]
+    hs = np.minimum(np.floor(np.arange(2 * H) * (Hs / (2 * H))).astype(np.int64), Hs - 1)      # torch 'nearest'
+    ws = np.minimum(np.floor(np.arange(2 * W) * (Ws / (2 * W))).astype(np.int64), Ws - 1)
+    return upsample_bilinear_ac(x, (H, W)), upsample_bilinear_ac(x, (2 * H, 2 * W)), seg[:, hs][:, :, ws]
 
 
 # --------------------------------------------------------------------------------------------------

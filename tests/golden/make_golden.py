@@ -337,7 +337,50 @@ def golden_train_steps():
     print('train_steps.npz', out['step0.losses'], out['step1.losses'])
 
 
+def golden_pipeline_and_metrics():
+    """metrices/mIoU.py + Accuracy.py on seeded class maps; JointScaledImage.py on a normalised float crop (the other two
+    transforms of the deterministic tail need torchvision/PIL and are restated formulas)."""
+    import importlib.util
+    out = {}
+    from metrices import mIoU, Accuracy                      # numpy only
+    rs = np.random.RandomState(31)
+    m, a = mIoU(num_classes=19), Accuracy()
+    for b in range(3):
+        nc = (19, 7, 12)[b]                                  # some batches miss classes -> nan handling
+        pred = rs.randint(0, nc, (2, 24, 40)); target = rs.randint(0, nc, (2, 24, 40)).astype(np.uint8)
+        agree = rs.uniform(size=pred.shape) < 0.6
+        pred = np.where(agree, target, pred)
+        target[rs.uniform(size=target.shape) < 0.1] = 255
+        valid = target != 255
+        m.update(pred, target, valid); a.update(pred, target, valid)
+        out[f'metrics.pred{b}'] = pred.astype(np.uint8); out[f'metrics.target{b}'] = target
+        out[f'metrics.batch_miou{b}'] = np.float64(m.ious[-1]); out[f'metrics.batch_acc{b}'] = np.float64(a.accuracies[-1])
+    out['metrics.miou'] = np.float64(m()); out['metrics.acc'] = np.float64(a())
+    spec = importlib.util.spec_from_file_location('JointScaledImage', os.path.join(REF, 'models', 'transforms', 'JointScaledImage.py'))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    rgb = rs.randint(0, 256, (2, 37, 53, 3)).astype(np.uint8); lab = rs.randint(0, 34, (2, 37, 53)).astype(np.uint8)
+    mean, std = (0.28690, 0.32513, 0.28389), (0.17614, 0.18099, 0.17772)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    lut = np.full(256, 255, np.uint8)
+    for k, v in cs.LABEL_MAPPING_DICT.items():
+        if 0 <= k < 256:
+            lut[k] = v
+    tr = mod.JointScaledImage(new_img_sizes=((16, 32), (32, 64)), new_seg_size=(32, 64))
+    imgs_in, imgs_org, segs = [], [], []
+    for n in range(2):
+        x = (t.from_numpy(rgb[n]).permute(2, 0, 1).float() / 255. - t.tensor(mean).view(3, 1, 1)) / t.tensor(std).view(3, 1, 1)    # ToTensor + Normalize
+        (i1, i2), (sg, _) = tr(x, t.from_numpy(lut[lab[n]]))
+        imgs_in.append(np_(i1)); imgs_org.append(np_(i2)); segs.append(np_(sg))
+    out.update({'prep.rgb': rgb, 'prep.labels': lab, 'prep.img_in': np.stack(imgs_in), 'prep.img_org': np.stack(imgs_org), 'prep.target': np.stack(segs)})
+    np.savez_compressed(os.path.join(HERE, 'pipeline_metrics.npz'), **out)
+    print('pipeline_metrics.npz', float(out['metrics.miou']), float(out['metrics.acc']))
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'pipeline':
+        golden_pipeline_and_metrics(); sys.exit(0)
+    golden_pipeline_and_metrics()
     golden_fa()
     golden_ops()
     golden_head_small()

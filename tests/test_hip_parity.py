@@ -510,3 +510,30 @@ def test_train_or_resume_end_to_end(tmp_path):
     hist2 = train_or_resume(is_resuming_training=True, model_state_dict=ck['model_state_dict'], optimizer_state_dict=ck['optimizer_state_dict'],
                             epoch=ck['epoch'], best_validation_dict=ck['best_validation_dict'], **kw)
     assert hist2[0]['epoch'] == 3
+
+
+def test_seg_metrics_golden(golden):
+    """On-device mIoU / accuracy (dsrl_seg_metrics, argmax fused) vs the reference's metrices classes."""
+    from dualsuperreslearningforsemseg_amd.metrices import Accuracy, mIoU
+    g = golden('pipeline_metrics')
+    m, a, m2 = mIoU(19), Accuracy(19), mIoU(19)
+    rs = np.random.RandomState(1)
+    for b in range(3):
+        pred, target = g[f'metrics.pred{b}'], g[f'metrics.target{b}']
+        logits = rs.uniform(0, 1, (2, 19, 24, 40)).astype(np.float32)
+        np.put_along_axis(logits, pred[:, None].astype(np.int64), 2.0, axis=1)            # argmax(logits) == pred
+        m.update_from_logits(dev(logits), dev(target)); a.update_from_logits(dev(logits), dev(target))
+        m2.update(dev(pred.astype(np.int64)), dev(target), dev(target != 255))             # the reference's (pred, target, mask) call shape
+    assert abs(m() - float(g['metrics.miou'])) < 1e-9 and abs(a() - float(g['metrics.acc'])) < 1e-9 and abs(m2() - float(g['metrics.miou'])) < 1e-9
+
+
+def test_prepare_batch_golden(golden):
+    """Device-side ToTensor+Normalize+label remap+dual-scale resize vs the reference's JointScaledImage output."""
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    from dualsuperreslearningforsemseg_amd.models.transforms import DeviceBatchPreparation
+    g = golden('pipeline_metrics')
+    prep = DeviceBatchPreparation(cs.LABEL_MAPPING_DICT, cs.MEAN, cs.STD, (16, 32))
+    (img_in, img_org), (target, _) = prep(dev(g['prep.rgb']), dev(g['prep.labels']))
+    check(host(img_in), g['prep.img_in'], 1e-5, 'img_in'); check(host(img_org), g['prep.img_org'], 1e-5, 'img_org')
+    assert np.array_equal(host(target.float()).astype(np.uint8), g['prep.target'])
+    assert img_in.shape == (2, 3, 16, 32) and HF._ld_of(img_in) == 4          # padded to the 4 channels the stem kernel reads

@@ -234,3 +234,22 @@ def test_philox_known_answer():
     assert [int(v) for v in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     m = philox.dropout_keep_mask_nchw((2, 19, 16, 32), 0.2, 1234, 3)
     assert abs(m.mean() - 0.8) < 0.02
+
+
+# ------------------------------------------------------------------- validation metrics + input-pipeline tail (rows f3/f4)
+def test_seg_metrics_vs_reference(golden):
+    g = golden('pipeline_metrics')
+    mious, accs = [], []
+    for b in range(3):
+        m, a = O.seg_metrics_batch(g[f'metrics.pred{b}'], g[f'metrics.target{b}'])
+        close(m, g[f'metrics.batch_miou{b}'], 1e-12); close(a, g[f'metrics.batch_acc{b}'], 1e-12)
+        mious.append(m); accs.append(a)
+    close(np.nanmean(mious) * 100, g['metrics.miou'], 1e-12); close(np.mean(accs) * 100, g['metrics.acc'], 1e-12)
+
+
+def test_prepare_batch_vs_reference(golden):
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    g = golden('pipeline_metrics')
+    img_in, img_org, target = O.prepare_batch(g['prep.rgb'], g['prep.labels'], cs.LABEL_MAPPING_DICT, cs.MEAN, cs.STD, (16, 32))
+    close(img_in, g['prep.img_in'], 1e-5); close(img_org, g['prep.img_org'], 1e-5)
+    np.testing.assert_array_equal(target, g['prep.target'])
