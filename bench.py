@@ -24,17 +24,19 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
-def cpu_baseline(budget_note=True):
-    """Stage-3 head forward + losses + backward of the numpy oracle, B=2 at 256x512 (fp32), on the host cores."""
-    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+def cpu_baseline(state_dict, batch=2, height=256, width=512):
+    """The same workload on the host cores: numpy oracle (oracle/, a port of the reference arithmetic), whole stage-3 step =
+    ResNet-101 + head forward, CE/MSE/FA losses and the full backward pass, fp32, B=2 at 256x512 (a bounded sample: ~20 s)."""
     import numpy as np
-    import gen
     import oracle as O
-    P = gen.make_head_params(505, gen.FULL, 3)
-    x16, x4, target, org = gen.make_head_inputs(606, 2, 16, 32, gen.FULL)
+    rs = np.random.RandomState(1234)
+    sd = {k: v.detach().float().cpu().numpy() for k, v in state_dict.items() if 'num_batches' not in k}
+    x = rs.standard_normal((batch, 3, height, width)).astype(np.float32)
+    org = rs.standard_normal((batch, 3, 2 * height, 2 * width)).astype(np.float32)
+    tg = rs.randint(0, 19, (batch, 2 * height, 2 * width)).astype(np.uint8); tg[rs.uniform(size=tg.shape) < 0.1] = 255
     t0 = time.time()
-    out = O.head_forward(P, x16, x4, 3, True)
-    O.total_loss(out, target, org, 3)
+    out = O.model_forward(sd, x, 3, True)
+    O.total_loss(out, tg, org, 3)
     dt = time.time() - t0
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
     try:                                        # threads the BLAS behind numpy actually uses
@@ -43,9 +45,9 @@ def cpu_baseline(budget_note=True):
         cores = max(blas) if blas else cores
     except Exception:
         pass
-    return {'value': round(2.0 / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': 'numpy oracle (fp32, multi-threaded BLAS): DSRL head only (ASPP + decoders + transformers, no ResNet-101) '
-                      f'forward + CE/MSE/FA + backward, B=2 at 256x512->512x1024, one pass = {dt:.1f} s'}
+    return {'value': round(batch / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'numpy oracle (fp32, multi-threaded BLAS), whole stage-3 step without the optimizer update: ResNet-101 + head forward, '
+                      f'CE/MSE/FA, full backward; B={batch} at {height}x{width}->{2 * height}x{2 * width}; one pass = {dt:.1f} s'}
 
 
 def main():
@@ -152,6 +154,13 @@ def main():
         from dualsuperreslearningforsemseg_amd import functional as HF
         timed = read_prof(args.steps)
         roof = {'bound': 'mfma', 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'traffic': None}
+        try:        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (not collectable in-process)
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'round1_pmc_traffic.json')))
+            if (args.stage, args.height, args.width, args.batch) == (3, 256, 512, 8):
+                roof['traffic'] = pmc['conv_igemm_f32_kernel']['hbm_bytes_per_launch']
+                roof['traffic_source'] = 'profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950)'
+        except Exception:
+            pass
         if HF.overlap_wgrad:
             # In the timed region weight-gradient kernels run on a side stream concurrently with data-gradient / BN kernels, so a
             # kernel's event-to-event time includes the share of the GPU it gave away. The per-kernel roofline is therefore taken
@@ -185,7 +194,7 @@ def main():
             'roofline': roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline()
+            line['cpu_baseline'] = cpu_baseline(model.state_dict())
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -32,7 +32,15 @@ struct ConvArgs {
     int splits;
     long long slab;          // floats per split slab (M*K) when splits > 1
     unsigned x_bytes, w_bytes, y_bytes;   // extents of the three buffers (< 2^31): buffer loads/stores bounds-check against them
+    int mtiles, ntiles, xcd_remap;        // 1-D launch of mtiles*ntiles blocks (x splits in z); XCD-aware tile order when xcd_remap
 };
+
+// Blocks are dealt round-robin over the 8 XCDs (private L2 each). Remap the linear block id so that every XCD works on a contiguous
+// range of tile ids (bijective for any count): tiles that share input rows then hit the same L2. Speed only, never correctness.
+__device__ inline int xcd_contiguous(int bid, int n) {
+    const int q = n / kNumXCD, r = n % kNumXCD, xcd = bid % kNumXCD, local = bid / kNumXCD;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 constexpr unsigned kOOB = 0x80000000u;      // any offset >= 2^31 is outside every descriptor: loads return 0, stores are dropped
@@ -58,7 +66,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+    const int tile = a.xcd_remap ? xcd_contiguous(blockIdx.x, a.mtiles * a.ntiles) : blockIdx.x;
+    const int m0 = (tile / a.ntiles) * BM, n0 = (tile % a.ntiles) * BN, z = blockIdx.z;      // n fastest: the N tiles of one M tile are neighbours
     const int HoWo = a.Ho * a.Wo;
 
     // ---- rows this thread stages: row = r0 + 32*i, 16-byte column c4
@@ -298,6 +307,8 @@ struct WgradArgs {
     int psplits;
     long long slab;             // floats per split slab (K*RS*C) when psplits > 1
     int taps[64]; int ntaps;    // active filter taps (whole-tensor)
+    int xcd_remap;              // pixel-range-major block order per XCD (blocks of one pixel range share dy / x chunks)
+    int kctiles;                // ktiles * ctiles
 };
 
 template <int MR, int NR, int WGM, int WGN>
@@ -313,13 +324,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs a) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
-    const int kt = blockIdx.x / a.ctiles, ct = blockIdx.x - kt * a.ctiles;
+    // 1-D launch: id -> (pixel split z, tap, k tile, c tile), z slowest; with xcd_remap every XCD owns a contiguous range of ids,
+    // i.e. whole pixel ranges, so a dy / x chunk is fetched into one L2 instead of eight
+    const int per_z = a.ntaps * a.kctiles;
+    const int nb = per_z * a.psplits;
+    const int id = a.xcd_remap ? xcd_contiguous(blockIdx.x, nb) : blockIdx.x;
+    const int zsplit = id / per_z, rem_id = id - zsplit * per_z;
+    const int tapi = rem_id / a.kctiles, kc = rem_id - tapi * a.kctiles;
+    const int kt = kc / a.ctiles, ct = kc - kt * a.ctiles;
     const int k0 = kt * BM, c0 = ct * BN;
-    const int tap = a.taps[blockIdx.y];
+    const int tap = a.taps[tapi];
     const int r = tap / a.S, s = tap - r * a.S;
     const int dh = r * a.dil - a.pad, dw_ = s * a.dil - a.pad;
     const long long nchunks = (a.P + BP - 1) / BP;
-    const long long ch0 = nchunks * blockIdx.z / a.psplits, ch1 = nchunks * (blockIdx.z + 1) / a.psplits;
+    const long long ch0 = nchunks * zsplit / a.psplits, ch1 = nchunks * (zsplit + 1) / a.psplits;
     const int HoWo = a.Ho * a.Wo;
 
     const int a_col = (tid % A_V) * 4, a_row = tid / A_V;
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs a) 
         __syncthreads();
         ch = nxt;
     }
-    float* out = a.dw + (a.psplits > 1 ? (long long)blockIdx.z * a.slab : 0ll);
+    float* out = a.dw + (a.psplits > 1 ? (long long)zsplit * a.slab : 0ll);
     const int RS = a.R * a.S;
     const int col = lane & 31, rq = (lane >> 5) * 4;
 #pragma unroll
@@ -533,9 +551,12 @@ static int pick_splits(long long tiles, int nq) {
 }
 
 template <bool DGRAD>
-static int launch_igemm(const ConvArgs& a, TileCfg cfg, hipStream_t st) {
+static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
     int bm, bn; cfg_dims(cfg, bm, bn);
-    dim3 grid((unsigned)ceil_div(a.M, bm), (unsigned)ceil_div(a.K, bn), (unsigned)a.splits);
+    ConvArgs a = a_in;
+    a.mtiles = (int)ceil_div(a.M, bm); a.ntiles = (int)ceil_div(a.K, bn);
+    a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
+    dim3 grid((unsigned)(a.mtiles * a.ntiles), 1u, (unsigned)a.splits);
     const size_t lds1 = (size_t)(bm + bn) * LDS_LD * sizeof(float);
     const long long nblocks = (long long)grid.x * grid.y * grid.z;
     const bool dbuf = env_int("DSRL_IGEMM_DBUF", 0) != 0;     // measured: no gain from the two-stage LDS variant; kept selectable
@@ -749,7 +770,8 @@ extern "C" int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int l
     a.ntaps = p.tl.n;
     for (int i = 0; i < p.tl.n; ++i) a.taps[i] = p.tl.taps[i];
     a.dw = p.psplits > 1 ? (float*)ws : dw;
-    dim3 grid((unsigned)(p.ktiles * p.ctiles), (unsigned)p.tl.n, (unsigned)p.psplits);
+    a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
+    dim3 grid((unsigned)(a.kctiles * p.tl.n * p.psplits));
     const size_t lds = (size_t)32 * (p.bm + p.bn) * sizeof(float);
     ProfScope prof(1, 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), st);
 #define DSRL_LAUNCH_WGRAD(a_, b_, c_, d_) hipLaunchKernelGGL((conv_wgrad_f32_kernel<a_, b_, c_, d_>), grid, dim3(256), lds, st, a)
@@ -847,7 +869,8 @@ extern "C" int dsrl_conv2d_rowfold_wgrad(const float* x, int ldx, const float* d
     a.ntaps = R;
     for (int r = 0; r < R; ++r) a.taps[r] = r;
     a.dw = p.psplits > 1 ? (float*)ws : dw;
-    dim3 grid((unsigned)(p.ktiles * p.ctiles), (unsigned)R, (unsigned)p.psplits);
+    a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
+    dim3 grid((unsigned)(a.kctiles * R * p.psplits));
     const size_t lds = (size_t)32 * (p.bm + p.bn) * sizeof(float);
     ProfScope prof(1, 2.0 * (double)algorithmic_macs, st);
 #define DSRL_LAUNCH_WGRAD(a_, b_, c_, d_) hipLaunchKernelGGL((conv_wgrad_f32_kernel<a_, b_, c_, d_>), grid, dim3(256), lds, st, a)

@@ -108,3 +108,20 @@ def test_train_or_resume_rejects_cpu_and_amp():
         train_or_resume(device='cpu', mixed_precision=None, **kw)
     with pytest.raises(RuntimeError):
         train_or_resume(device='gpu', mixed_precision='O1', **kw)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No .so -> DsrlHipError with the build hint; nothing falls back to another code path."""
+    from dualsuperreslearningforsemseg_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'libdsrl_hip.so'))
+    with pytest.raises(_lib.DsrlHipError, match='no fallback'):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    import subprocess, sys
+    code = "import sys; import dualsuperreslearningforsemseg_amd, dualsuperreslearningforsemseg_amd.command_handlers.train_or_resume; " \
+           "import dualsuperreslearningforsemseg_amd.metrices, dualsuperreslearningforsemseg_amd.models.transforms; " \
+           "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'"
+    subprocess.run([sys.executable, '-c', code], check=True, cwd=ROOT)
