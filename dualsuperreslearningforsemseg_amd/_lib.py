@@ -34,6 +34,7 @@ PROTOTYPES = {
     'dsrl_conv2d_dgrad': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv2d_wgrad_workspace_bytes': (sz, _conv_shape),
     'dsrl_conv2d_wgrad': (i32, [fp, i32, fp, i32, fp] + _conv_shape + [fp, sz, stream_t]),
+    'dsrl_conv_precision': (i32, [i32]),
     'dsrl_conv2d_inbounds_macs': (i64, _conv_shape),
     'dsrl_conv2d_rowfold_fwd_workspace_bytes': (sz, [i32] * 9),
     'dsrl_conv2d_rowfold_fwd': (i32, [fp, i32, fp, fp, fp, i32] + [i32] * 9 + [i64, fp, sz, stream_t]),

@@ -10,6 +10,7 @@
 // skipped (dilated ASPP convs, ASPP.py:11-13), so the work done equals the in-bounds MAC count the roofline uses.
 #include "common.h"
 #include <algorithm>
+#include <atomic>
 #include <stdlib.h>
 #include <mutex>
 #include <vector>
@@ -19,6 +20,13 @@ namespace dsrl {
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }   // tuning knobs (tools/sweep_conv.py)
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+// Precision modes of the implicit-GEMM kernels.  0: v_mfma_f32_32x32x2_f32, exact fp32.  1 ("bf16x3"): every fp32 operand is split
+// on the way into LDS into hi = bf16(x) and lo = bf16(x - hi); a 16-deep K step costs three v_mfma_f32_32x32x16_bf16 (lo*hi, hi*lo,
+// hi*hi; the lo*lo term, 2^-16 relative, is dropped) accumulated in fp32: ~1e-5 relative error at 16/3 of the fp32 MFMA rate.
+static std::atomic<int> g_conv_precision{-1};
+constexpr int ROW_BF16 = 80;        // bytes per LDS row of 32 bf16 (64 B) + 16 B pad: conflict-free ds_read_b128 over 16 rows
 
 struct ConvArgs {
     const float* x; const float* w; const float* bias; float* y;
@@ -55,8 +63,9 @@ constexpr int LDS_LD = 36;
 // 4 waves per SIMD (<= 128 registers) for the tiles that stage at most 8 rows per thread: 4 blocks of 36.9 KB LDS per CU
 // DBUF: two LDS stages - the next chunk is written while the current one feeds the MFMAs, one barrier per chunk (used when
 // few blocks share a CU); !DBUF: one stage, two barriers, half the LDS (4 blocks per CU on the big grids).
-template <int MR, int NR, int WGM, int WGN, bool DGRAD, int MINW = 2, bool DBUF = false>
+template <int MR, int NR, int WGM, int WGN, bool DGRAD, int MINW = 2, bool DBUF = false, int PREC = 0>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArgs a) {
+    static_assert(!(DBUF && PREC), "the two-stage LDS variant exists for the fp32 path only");
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
     constexpr int STAGE = (BM + BN) * LDS_LD;
@@ -172,10 +181,25 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
 
     const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
     auto lds_store = [&](const float4* ra, const float4* rb, float* As, float* Bs) {
+        if constexpr (PREC == 0) {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
+            for (int i = 0; i < A_IT; ++i) *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
+            for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
+        } else {
+            // planes: A_hi | A_lo | B_hi | B_lo, rows of ROW_BF16 bytes; this thread owns k = 4*c4 .. 4*c4+3 of its rows
+            char* base = reinterpret_cast<char*>(As);
+            auto split_store = [&](const float4 v, char* hi_row, char* lo_row) {
+                const bf16x4 hi = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                const bf16x4 lo = {(__bf16)(v.x - (float)hi[0]), (__bf16)(v.y - (float)hi[1]), (__bf16)(v.z - (float)hi[2]), (__bf16)(v.w - (float)hi[3])};
+                *reinterpret_cast<bf16x4*>(hi_row + c4 * 8) = hi;
+                *reinterpret_cast<bf16x4*>(lo_row + c4 * 8) = lo;
+            };
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) split_store(ra[i], base + (r0 + 32 * i) * ROW_BF16, base + (BM + r0 + 32 * i) * ROW_BF16);
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) split_store(rb[i], base + (2 * BM + r0 + 32 * i) * ROW_BF16, base + (2 * BM + BN + r0 + 32 * i) * ROW_BF16);
+        }
     };
     int issued = q0;           // chunks whose loads have been issued
     auto issue = [&](float4* ra, float4* rb) {
@@ -185,24 +209,54 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
         ++issued;
     };
     auto compute = [&](const float* As, const float* Bs) {
+        if constexpr (PREC == 0) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            float4 fa[MR], fb[NR];
+            for (int ks = 0; ks < BK / 8; ++ks) {
+                float4 fa[MR], fb[NR];
 #pragma unroll
-            for (int i = 0; i < MR; ++i)
-                fa[i] = *reinterpret_cast<const float4*>(&As[((wm * MR + i) * 32 + frag_row) * LDS_LD + ks * 8 + frag_k]);
+                for (int i = 0; i < MR; ++i)
+                    fa[i] = *reinterpret_cast<const float4*>(&As[((wm * MR + i) * 32 + frag_row) * LDS_LD + ks * 8 + frag_k]);
 #pragma unroll
-            for (int j = 0; j < NR; ++j)
-                fb[j] = *reinterpret_cast<const float4*>(&Bs[((wn * NR + j) * 32 + frag_row) * LDS_LD + ks * 8 + frag_k]);
+                for (int j = 0; j < NR; ++j)
+                    fb[j] = *reinterpret_cast<const float4*>(&Bs[((wn * NR + j) * 32 + frag_row) * LDS_LD + ks * 8 + frag_k]);
 #pragma unroll
-            for (int i = 0; i < MR; ++i)
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
+            // lane (r = lane&31, h = lane>>5) holds A[r][8h..8h+7] and B^T[r][8h..8h+7] of each 16-deep step (32x32x16 bf16 operand map)
+            const char* base = reinterpret_cast<const char*>(As);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int koff = ks * 32 + (lane >> 5) * 16;
+                bf16x8 ah[MR], al[MR], bh[NR], bl[NR];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) {
+                    const int row = (wm * MR + i) * 32 + frag_row;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(base + row * ROW_BF16 + koff);
+                    al[i] = *reinterpret_cast<const bf16x8*>(base + (BM + row) * ROW_BF16 + koff);
+                }
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    const int row = (wn * NR + j) * 32 + frag_row;
+                    bh[j] = *reinterpret_cast<const bf16x8*>(base + (2 * BM + row) * ROW_BF16 + koff);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(base + (2 * BM + BN + row) * ROW_BF16 + koff);
                 }
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
     };
     if (q0 < q1) set_tap(tap);
@@ -557,8 +611,16 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
     a.mtiles = (int)ceil_div(a.M, bm); a.ntiles = (int)ceil_div(a.K, bn);
     a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
     dim3 grid((unsigned)(a.mtiles * a.ntiles), 1u, (unsigned)a.splits);
-    const size_t lds1 = (size_t)(bm + bn) * LDS_LD * sizeof(float);
+    int prec = g_conv_precision.load();
+    if (prec < 0) prec = env_int("DSRL_CONV_PRECISION", 0);
+    const size_t lds1 = prec ? (size_t)(bm + bn) * 2 * ROW_BF16 : (size_t)(bm + bn) * LDS_LD * sizeof(float);
     const long long nblocks = (long long)grid.x * grid.y * grid.z;
+    if (prec) {
+#define DSRL_LAUNCH_IGEMM_BF(a_, b_, c_, d_) hipLaunchKernelGGL((conv_igemm_f32_kernel<a_, b_, c_, d_, DGRAD, 2, false, 1>), grid, dim3(256), lds1, st, a)
+        DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_IGEMM_BF)
+#undef DSRL_LAUNCH_IGEMM_BF
+        return launch_status("conv_igemm_f32_kernel<bf16x3>");
+    }
     const bool dbuf = env_int("DSRL_IGEMM_DBUF", 0) != 0;     // measured: no gain from the two-stage LDS variant; kept selectable
 #define DSRL_LAUNCH_IGEMM(a_, b_, c_, d_) hipLaunchKernelGGL((conv_igemm_f32_kernel<a_, b_, c_, d_, DGRAD>), grid, dim3(256), lds1, st, a)
 #define DSRL_LAUNCH_IGEMM_DB(a_, b_, c_, d_) hipLaunchKernelGGL((conv_igemm_f32_kernel<a_, b_, c_, d_, DGRAD, 2, true>), grid, dim3(256), 2 * lds1, st, a)
@@ -884,6 +946,12 @@ extern "C" int dsrl_conv2d_rowfold_wgrad(const float* x, int ldx, const float* d
         return launch_status("wgrad_reduce_kernel");
     }
     return DSRL_OK;
+}
+
+extern "C" int dsrl_conv_precision(int mode) {
+    const int prev = g_conv_precision.load();
+    if (mode >= -1 && mode <= 1) g_conv_precision.store(mode);
+    return prev;
 }
 
 extern "C" int dsrl_prof_enable(int on) {

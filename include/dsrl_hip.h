@@ -64,6 +64,10 @@ size_t dsrl_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int 
 int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                       void* ws, size_t ws_bytes, dsrl_stream_t stream);
+/* Arithmetic of the implicit-GEMM conv kernels, process-wide: 0 = exact fp32 MFMA (default), 1 = "bf16x3" split precision (each fp32
+ * operand = bf16 hi + bf16 lo, three bf16 MFMAs per product, fp32 accumulation, ~1e-5 relative error), -1 = follow the environment
+ * variable DSRL_CONV_PRECISION. Returns the previous setting. */
+int dsrl_conv_precision(int mode);
 /* in-bounds multiply-accumulates of one forward conv (zero-padding taps excluded): the roofline numerator */
 int64_t dsrl_conv2d_inbounds_macs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 
