@@ -7,8 +7,10 @@ gradient reduction + SGD update + the per-iteration loss/NaN readback, exactly w
     python bench.py [--gpus N --steps K --warmup W]           (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     - the dominant kernel (the MFMA implicit-GEMM conv): achieved in-bounds TFLOP/s from HIP events recorded by the
-                 library around every launch inside the timed region, against the 157.3 TFLOP/s dense fp32-MFMA peak;
+  roofline     - the dominant kernel (the MFMA implicit-GEMM conv that takes the most device time): achieved in-bounds (algorithmic)
+                 TFLOP/s from HIP events recorded by the library around every launch, against the dense MFMA peak of the
+                 arithmetic that kernel runs in: 157.3 TFLOP/s for fp32 MFMA, 2516.6/3 for bf16x3 and 2516.6/6 for bf16x6
+                 (three / six bf16 MFMAs per algorithmic product - DESIGN.md section 4); every conv kernel family is listed;
   cpu_baseline - the numpy oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample.
 """
 import argparse
@@ -21,7 +23,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak 157.3 TFLOP/s, dense bf16 2516.6 TFLOP/s.  A split-precision conv
+# issues 3 (bf16x3) or 6 (bf16x6) bf16 MFMAs per algorithmic product, so its MFMA roof for ALGORITHMIC flops is the bf16 peak / 3 or / 6.
+BF16_MFMA_PEAK_TFLOPS = 2516.6
+MFMA_PEAK_TFLOPS = {0: 157.3, 1: BF16_MFMA_PEAK_TFLOPS / 3, 2: BF16_MFMA_PEAK_TFLOPS / 6}      # by arithmetic: fp32, bf16x3, bf16x6
+ARITH_NAME = {0: 'fp32', 1: 'bf16x3', 2: 'bf16x6'}
 
 
 def cpu_baseline(state_dict, batch=2, height=256, width=512):
@@ -137,30 +143,30 @@ def main():
 
     def read_prof(nsteps):
         fams = []
-        for fam in (0, 1):
+        for fam in range(9):                 # family = 3 * arithmetic + pass (include/dsrl_hip.h)
             n = ctypes.c_int64(0); ms = ctypes.c_double(0); fl = ctypes.c_double(0)
             _lib.check(lib.dsrl_prof_read(fam, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), 'dsrl_prof_read')
-            fams.append((lib.dsrl_prof_kernel_name(fam).decode(), n.value, ms.value, fl.value))
+            if n.value:
+                fams.append((lib.dsrl_prof_kernel_name(fam).decode(), n.value, ms.value, fl.value, fam // 3))
         lib.dsrl_prof_enable(0)
-        name, n, ms, fl = max(fams, key=lambda f: f[2])          # dominant = most device time
+        name, n, ms, fl, arith = max(fams, key=lambda f: f[2])          # dominant = most device time
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return {'achieved': round(ach, 2), 'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'kernel': name, 'launches_per_step': n // max(nsteps, 1),
+        peak = MFMA_PEAK_TFLOPS[arith]
+        return {'achieved': round(ach, 2), 'peak': round(peak, 1), 'frac': round(ach / peak, 4), 'kernel': name, 'arithmetic': ARITH_NAME[arith],
+                'launches_per_step': n // max(nsteps, 1),
                 'avg_launch_ms': round(ms / max(n, 1), 5), 'avg_launch_gflop': round(fl / max(n, 1) / 1e9, 3), 'kernel_ms_per_step': round(ms / nsteps, 3),
-                'all_mfma_kernels': {f[0]: {'ms_per_step': round(f[2] / nsteps, 3), 'tflops': round(f[3] / (f[2] * 1e-3) / 1e12, 2) if f[2] > 0 else 0.0}
+                'all_mfma_kernels': {f[0]: {'ms_per_step': round(f[2] / nsteps, 3), 'tflops': round(f[3] / (f[2] * 1e-3) / 1e12, 2) if f[2] > 0 else 0.0,
+                                            'peak': round(MFMA_PEAK_TFLOPS[f[4]], 1),
+                                            'frac': round(f[3] / (f[2] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[f[4]], 4) if f[2] > 0 else 0.0}
                                      for f in fams}}
 
+    from dualsuperreslearningforsemseg_amd import functional as HF
+    conv_arith = {'fp32': 'fp32 MFMA', 'bf16x3': 'bf16x3 split, fp32 accumulate', 'bf16x6': 'bf16x6 split (fp32-equivalent), fp32 accumulate',
+                  'mixed': 'forward bf16x6 (fp32-equivalent), dgrad/wgrad bf16x3; fp32 storage and accumulation'}[HF.get_conv_precision()]
     roof = None
     if not args.no_prof:
-        from dualsuperreslearningforsemseg_amd import functional as HF
         timed = read_prof(args.steps)
-        roof = {'bound': 'mfma', 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'traffic': None}
-        try:        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (not collectable in-process)
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'round1_pmc_traffic.json')))
-            if (args.stage, args.height, args.width, args.batch) == (3, 256, 512, 8):
-                roof['traffic'] = pmc['conv_igemm_f32_kernel']['hbm_bytes_per_launch']
-                roof['traffic_source'] = 'profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950)'
-        except Exception:
-            pass
+        roof = {'bound': 'mfma', 'peak': None, 'unit': 'TFLOP/s', 'traffic': None}
         if HF.overlap_wgrad:
             # In the timed region weight-gradient kernels run on a side stream concurrently with data-gradient / BN kernels, so a
             # kernel's event-to-event time includes the share of the GPU it gave away. The per-kernel roofline is therefore taken
@@ -174,10 +180,19 @@ def main():
             HF.overlap_wgrad = True
             roof.update(excl)
             roof['measured'] = f'{excl_steps} extra steps right after the timed region, weight-gradient side stream disabled (exclusive kernel execution)'
-            roof['timed_region_with_stream_overlap'] = {k: timed[k] for k in ('achieved', 'frac', 'avg_launch_ms', 'kernel_ms_per_step', 'all_mfma_kernels')}
+            roof['timed_region_with_stream_overlap'] = {k: timed[k] for k in ('kernel', 'achieved', 'peak', 'frac', 'avg_launch_ms', 'kernel_ms_per_step', 'all_mfma_kernels')}
         else:
             roof.update(timed)
             roof['measured'] = 'timed region'
+
+    if roof is not None:
+        try:        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (not collectable in-process)
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'round1_pmc_traffic.json')))
+            if (args.stage, args.height, args.width, args.batch) == (3, 256, 512, 8) and roof.get('kernel') in pmc:
+                roof['traffic'] = pmc[roof['kernel']]['hbm_bytes_per_launch']
+                roof['traffic_source'] = 'profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950)'
+        except Exception:
+            pass
 
     if rank == 0:
         gb = args.batch * world
@@ -186,7 +201,7 @@ def main():
                       else f'stage-{args.stage} train images/sec at {args.height}x{args.width}',
             'value': round(gb * args.steps / elapsed, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'host_enqueue_ms_per_step': round(sorted(host_ms[args.warmup:args.warmup + args.steps])[args.steps // 2], 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32', 'conv_arithmetic': conv_arith, 'data': 'synthetic',
             'config': {'workload': f'DSRL stage {args.stage} (ResNet-101 OS16 + ASPP + SSSR/SISR decoders + FA loss), full train step, '
                                    f'random-init weights, {args.height}x{args.width} input -> {2 * args.height}x{2 * args.width} logits',
                        'global_batch': gb, 'per_gpu_batch': args.batch, 'parallelism': f'dp{world}', 'optimizer': 'SGD m0.9 wd5e-4 lr0.006',

@@ -22,11 +22,12 @@ static int env_int(const char* name, int dflt) { const char* v = getenv(name); r
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
-// Precision modes of the implicit-GEMM kernels.  0: v_mfma_f32_32x32x2_f32, exact fp32.  1 ("bf16x3"): every fp32 operand is split
-// on the way into LDS into hi = bf16(x) and lo = bf16(x - hi); a 16-deep K step costs three v_mfma_f32_32x32x16_bf16 (lo*hi, hi*lo,
-// hi*hi; the lo*lo term, 2^-16 relative, is dropped) accumulated in fp32: ~1e-5 relative error at 16/3 of the fp32 MFMA rate.
-static std::atomic<int> g_conv_precision{-1};
-constexpr int ROW_BF16 = 80;        // bytes per LDS row of 32 bf16 (64 B) + 16 B pad: conflict-free ds_read_b128 over 16 rows
+static std::atomic<int> g_conv_precision{-1};     // dsrl_conv_precision(); -1 = DSRL_CONV_PRECISION, modes in conv_precision_mode()
+
+// Split-precision arithmetic ("bf16x3": NPL = 2 planes, "bf16x6": NPL = 3): an fp32 value is carried as NPL bf16 terms
+// x = t0 + t1 (+ t2), t0 = bf16(x), t1 = bf16(x - t0), t2 = bf16(x - t0 - t1), i.e. 16 (24) mantissa bits, and a product is the sum
+// of the bf16 MFMAs a_i * b_j with i + j < NPL (3 or 6 of them), small terms first, all accumulated in fp32
+// (conv_igemm_split_kernel, conv_wgrad_split_kernel).
 
 struct ConvArgs {
     const float* x; const float* w; const float* bias; float* y;
@@ -63,12 +64,11 @@ constexpr int LDS_LD = 36;
 // 4 waves per SIMD (<= 128 registers) for the tiles that stage at most 8 rows per thread: 4 blocks of 36.9 KB LDS per CU
 // DBUF: two LDS stages - the next chunk is written while the current one feeds the MFMAs, one barrier per chunk (used when
 // few blocks share a CU); !DBUF: one stage, two barriers, half the LDS (4 blocks per CU on the big grids).
-template <int MR, int NR, int WGM, int WGN, bool DGRAD, int MINW = 2, bool DBUF = false, int PREC = 0>
+template <int MR, int NR, int WGM, int WGN, bool DGRAD, int MINW = 2, bool DBUF = false>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArgs a) {
-    static_assert(!(DBUF && PREC), "the two-stage LDS variant exists for the fp32 path only");
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
-    constexpr int STAGE = (BM + BN) * LDS_LD;
+    constexpr int STAGE = (BM + BN) * LDS_LD;                    // floats per LDS stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -181,25 +181,10 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
 
     const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
     auto lds_store = [&](const float4* ra, const float4* rb, float* As, float* Bs) {
-        if constexpr (PREC == 0) {
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
 #pragma unroll
-            for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
-        } else {
-            // planes: A_hi | A_lo | B_hi | B_lo, rows of ROW_BF16 bytes; this thread owns k = 4*c4 .. 4*c4+3 of its rows
-            char* base = reinterpret_cast<char*>(As);
-            auto split_store = [&](const float4 v, char* hi_row, char* lo_row) {
-                const bf16x4 hi = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-                const bf16x4 lo = {(__bf16)(v.x - (float)hi[0]), (__bf16)(v.y - (float)hi[1]), (__bf16)(v.z - (float)hi[2]), (__bf16)(v.w - (float)hi[3])};
-                *reinterpret_cast<bf16x4*>(hi_row + c4 * 8) = hi;
-                *reinterpret_cast<bf16x4*>(lo_row + c4 * 8) = lo;
-            };
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) split_store(ra[i], base + (r0 + 32 * i) * ROW_BF16, base + (BM + r0 + 32 * i) * ROW_BF16);
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i) split_store(rb[i], base + (2 * BM + r0 + 32 * i) * ROW_BF16, base + (2 * BM + BN + r0 + 32 * i) * ROW_BF16);
-        }
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
     };
     int issued = q0;           // chunks whose loads have been issued
     auto issue = [&](float4* ra, float4* rb) {
@@ -209,54 +194,24 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
         ++issued;
     };
     auto compute = [&](const float* As, const float* Bs) {
-        if constexpr (PREC == 0) {
 #pragma unroll
-            for (int ks = 0; ks < BK / 8; ++ks) {
-                float4 fa[MR], fb[NR];
+        for (int ks = 0; ks < BK / 8; ++ks) {
+            float4 fa[MR], fb[NR];
 #pragma unroll
-                for (int i = 0; i < MR; ++i)
-                    fa[i] = *reinterpret_cast<const float4*>(&As[((wm * MR + i) * 32 + frag_row) * LDS_LD + ks * 8 + frag_k]);
+            for (int i = 0; i < MR; ++i)
+                fa[i] = *reinterpret_cast<const float4*>(&As[((wm * MR + i) * 32 + frag_row) * LDS_LD + ks * 8 + frag_k]);
 #pragma unroll
-                for (int j = 0; j < NR; ++j)
-                    fb[j] = *reinterpret_cast<const float4*>(&Bs[((wn * NR + j) * 32 + frag_row) * LDS_LD + ks * 8 + frag_k]);
+            for (int j = 0; j < NR; ++j)
+                fb[j] = *reinterpret_cast<const float4*>(&Bs[((wn * NR + j) * 32 + frag_row) * LDS_LD + ks * 8 + frag_k]);
 #pragma unroll
-                for (int i = 0; i < MR; ++i)
-#pragma unroll
-                    for (int j = 0; j < NR; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                    }
-            }
-        } else {
-            // lane (r = lane&31, h = lane>>5) holds A[r][8h..8h+7] and B^T[r][8h..8h+7] of each 16-deep step (32x32x16 bf16 operand map)
-            const char* base = reinterpret_cast<const char*>(As);
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                const int koff = ks * 32 + (lane >> 5) * 16;
-                bf16x8 ah[MR], al[MR], bh[NR], bl[NR];
-#pragma unroll
-                for (int i = 0; i < MR; ++i) {
-                    const int row = (wm * MR + i) * 32 + frag_row;
-                    ah[i] = *reinterpret_cast<const bf16x8*>(base + row * ROW_BF16 + koff);
-                    al[i] = *reinterpret_cast<const bf16x8*>(base + (BM + row) * ROW_BF16 + koff);
-                }
+            for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
-                    const int row = (wn * NR + j) * 32 + frag_row;
-                    bh[j] = *reinterpret_cast<const bf16x8*>(base + (2 * BM + row) * ROW_BF16 + koff);
-                    bl[j] = *reinterpret_cast<const bf16x8*>(base + (2 * BM + BN + row) * ROW_BF16 + koff);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
-#pragma unroll
-                for (int i = 0; i < MR; ++i)
-#pragma unroll
-                    for (int j = 0; j < NR; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-            }
         }
     };
     if (q0 < q1) set_tap(tap);
@@ -296,6 +251,242 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
                 compute(As, Bs);
                 __syncthreads();
             }
+        }
+    }
+
+    // ---- epilogue: D[row][col], col = lane&31 (out channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); bounds by the descriptor
+    float* yout = a.y + (a.splits > 1 ? (long long)z * a.slab : 0ll);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)yout, 0, (int)a.y_bytes, 0x00020000);
+    const int col = lane & 31, rq = (lane >> 5) * 4;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int k = n0 + (wn * NR + j) * 32 + col;
+        const bool kok = k < a.K;
+        const float bv = (a.bias != nullptr && kok) ? a.bias[k] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            const int mb = m0 + (wm * MR + i) * 32 + rq;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                const unsigned off = (kok && m < a.M) ? ((unsigned)m * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e] + bv), yr, (int)off, 0, 0);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ split-precision forward / dgrad
+// bf16x3 (NPL = 2) / bf16x6 (NPL = 3) implicit GEMM, software-pipelined for two waves per SIMD:
+//   * a 32-channel chunk is fetched as before (two float4 per staged row: k = 4*c4.. and 16 + 4*c4..) into one of two register
+//     sets and consumed as two 16-deep half-steps, each with its own LDS stage (two stages, ping-pong);
+//   * one half-step = fragment reads of the current stage, then its MFMAs with the split/convert + LDS writes of the NEXT
+//     half-step interleaved between them (one convert step = one bf16 plane of one staged float4), one barrier;
+//   * LDS rows are 32 B (16 bf16) per plane, unpadded, with the two 16-byte halves swapped on rows with bit 3 set: the b64
+//     writes (8 rows x 32 B per 32 lanes) and the b128 fragment reads (16 rows per 16 lanes) are both bank-conflict-free;
+//   * the loads of chunk q+2 are issued when the registers of chunk q are drained: two half-steps of flight time.
+template <int MR, int NR, int WGM, int WGN, bool DGRAD, int NPL>
+__global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvArgs a) {
+    constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
+    constexpr int A_IT = (BM + 63) / 64, B_IT = (BN + 63) / 64;      // 64 rows per staging pass (4 lanes per row)
+    constexpr int NV = A_IT + B_IT;
+    constexpr int ROWB = 32;
+    constexpr int STAGE = (BM + BN) * NPL * ROWB;                     // bytes
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const S0 = reinterpret_cast<char*>(smem);
+    char* const S1 = S0 + STAGE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tile = a.xcd_remap ? xcd_contiguous(blockIdx.x, a.mtiles * a.ntiles) : blockIdx.x;
+    const int m0 = (tile / a.ntiles) * BM, n0 = (tile % a.ntiles) * BN, z = blockIdx.z;
+    const int HoWo = a.Ho * a.Wo;
+
+    const int c4 = tid & 3, r0 = tid >> 2;
+    const bool b_rows = (BN % 64 == 0) || r0 < BN;                   // BN = 32: only waves 0,1 stage filter rows
+    int a_n[A_IT], a_h[A_IT], a_w[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + r0 + 64 * i;
+        a_ok[i] = m < a.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int n = mm / HoWo, rem = mm - n * HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        a_n[i] = n;
+        if (DGRAD) { a_h[i] = ho + a.pad; a_w[i] = wo + a.pad; }
+        else { a_h[i] = ho * a.stride - a.pad; a_w[i] = wo * a.stride - a.pad; }
+    }
+    const int RS = a.R * a.S;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
+    unsigned b_off[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int k = n0 + r0 + 64 * i;
+        b_off[i] = (k < a.K && b_rows) ? (unsigned)k * (unsigned)(RS * a.C) * 4u : kOOB;
+    }
+
+    // ---- taps that touch at least one in-bounds input pixel for this tile (block-uniform)
+    unsigned long long tapmask = 0ull;
+    {
+        const int mf = m0, ml = min(m0 + BM, a.M) - 1;
+        const int nf = mf / HoWo, nl = ml / HoWo;
+        int hf = 0, hl = a.Ho - 1, wf = 0, wl = a.Wo - 1;
+        if (nf == nl) {
+            hf = (mf - nf * HoWo) / a.Wo; hl = (ml - nl * HoWo) / a.Wo;
+            if (hf == hl) { wf = (mf - nf * HoWo) - hf * a.Wo; wl = (ml - nl * HoWo) - hl * a.Wo; }
+        }
+        for (int r = 0; r < a.R; ++r)
+            for (int s = 0; s < a.S; ++s) {
+                bool act;
+                if (DGRAD) {
+                    act = (hl + a.pad - r * a.dil >= 0) && (hf + a.pad - r * a.dil <= (a.H - 1) * a.stride) &&
+                          (wl + a.pad - s * a.dil >= 0) && (wf + a.pad - s * a.dil <= (a.W - 1) * a.stride);
+                } else {
+                    act = (hl * a.stride - a.pad + r * a.dil >= 0) && (hf * a.stride - a.pad + r * a.dil <= a.H - 1) &&
+                          (wl * a.stride - a.pad + s * a.dil >= 0) && (wf * a.stride - a.pad + s * a.dil <= a.W - 1);
+                }
+                if (act) tapmask |= 1ull << (r * a.S + s);
+            }
+    }
+    const int ntaps = __builtin_popcountll(tapmask);
+    const int nq = ntaps * a.cchunks;
+    const int q0 = (int)((long long)nq * z / a.splits), q1 = (int)((long long)nq * (z + 1) / a.splits);
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    int cc = 0, tap = 0;
+    unsigned long long rem_mask = tapmask;
+    if (q0 < q1) {
+        int skip = q0 / a.cchunks;
+        cc = q0 - skip * a.cchunks;
+        while (skip--) rem_mask &= rem_mask - 1;
+        tap = __builtin_ctzll(rem_mask);
+    }
+    unsigned a_off[A_IT];
+    auto set_tap = [&](int t) {
+        const int r = t / a.S, s = t - r * a.S;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            int hi, wi; bool ok = a_ok[i];
+            if (DGRAD) {
+                const int hn = a_h[i] - r * a.dil, wn_ = a_w[i] - s * a.dil;
+                hi = hn / a.stride; wi = wn_ / a.stride;
+                ok = ok && hn >= 0 && wn_ >= 0 && hi * a.stride == hn && wi * a.stride == wn_ && hi < a.H && wi < a.W;
+            } else {
+                hi = a_h[i] + r * a.dil; wi = a_w[i] + s * a.dil;
+                ok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+            }
+            a_off[i] = ok ? (unsigned)((a_n[i] * a.H + hi) * a.W + wi) * (unsigned)a.ldx * 4u : kOOB;
+        }
+    };
+    // register sets: R[v][half], v < A_IT: pixel rows, v >= A_IT: filter rows
+    float4 R0[NV][2], R1[NV][2];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { R0[v][0] = R0[v][1] = R1[v][0] = R1[v][1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    auto gload = [&](float4 (*R)[2], int t, int ch) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int c = ch * 32 + hf * 16 + c4 * 4;
+            const unsigned coff = c < a.C ? (unsigned)c * 4u : kOOB;          // channel tail of the last chunk reads as zeros
+            const unsigned woff = coff + (unsigned)(t * a.C) * 4u;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) R[i][hf] = buf_load4(xr, a_off[i] + coff);
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) R[A_IT + i][hf] = buf_load4(wr, b_off[i] + woff);
+        }
+    };
+    int issued = q0;
+    auto issue = [&](float4 (*R)[2]) {
+        if (issued >= q1) return;
+        if (issued > q0 && ++cc == a.cchunks) { cc = 0; rem_mask &= rem_mask - 1; tap = __builtin_ctzll(rem_mask); set_tap(tap); }
+        gload(R, tap, cc);
+        ++issued;
+    };
+
+    // ---- LDS addressing (swizzle: 16-byte half h of row r lives at half h ^ bit3(r))
+    const int w_swz = (((c4 >> 1) ^ ((r0 >> 3) & 1)) << 4) + ((c4 & 1) << 3);
+    const int frag_row = lane & 31;
+    const int r_swz = ((lane >> 5) ^ ((frag_row >> 3) & 1)) << 4;
+    float res[4] = {0.f, 0.f, 0.f, 0.f};
+    auto cstep = [&](char* nb, float4 (*R)[2], int hf, int c) {        // plane c % NPL of staged value c / NPL
+        const int v = c / NPL, pl = c % NPL;
+        if (pl == 0) { const float4 x = R[v][hf]; res[0] = x.x; res[1] = x.y; res[2] = x.z; res[3] = x.w; }
+        const bf16x4 t = {(__bf16)res[0], (__bf16)res[1], (__bf16)res[2], (__bf16)res[3]};
+        if (v < A_IT) {
+            *reinterpret_cast<bf16x4*>(nb + (pl * BM + r0 + 64 * v) * ROWB + w_swz) = t;
+        } else if (b_rows) {
+            *reinterpret_cast<bf16x4*>(nb + (NPL * BM + pl * BN + r0 + 64 * (v - A_IT)) * ROWB + w_swz) = t;
+        }
+        if (pl + 1 < NPL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) res[e] -= (float)t[e];
+        }
+    };
+    constexpr int NMFMA = MR * NR * (NPL * (NPL + 1) / 2), CSTEPS = NV * NPL;
+    constexpr int MPS = NMFMA / CSTEPS > 0 ? NMFMA / CSTEPS : 1;
+    auto pipe = [&](const char* cur, char* nxt, float4 (*R)[2], int hf) {
+        // every fragment read first (the compiler cannot prove the two stages disjoint: a read placed after a write would wait)
+        bf16x8 fa[MR][NPL], fb[NR][NPL];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+                fa[i][pl] = *reinterpret_cast<const bf16x8*>(cur + (pl * BM + (wm * MR + i) * 32 + frag_row) * ROWB + r_swz);
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+                fb[j][pl] = *reinterpret_cast<const bf16x8*>(cur + (NPL * BM + pl * BN + (wn * NR + j) * 32 + frag_row) * ROWB + r_swz);
+        __builtin_amdgcn_sched_barrier(0);
+        int m = 0;
+        // small terms first; consecutive MFMAs go to different accumulator tiles; a convert step after every MPS-th MFMA
+#pragma unroll
+        for (int sum = NPL - 1; sum >= 0; --sum)
+#pragma unroll
+            for (int pa = 0; pa <= sum; ++pa)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa], fb[j][sum - pa], acc[i][j], 0, 0, 0);
+                        if (m % MPS == 0 && m / MPS < CSTEPS) cstep(nxt, R, hf, m / MPS);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ++m;
+                    }
+#pragma unroll
+        for (int c = (NMFMA + MPS - 1) / MPS; c < CSTEPS; ++c) cstep(nxt, R, hf, c);
+    };
+
+    if (q0 < q1) {
+        set_tap(tap);
+        issue(R0);
+        issue(R1);
+#pragma unroll
+        for (int c = 0; c < CSTEPS; ++c) cstep(S0, R0, 0, c);
+        __syncthreads();
+    }
+    for (int q = q0; q < q1; q += 2) {
+        pipe(S0, S1, R0, 1);            // MFMAs of chunk q / half 0, convert chunk q / half 1
+        issue(R0);                      // chunk q+2
+        __syncthreads();
+        pipe(S1, S0, R1, 0);            // MFMAs of chunk q / half 1, convert chunk q+1 / half 0 (stale registers past the end: unused)
+        __syncthreads();
+        if (q + 1 < q1) {
+            pipe(S0, S1, R1, 1);
+            issue(R1);                  // chunk q+3
+            __syncthreads();
+            pipe(S1, S0, R0, 0);
+            __syncthreads();
         }
     }
 
@@ -363,6 +554,7 @@ struct WgradArgs {
     int taps[64]; int ntaps;    // active filter taps (whole-tensor)
     int xcd_remap;              // pixel-range-major block order per XCD (blocks of one pixel range share dy / x chunks)
     int kctiles;                // ktiles * ctiles
+    unsigned mHW, sHW, mW, sW;  // magic multipliers / shifts: p / (Ho*Wo) and rem / Wo for p < 2^31 (fast_div)
 };
 
 template <int MR, int NR, int WGM, int WGN>
@@ -471,6 +663,217 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs a) 
         __syncthreads();
         ch = nxt;
     }
+    float* out = a.dw + (a.psplits > 1 ? (long long)zsplit * a.slab : 0ll);
+    const int RS = a.R * a.S;
+    const int col = lane & 31, rq = (lane >> 5) * 4;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int c = c0 + (wn * NR + j) * 32 + col;
+        if (c >= a.C) continue;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            const int kb = k0 + (wm * MR + i) * 32 + rq;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = kb + (e & 3) + 8 * (e >> 2);
+                if (k < a.K) out[((long long)k * RS + tap) * a.C + c] = acc[i][j][e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ split-precision wgrad
+// q = n / d for 0 <= n < 2^31: m = ceil(2^(31+l) / d) with l = ceil(log2 d) >= 1, q = mulhi(n, m) >> (l - 1), exact; d = 1 is
+// flagged by shift 255 (host side: make_magic)
+__device__ __forceinline__ int fast_div(int n, unsigned m, unsigned s) { return s == 255u ? n : (int)(__umulhi((unsigned)n, m) >> s); }
+
+// bf16x3 / bf16x6 weight gradient, software-pipelined like conv_igemm_split_kernel: a 32-pixel chunk is fetched into one of two
+// register sets and consumed as two 16-pixel half-steps (= one 16-deep MFMA step each) through two LDS stages; the split /
+// convert work of the next half-step is interleaved with the MFMAs of the current one.  LDS keeps the chunks pixel-major
+// ([16 px][BM | BN] bf16 per plane, row stride + 64 B) and the K-contiguous MFMA operands are gathered with
+// ds_read_b64_tr_b16 (per 16-lane group: lane 4q+p addresses row q / columns 4p..4p+3, lane i receives column i of the 4 rows).
+// The pixel -> (n, ho, wo) decomposition of every staged x row uses magic-number division (two mul-hi instead of two divides).
+template <int MR, int NR, int WGM, int WGN, int NPL>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArgs a) {
+    constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
+    constexpr int A_V = BM / 4, B_V = BN / 4;                 // float4 per pixel row
+    constexpr int A_RP = 256 / A_V, B_RP = 256 / B_V;          // pixel rows per staging pass
+    constexpr int A_IT = 32 / A_RP, B_IT = 32 / B_RP;          // passes per 32-pixel chunk
+    static_assert(A_IT >= 2, "the dy tile is staged in at least two passes per chunk");
+    constexpr int A_H = A_IT / 2, B_H = B_IT >= 2 ? B_IT / 2 : 1;      // staged values per half-step
+    constexpr int SA = BM * 2 + 64, SB = BN * 2 + 64;          // LDS row strides in bytes
+    constexpr int PLA = 16 * SA, PLB = 16 * SB, OFF_B = NPL * PLA, STAGE = NPL * (PLA + PLB);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const S0 = reinterpret_cast<char*>(smem);
+    char* const S1 = S0 + STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int per_z = a.ntaps * a.kctiles;
+    const int nb = per_z * a.psplits;
+    const int id = a.xcd_remap ? xcd_contiguous(blockIdx.x, nb) : blockIdx.x;
+    const int zsplit = id / per_z, rem_id = id - zsplit * per_z;
+    const int tapi = rem_id / a.kctiles, kc = rem_id - tapi * a.kctiles;
+    const int kt = kc / a.ctiles, ct = kc - kt * a.ctiles;
+    const int k0 = kt * BM, c0 = ct * BN;
+    const int tap = a.taps[tapi];
+    const int r = tap / a.S, s = tap - r * a.S;
+    const int dh = r * a.dil - a.pad, dw_ = s * a.dil - a.pad;
+    const long long nchunks = (a.P + 31) / 32;
+    const int ch0 = (int)(nchunks * zsplit / a.psplits), ch1 = (int)(nchunks * (zsplit + 1) / a.psplits);
+    const int HoWo = a.Ho * a.Wo;
+
+    const int a_col = (tid % A_V) * 4, a_row = tid / A_V;
+    const int b_col = (tid % B_V) * 4, b_row = tid / B_V;
+    const bool a_cok = k0 + a_col < a.K, b_cok = c0 + b_col < a.C;
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
+    const unsigned a_coff = a_cok ? (unsigned)(k0 + a_col) * 4u : kOOB, b_coff = b_cok ? (unsigned)(c0 + b_col) * 4u : kOOB;
+    const int Pi = (int)a.P;
+
+    // register sets: RA[pass], RB[pass] of one 32-pixel chunk
+    float4 RA0[A_IT], RB0[B_IT], RA1[A_IT], RB1[B_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) RA0[i] = RA1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) RB0[i] = RB1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](float4* ra, float4* rb, int ch) {
+        const int pb = ch * 32;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int p = pb + a_row + i * A_RP;
+            ra[i] = buf_load4(dr, (p < Pi ? (unsigned)p * (unsigned)a.lddy * 4u : kOOB) + a_coff);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int p = pb + b_row + i * B_RP;
+            unsigned off = kOOB;
+            if (p < Pi) {
+                const int n = fast_div(p, a.mHW, a.sHW), rem = p - n * HoWo;
+                const int ho = fast_div(rem, a.mW, a.sW), wo = rem - ho * a.Wo;
+                const int hi = ho * a.stride + dh, wi = wo * a.stride + dw_;
+                if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) off = (unsigned)((n * a.H + hi) * a.W + wi) * (unsigned)a.ldx * 4u;
+            }
+            rb[i] = buf_load4(xr, off + b_coff);
+        }
+    };
+    // a 32-pixel chunk whose pixels all read zero padding for this tap contributes nothing: skip it (block-uniform test)
+    auto chunk_live = [&](int ch) -> bool {
+        const int pf = ch * 32, pl = min(pf + 32, Pi) - 1;
+        const int nf = pf / HoWo, nl = pl / HoWo;
+        if (nf != nl) return true;
+        const int hf = (pf - nf * HoWo) / a.Wo, hl = (pl - nl * HoWo) / a.Wo;
+        if (hl * a.stride + dh < 0 || hf * a.stride + dh >= a.H) return false;
+        if (hf == hl) {
+            const int wf = pf - nf * HoWo - hf * a.Wo, wl = pl - nl * HoWo - hl * a.Wo;
+            if (wl * a.stride + dw_ < 0 || wf * a.stride + dw_ >= a.W) return false;
+        }
+        return true;
+    };
+    int ci = ch0;                                  // next chunk to fetch
+    auto issue = [&](float4* ra, float4* rb) -> bool {
+        while (ci < ch1 && !chunk_live(ci)) ++ci;
+        if (ci >= ch1) return false;
+        gload(ra, rb, ci);
+        ++ci;
+        return true;
+    };
+
+    // ---- LDS addressing.  Transposed reads: 16-lane group g -> k half (g >> 1), channel half (g & 1); t = 4q + p
+    const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int tr_off_a = (8 * (tg >> 1) + tq) * SA + (16 * (tg & 1) + 4 * tp) * 2;
+    const int tr_off_b = (8 * (tg >> 1) + tq) * SB + (16 * (tg & 1) + 4 * tp) * 2;
+    const int wa_off = a_row * SA + a_col * 2;                               // + v * A_RP * SA
+    const int b_lrow = B_IT >= 2 ? b_row : (b_row & 15);
+    const int wb_off = OFF_B + b_lrow * SB + b_col * 2;                      // + v * B_RP * SB
+    const int b_half = B_IT >= 2 ? -1 : (b_row >> 4);                        // B_IT == 1: the single pass spans both halves
+    using lds_bf16x4 = __attribute__((address_space(3))) bf16x4;
+    float res[4] = {0.f, 0.f, 0.f, 0.f};
+    auto cstep = [&](char* nb_, const float4* ra, const float4* rb, int hf, int c) {     // plane c % NPL of staged value c / NPL
+        const int v = c / NPL, pl = c % NPL;
+        if (pl == 0) {
+            const float4 x = v < A_H ? ra[hf * A_H + v] : rb[B_IT >= 2 ? hf * B_H + (v - A_H) : 0];
+            res[0] = x.x; res[1] = x.y; res[2] = x.z; res[3] = x.w;
+        }
+        const bf16x4 t = {(__bf16)res[0], (__bf16)res[1], (__bf16)res[2], (__bf16)res[3]};
+        if (v < A_H) {
+            *reinterpret_cast<bf16x4*>(nb_ + pl * PLA + wa_off + v * (A_RP * SA)) = t;
+        } else if (B_IT >= 2 || b_half == hf) {
+            *reinterpret_cast<bf16x4*>(nb_ + pl * PLB + wb_off + (v - A_H) * (B_RP * SB)) = t;
+        }
+        if (pl + 1 < NPL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) res[e] -= (float)t[e];
+        }
+    };
+    constexpr int NMFMA = MR * NR * (NPL * (NPL + 1) / 2), CSTEPS = (A_H + B_H) * NPL;
+    constexpr int MPS = NMFMA / CSTEPS > 0 ? NMFMA / CSTEPS : 1;
+    auto tr8 = [&](const char* q, int stride) -> bf16x8 {
+        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q));
+        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * stride));
+        return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto pipe = [&](const char* cur, char* nxt, const float4* ra, const float4* rb, int hf) {
+        bf16x8 fa[MR][NPL], fb[NR][NPL];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) fa[i][pl] = tr8(cur + pl * PLA + tr_off_a + (wm * MR + i) * 64, SA);
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = tr8(cur + OFF_B + pl * PLB + tr_off_b + (wn * NR + j) * 64, SB);
+        __builtin_amdgcn_sched_barrier(0);
+        int m = 0;
+#pragma unroll
+        for (int sum = NPL - 1; sum >= 0; --sum)
+#pragma unroll
+            for (int pa = 0; pa <= sum; ++pa)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa], fb[j][sum - pa], acc[i][j], 0, 0, 0);
+                        if (m % MPS == 0 && m / MPS < CSTEPS) cstep(nxt, ra, rb, hf, m / MPS);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ++m;
+                    }
+#pragma unroll
+        for (int c = (NMFMA + MPS - 1) / MPS; c < CSTEPS; ++c) cstep(nxt, ra, rb, hf, c);
+    };
+
+    bool v0 = issue(RA0, RB0);
+    bool v1 = v0 && issue(RA1, RB1);
+    if (v0) {
+#pragma unroll
+        for (int c = 0; c < CSTEPS; ++c) cstep(S0, RA0, RB0, 0, c);
+        __syncthreads();
+    }
+    while (v0) {
+        pipe(S0, S1, RA0, RB0, 1);                     // MFMAs of chunk A / half 0, convert chunk A / half 1
+        const bool n0 = v1 && issue(RA0, RB0);         // chunk A+2
+        __syncthreads();
+        pipe(S1, S0, RA1, RB1, 0);                     // MFMAs of chunk A / half 1, convert chunk B / half 0 (stale if !v1: unused)
+        __syncthreads();
+        if (!v1) break;
+        pipe(S0, S1, RA1, RB1, 1);
+        const bool n1 = n0 && issue(RA1, RB1);         // chunk B+2
+        __syncthreads();
+        pipe(S1, S0, RA0, RB0, 0);
+        __syncthreads();
+        v0 = n0; v1 = n1;
+    }
+
     float* out = a.dw + (a.psplits > 1 ? (long long)zsplit * a.slab : 0ll);
     const int RS = a.R * a.S;
     const int col = lane & 31, rq = (lane >> 5) * 4;
@@ -604,6 +1007,33 @@ static int pick_splits(long long tiles, int nq) {
     return (int)std::max<long long>(1, std::min<long long>(nq / 24, cap));
 }
 
+// Conv arithmetic, per pass.  Mode (dsrl_conv_precision(), else DSRL_CONV_PRECISION, else the default 3):
+//   0  fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32, exact products)
+//   1  bf16x3 everywhere   (16 mantissa bits per operand, ~5e-6 relative error per conv)
+//   2  bf16x6 everywhere   (24 mantissa bits per operand: fp32-equivalent, measured error vs fp64 equal to mode 0)
+//   3  forward bf16x6, dgrad / wgrad bf16x3 (logits keep fp32 accuracy, gradients carry ~5e-6)
+// Returns the number of bf16 planes per operand for the pass (0 = fp32 kernel).
+enum ConvPass { PASS_FWD, PASS_DGRAD, PASS_WGRAD };
+static int conv_precision_mode() {
+    int prec = g_conv_precision.load();
+    if (prec < 0) prec = env_int("DSRL_CONV_PRECISION", 3);
+    return prec < 0 ? 0 : (prec > 3 ? 3 : prec);
+}
+static int conv_planes(ConvPass pass) {
+    switch (conv_precision_mode()) {
+        case 0: return 0;
+        case 1: return 2;
+        case 2: return 3;
+        default: return pass == PASS_FWD ? 3 : 2;
+    }
+}
+
+// launch-timer family = 3 * arithmetic (0 fp32, 1 bf16x3, 2 bf16x6) + pass (0 forward, 1 wgrad, 2 dgrad)
+static int prof_family(ConvPass pass) {
+    const int npl = conv_planes(pass);
+    return 3 * (npl ? npl - 1 : 0) + (pass == PASS_FWD ? 0 : (pass == PASS_WGRAD ? 1 : 2));
+}
+
 template <bool DGRAD>
 static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
     int bm, bn; cfg_dims(cfg, bm, bn);
@@ -611,16 +1041,18 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
     a.mtiles = (int)ceil_div(a.M, bm); a.ntiles = (int)ceil_div(a.K, bn);
     a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
     dim3 grid((unsigned)(a.mtiles * a.ntiles), 1u, (unsigned)a.splits);
-    int prec = g_conv_precision.load();
-    if (prec < 0) prec = env_int("DSRL_CONV_PRECISION", 0);
-    const size_t lds1 = prec ? (size_t)(bm + bn) * 2 * ROW_BF16 : (size_t)(bm + bn) * LDS_LD * sizeof(float);
+    const int npl = conv_planes(DGRAD ? PASS_DGRAD : PASS_FWD);
     const long long nblocks = (long long)grid.x * grid.y * grid.z;
-    if (prec) {
-#define DSRL_LAUNCH_IGEMM_BF(a_, b_, c_, d_) hipLaunchKernelGGL((conv_igemm_f32_kernel<a_, b_, c_, d_, DGRAD, 2, false, 1>), grid, dim3(256), lds1, st, a)
-        DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_IGEMM_BF)
-#undef DSRL_LAUNCH_IGEMM_BF
-        return launch_status("conv_igemm_f32_kernel<bf16x3>");
+    if (npl) {
+        const size_t lds2 = (size_t)2 * (bm + bn) * npl * 32;      // two stages of 32-byte rows: <= 60 KiB for every tile
+#define DSRL_LAUNCH_SPLIT(a_, b_, c_, d_)                                                                                    \
+        if (npl == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2>), grid, dim3(256), lds2, st, a); \
+        else hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 3>), grid, dim3(256), lds2, st, a);
+        DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_SPLIT)
+#undef DSRL_LAUNCH_SPLIT
+        return launch_status(npl == 2 ? "conv_igemm_split_kernel<bf16x3>" : "conv_igemm_split_kernel<bf16x6>");
     }
+    const size_t lds1 = (size_t)(bm + bn) * LDS_LD * sizeof(float);
     const bool dbuf = env_int("DSRL_IGEMM_DBUF", 0) != 0;     // measured: no gain from the two-stage LDS variant; kept selectable
 #define DSRL_LAUNCH_IGEMM(a_, b_, c_, d_) hipLaunchKernelGGL((conv_igemm_f32_kernel<a_, b_, c_, d_, DGRAD>), grid, dim3(256), lds1, st, a)
 #define DSRL_LAUNCH_IGEMM_DB(a_, b_, c_, d_) hipLaunchKernelGGL((conv_igemm_f32_kernel<a_, b_, c_, d_, DGRAD, 2, true>), grid, dim3(256), 2 * lds1, st, a)
@@ -702,7 +1134,7 @@ extern "C" int dsrl_conv2d_fwd(const float* x, int ldx, const float* w, const fl
     const long long xb = span_bytes((long long)N * H * W, ldx, C), wb = (long long)K * R * S * C * 4, yb = p.splits > 1 ? (long long)p.M * K * 4 : span_bytes(p.M, ldy, K);
     DSRL_REQUIRE_31(xb, "conv2d_fwd(x)"); DSRL_REQUIRE_31(wb, "conv2d_fwd(w)"); DSRL_REQUIRE_31(yb, "conv2d_fwd(y)");
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
-    ProfScope prof(0, 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), st);
+    ProfScope prof(prof_family(PASS_FWD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), st);
     if (p.splits > 1) {
         a.y = (float*)ws; a.ldy = K; a.bias = nullptr;
         if (int e = launch_igemm<false>(a, p.cfg, st)) return e;
@@ -766,7 +1198,7 @@ extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, cons
         DSRL_REQUIRE_31(xb, "conv2d_dgrad(dy)"); DSRL_REQUIRE_31(wb, "conv2d_dgrad(w)"); DSRL_REQUIRE_31(yb, "conv2d_dgrad(dx)");
         a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
     }
-    ProfScope prof(0, 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), st);
+    ProfScope prof(prof_family(PASS_DGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), st);
     if (p.splits > 1) {
         a.y = slabs; a.ldy = C; a.bias = nullptr;
         if (int e = launch_igemm<true>(a, p.cfg, st)) return e;
@@ -777,6 +1209,34 @@ extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, cons
     }
     a.y = dx; a.ldy = lddx; a.bias = nullptr;
     return launch_igemm<true>(a, p.cfg, st);
+}
+
+static void make_magic(int d, unsigned& m, unsigned& sh) {
+    if (d <= 1) { m = 0; sh = 255u; return; }
+    int l = 0;
+    while ((1ll << l) < d) ++l;
+    const unsigned long long k = 31 + l;
+    m = (unsigned)((((unsigned long long)1 << k) + (unsigned long long)d - 1) / (unsigned long long)d);
+    sh = (unsigned)(l - 1);
+}
+static void launch_wgrad(const WgradArgs& a_in, TileCfg cfg, int bm, int bn, dim3 grid, hipStream_t st) {
+    const int npl = conv_planes(PASS_WGRAD);
+    if (npl) {
+        WgradArgs a = a_in;
+        make_magic(a.Ho * a.Wo, a.mHW, a.sHW);
+        make_magic(a.Wo, a.mW, a.sW);
+        const size_t lds = (size_t)2 * npl * 16 * ((bm * 2 + 64) + (bn * 2 + 64));        // two stages: <= 60 KiB for every tile
+#define DSRL_LAUNCH_WGRAD(a_, b_, c_, d_)                                                                           \
+        if (npl == 2) hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, 2>), grid, dim3(256), lds, st, a); \
+        else hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, 3>), grid, dim3(256), lds, st, a);
+        DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_WGRAD)
+#undef DSRL_LAUNCH_WGRAD
+        return;
+    }
+    const size_t lds = (size_t)32 * (bm + bn) * sizeof(float);
+#define DSRL_LAUNCH_WGRAD(a_, b_, c_, d_) hipLaunchKernelGGL((conv_wgrad_f32_kernel<a_, b_, c_, d_>), grid, dim3(256), lds, st, a_in)
+    DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_WGRAD)
+#undef DSRL_LAUNCH_WGRAD
 }
 
 namespace dsrl {
@@ -834,11 +1294,8 @@ extern "C" int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int l
     a.dw = p.psplits > 1 ? (float*)ws : dw;
     a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
     dim3 grid((unsigned)(a.kctiles * p.tl.n * p.psplits));
-    const size_t lds = (size_t)32 * (p.bm + p.bn) * sizeof(float);
-    ProfScope prof(1, 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), st);
-#define DSRL_LAUNCH_WGRAD(a_, b_, c_, d_) hipLaunchKernelGGL((conv_wgrad_f32_kernel<a_, b_, c_, d_>), grid, dim3(256), lds, st, a)
-    DSRL_CFG_SWITCH(p.cfg, DSRL_LAUNCH_WGRAD)
-#undef DSRL_LAUNCH_WGRAD
+    ProfScope prof(prof_family(PASS_WGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), st);
+    launch_wgrad(a, p.cfg, p.bm, p.bn, grid, st);
     if (int e = launch_status("conv_wgrad_f32_kernel")) return e;
     if (p.psplits > 1) {
         const long long total = (long long)K * p.tl.n * (C / 4);
@@ -879,7 +1336,7 @@ extern "C" int dsrl_conv2d_rowfold_fwd(const float* x, int ldx, const float* w, 
         DSRL_REQUIRE_31(xb, "conv2d_rowfold_fwd(x)"); DSRL_REQUIRE_31(wb, "conv2d_rowfold_fwd(w)"); DSRL_REQUIRE_31(yb, "conv2d_rowfold_fwd(y)");
         a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
     }
-    ProfScope prof(0, 2.0 * (double)algorithmic_macs, st);
+    ProfScope prof(prof_family(PASS_FWD), 2.0 * (double)algorithmic_macs, st);
     if (p.splits > 1) {
         a.y = (float*)ws; a.ldy = K; a.bias = nullptr;
         if (int e = launch_igemm<false>(a, p.cfg, st)) return e;
@@ -933,11 +1390,8 @@ extern "C" int dsrl_conv2d_rowfold_wgrad(const float* x, int ldx, const float* d
     a.dw = p.psplits > 1 ? (float*)ws : dw;
     a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
     dim3 grid((unsigned)(a.kctiles * R * p.psplits));
-    const size_t lds = (size_t)32 * (p.bm + p.bn) * sizeof(float);
-    ProfScope prof(1, 2.0 * (double)algorithmic_macs, st);
-#define DSRL_LAUNCH_WGRAD(a_, b_, c_, d_) hipLaunchKernelGGL((conv_wgrad_f32_kernel<a_, b_, c_, d_>), grid, dim3(256), lds, st, a)
-    DSRL_CFG_SWITCH(p.cfg, DSRL_LAUNCH_WGRAD)
-#undef DSRL_LAUNCH_WGRAD
+    ProfScope prof(prof_family(PASS_WGRAD), 2.0 * (double)algorithmic_macs, st);
+    launch_wgrad(a, p.cfg, p.bm, p.bn, grid, st);
     if (int e = launch_status("conv_wgrad_f32_kernel")) return e;
     if (p.psplits > 1) {
         const long long total = (long long)K * R * (Cfold / 4);
@@ -950,7 +1404,7 @@ extern "C" int dsrl_conv2d_rowfold_wgrad(const float* x, int ldx, const float* d
 
 extern "C" int dsrl_conv_precision(int mode) {
     const int prev = g_conv_precision.load();
-    if (mode >= -1 && mode <= 1) g_conv_precision.store(mode);
+    if (mode >= -1 && mode <= 3) g_conv_precision.store(mode);
     return prev;
 }
 
@@ -981,5 +1435,9 @@ extern "C" int dsrl_prof_read(int family, int64_t* launches, double* total_ms, d
 }
 
 extern "C" const char* dsrl_prof_kernel_name(int family) {
-    return family == 0 ? "conv_igemm_f32_kernel" : (family == 1 ? "conv_wgrad_f32_kernel" : "");
+    static const char* names[9] = {
+        "conv_igemm_f32_kernel (forward)", "conv_wgrad_f32_kernel<fp32>", "conv_igemm_f32_kernel (dgrad)",
+        "conv_igemm_split_kernel<bf16x3> (forward)", "conv_wgrad_f32_kernel<bf16x3>", "conv_igemm_split_kernel<bf16x3> (dgrad)",
+        "conv_igemm_split_kernel<bf16x6> (forward)", "conv_wgrad_f32_kernel<bf16x6>", "conv_igemm_split_kernel<bf16x6> (dgrad)"};
+    return family >= 0 && family < 9 ? names[family] : "";
 }

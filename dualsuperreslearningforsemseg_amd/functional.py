@@ -29,6 +29,28 @@ overlap_wgrad = os.environ.get('DSRL_OVERLAP_WGRAD', '1') != '0'     # measured:
 pretranspose_filters = os.environ.get('DSRL_PRETRANSPOSE', '0') != '0'
 
 
+CONV_PRECISION_MODES = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'mixed': 3}
+
+
+def set_conv_precision(mode):
+    """Arithmetic of the conv kernels (include/dsrl_hip.h: dsrl_conv_precision): 'fp32' (exact fp32 MFMA products), 'bf16x3',
+    'bf16x6' (fp32-equivalent) or 'mixed' (forward bf16x6, backward bf16x3; the default); None follows DSRL_CONV_PRECISION.
+    Returns the previous setting as the library reported it (an int, -1 = environment)."""
+    code = -1 if mode is None else (CONV_PRECISION_MODES[mode] if isinstance(mode, str) else int(mode))
+    if not -1 <= code <= 3:
+        raise ValueError(f'conv precision mode {mode!r}')
+    return int(_lib.load().dsrl_conv_precision(code))
+
+
+def get_conv_precision():
+    """Name of the mode the conv kernels currently run in."""
+    lib = _lib.load()
+    prev = int(lib.dsrl_conv_precision(-2))          # out-of-range argument: query only
+    code = prev if prev >= 0 else int(os.environ.get('DSRL_CONV_PRECISION', '3'))
+    code = min(max(code, 0), 3)
+    return [k for k, v in CONV_PRECISION_MODES.items() if v == code][0]
+
+
 def side_stream(device):
     st = _side.get(device)
     if st is None:

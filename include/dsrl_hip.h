@@ -64,9 +64,14 @@ size_t dsrl_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int 
 int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                       void* ws, size_t ws_bytes, dsrl_stream_t stream);
-/* Arithmetic of the implicit-GEMM conv kernels, process-wide: 0 = exact fp32 MFMA (default), 1 = "bf16x3" split precision (each fp32
- * operand = bf16 hi + bf16 lo, three bf16 MFMAs per product, fp32 accumulation, ~1e-5 relative error), -1 = follow the environment
- * variable DSRL_CONV_PRECISION. Returns the previous setting. */
+/* Arithmetic of the implicit-GEMM conv kernels (forward, dgrad, wgrad, row-folded stem), process-wide. fp32 in, fp32 out and fp32
+ * accumulation in every mode; the modes differ in how the products are formed on the matrix cores:
+ *   0  v_mfma_f32_32x32x2_f32 (exact fp32 products)
+ *   1  "bf16x3": operand = 2 bf16 terms (16 mantissa bits), 3 bf16 MFMAs per product; ~5e-6 relative error per conv
+ *   2  "bf16x6": operand = 3 bf16 terms (24 mantissa bits), 6 bf16 MFMAs per product; error vs fp64 equal to mode 0
+ *   3  forward bf16x6, dgrad / wgrad bf16x3 (default)
+ *  -1  follow the environment variable DSRL_CONV_PRECISION (unset = 3)
+ * Any other value changes nothing (query). Returns the previous setting. */
 int dsrl_conv_precision(int mode);
 /* in-bounds multiply-accumulates of one forward conv (zero-padding taps excluded): the roofline numerator */
 int64_t dsrl_conv2d_inbounds_macs(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
@@ -216,8 +221,9 @@ int dsrl_nan_check(const float* x, int64_t n, int* flag, dsrl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * in-library launch timing (bench.py roofline): when enabled every MFMA conv launch is bracketed by HIP
- * events on its own stream. dsrl_prof_read() synchronises those events and reports per kernel family
- * (0 conv fwd/dgrad igemm, 1 conv wgrad) the launch count, summed milliseconds and summed in-bounds FLOPs.
+ * events on its own stream. dsrl_prof_read() synchronises those events and reports per kernel family the launch count,
+ * summed milliseconds and summed in-bounds FLOPs. family = 3 * arithmetic + pass, arithmetic 0 fp32 / 1 bf16x3 / 2 bf16x6
+ * (see dsrl_conv_precision), pass 0 forward / 1 wgrad / 2 dgrad; dsrl_prof_kernel_name() names the kernel of a family.
  * ---------------------------------------------------------------------------------------------- */
 int dsrl_prof_enable(int on);
 int dsrl_prof_read(int family, int64_t* launches, double* total_ms, double* total_flops);

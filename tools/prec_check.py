@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""fp32 vs bf16x3 conv kernels: accuracy against the fp32 result and timing, per shape (raw C ABI)."""
+"""fp32 / bf16x3 / bf16x6 conv kernels: timing per shape and error against an fp64 torch reference (raw C ABI)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,9 +22,16 @@ for name, (N, C, H, W, K, R, stride, pad, dil) in SHAPES.items():
     st = torch.cuda.current_stream().cuda_stream
     gf = 2 * lib.dsrl_conv2d_inbounds_macs(*shp) / 1e9
     res = {}
+    ref64 = {}
+    if gf < 12:      # fp64 references on the host for the moderate shapes
+        xc = x.view(N, H, W, C).permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+        wc = w.view(K, R, R, C).permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+        yc = torch.nn.functional.conv2d(xc, wc, None, stride, pad, dil)
+        yc.backward(dy.view(N, Ho, Wo, K).permute(0, 3, 1, 2).double().cpu())
+        ref64 = {'fwd': yc.detach().permute(0, 2, 3, 1).reshape(-1), 'dgrad': xc.grad.permute(0, 2, 3, 1).reshape(-1), 'wgrad': wc.grad.permute(0, 2, 3, 1).reshape(-1)}
     for what in ('fwd', 'dgrad', 'wgrad'):
         outs, times = [], []
-        for prec in (0, 1):
+        for prec in (0, 1, 2):
             lib.dsrl_conv_precision(prec)
             if what == 'fwd':
                 o = torch.empty(N * Ho * Wo * K, device=dev)
@@ -38,8 +45,12 @@ for name, (N, C, H, W, K, R, stride, pad, dil) in SHAPES.items():
                 if K % 4: break
                 f = lambda: _lib.check(lib.dsrl_conv2d_wgrad(x.data_ptr(), C, dy.data_ptr(), K, o.data_ptr(), *shp, ws.data_ptr(), ws.numel(), st), 'wgrad')
             times.append(t_ms(f, 10)); outs.append(o.clone())
-        if len(outs) == 2:
-            err = float((outs[1] - outs[0]).abs().max() / outs[0].abs().max())
-            res[what] = f'{what}: fp32 {times[0]*1e3:.0f}us/{gf/times[0]:.0f}TF  bf16x3 {times[1]*1e3:.0f}us/{gf/times[1]:.0f}TF  relerr {err:.1e}'
+        if len(outs) == 3:
+            if what in ref64:
+                r = ref64[what]; errs = [float((o.double().cpu() - r).abs().max() / r.abs().max()) for o in outs]; tag = 'err vs fp64'
+            else:
+                errs = [float((o - outs[0]).abs().max() / outs[0].abs().max()) for o in outs]; tag = 'err vs fp32'
+            res[what] = (f'{what}: fp32 {times[0]*1e3:.0f}us/{gf/times[0]:.0f}TF x3 {times[1]*1e3:.0f}us/{gf/times[1]:.0f}TF x6 {times[2]*1e3:.0f}us/{gf/times[2]:.0f}TF '
+                         f'{tag} {errs[0]:.1e}/{errs[1]:.1e}/{errs[2]:.1e}')
     lib.dsrl_conv_precision(0)
     print(f'{name:10s} ' + ' | '.join(res.values()), flush=True)
