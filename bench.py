@@ -112,10 +112,15 @@ def main():
     host_ms = []
 
     def run(n):
+        # train_or_resume()'s loop: iteration k's loss/NaN readback is collected after iteration k+1 has been enqueued
         last = None
         for _ in range(n):
-            last, _ = step(img, org, tgt, hp['lr'], hp['momentum'], hp['weight_decay'], True)
+            step.enqueue(img, org, tgt, hp['lr'], hp['momentum'], hp['weight_decay'], True)
             host_ms.append(step.host_enqueue_s * 1e3)
+            while step.pending() > 1:
+                last = step.collect()
+        while step.pending():
+            last = step.collect()
         return last
 
     run(args.warmup)
@@ -146,17 +151,20 @@ def main():
         for fam in range(9):                 # family = 3 * arithmetic + pass (include/dsrl_hip.h)
             n = ctypes.c_int64(0); ms = ctypes.c_double(0); fl = ctypes.c_double(0)
             _lib.check(lib.dsrl_prof_read(fam, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), 'dsrl_prof_read')
+            by = ctypes.c_double(0)
+            _lib.check(lib.dsrl_prof_read_bytes(fam, ctypes.byref(by)), 'dsrl_prof_read_bytes')
             if n.value:
-                fams.append((lib.dsrl_prof_kernel_name(fam).decode(), n.value, ms.value, fl.value, fam // 3))
+                fams.append((lib.dsrl_prof_kernel_name(fam).decode(), n.value, ms.value, fl.value, fam // 3, by.value))
         lib.dsrl_prof_enable(0)
-        name, n, ms, fl, arith = max(fams, key=lambda f: f[2])          # dominant = most device time
+        name, n, ms, fl, arith, by = max(fams, key=lambda f: f[2])          # dominant = most device time
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[arith]
         return {'achieved': round(ach, 2), 'peak': round(peak, 1), 'frac': round(ach / peak, 4), 'kernel': name, 'arithmetic': ARITH_NAME[arith],
                 'launches_per_step': n // max(nsteps, 1),
-                'avg_launch_ms': round(ms / max(n, 1), 5), 'avg_launch_gflop': round(fl / max(n, 1) / 1e9, 3), 'kernel_ms_per_step': round(ms / nsteps, 3),
+                'avg_launch_ms': round(ms / max(n, 1), 5), 'avg_launch_gflop': round(fl / max(n, 1) / 1e9, 3),
+                'algorithmic_bytes_per_launch': int(by / max(n, 1)), 'kernel_ms_per_step': round(ms / nsteps, 3),
                 'all_mfma_kernels': {f[0]: {'ms_per_step': round(f[2] / nsteps, 3), 'tflops': round(f[3] / (f[2] * 1e-3) / 1e12, 2) if f[2] > 0 else 0.0,
-                                            'peak': round(MFMA_PEAK_TFLOPS[f[4]], 1),
+                                            'peak': round(MFMA_PEAK_TFLOPS[f[4]], 1), 'algorithmic_bytes_per_launch': int(f[5] / max(f[1], 1)),
                                             'frac': round(f[3] / (f[2] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[f[4]], 4) if f[2] > 0 else 0.0}
                                      for f in fams}}
 

@@ -83,6 +83,7 @@ PROTOTYPES = {
     'dsrl_nan_check': (i32, [fp, i64, fp, stream_t]),
     'dsrl_prof_enable': (i32, [i32]),
     'dsrl_prof_read': (i32, [i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'dsrl_prof_read_bytes': (i32, [i32, C.POINTER(C.c_double)]),
     'dsrl_prof_kernel_name': (C.c_char_p, [i32]),
 }
 

@@ -69,6 +69,7 @@ class TrainStep:
         dev = flat.device
         self.flag = t.zeros(1, dtype=t.int32, device=dev)
         self.zero = t.zeros((), device=dev)
+        self._pending, self._free = [], []           # (pinned host buffer, event) of iterations in flight / reusable
 
     def losses(self, outs, input_org, target):
         SSSR, SISR, SSSR_ft, SISR_ft = outs
@@ -77,7 +78,12 @@ class TrainStep:
         fa = self.w2 * self.fa(SSSR_ft, SISR_ft) if self.stage > 2 else self.zero          # :437
         return ce, ms, fa, ce + ms + fa                                                    # :438
 
-    def __call__(self, input_image, input_org, target, lr, momentum, weight_decay, do_train=True):
+    def enqueue(self, input_image, input_org, target, lr, momentum, weight_decay, do_train=True):
+        """Enqueue one whole iteration on the device and start the asynchronous device->host copy of its five scalars (CE, MSE,
+        FA, total, NaN flag) into pinned memory.  Nothing is waited for: collect() returns the values of the OLDEST iteration
+        still outstanding.  Calling enqueue(k+1) before collect(k) keeps the launch queue fed across the iteration boundary
+        (the reference reads its losses synchronously every iteration, train_or_resume.py:457-460; here the read of
+        iteration k overlaps the enqueue of k+1 and the NaN assert fires one iteration late).  Returns the network outputs."""
         import time
         t_host0 = time.perf_counter()
         flat = self.flat
@@ -92,11 +98,35 @@ class TrainStep:
             if do_train:
                 total.backward()                                                           # :444 (chunked RCCL all-reduce overlaps)
                 flat.sgd_step(lr, momentum, weight_decay)                                  # :445
+        vals = t.cat([t.stack([ce, ms, fa, total]).detach().float(), self.flag.float()])
+        if len(self._free) == 0:
+            self._free.append((t.empty(5, dtype=t.float32, pin_memory=True), t.cuda.Event()))
+        host, ev = self._free.pop()
+        host.copy_(vals, non_blocking=True)                                                # ONE device->host read per iteration
+        ev.record()
+        self._pending.append((host, ev))
         self.host_enqueue_s = time.perf_counter() - t_host0                   # time the host needed to enqueue the whole step
-        vals = t.cat([t.stack([ce, ms, fa, total]).detach().float(), self.flag.float()]).cpu()   # ONE device->host read
+        return outs
+
+    def pending(self):
+        return len(self._pending)
+
+    def collect(self):
+        """Losses [CE, MSE, FA, total] of the oldest outstanding iteration (waits for it); raises on NaN network outputs."""
+        host, ev = self._pending.pop(0)
+        ev.synchronize()
+        vals = [float(v) for v in host]
+        self._free.append((host, ev))
         if vals[4] != 0:
             raise AssertionError("network output contains 'NaN' values and so cannot continue.")
-        return [float(v) for v in vals[:4]], outs
+        return vals[:4]
+
+    def __call__(self, input_image, input_org, target, lr, momentum, weight_decay, do_train=True):
+        """Synchronous form: enqueue + collect of the same iteration."""
+        while self._pending:
+            self.collect()
+        outs = self.enqueue(input_image, input_org, target, lr, momentum, weight_decay, do_train)
+        return self.collect(), outs
 
 
 def _get_state_dict(model):
@@ -202,12 +232,21 @@ def _do_train_val(do_train, epoch, model, step, data_loader, lr, momentum, weigh
     meters = [AverageMeter() for _ in range(4)]                                            # CE, MSE, FA, Total (:385-388)
     nc = model.SSSR_decoder['cls_conv'].out_channels
     miou, mean_accuracy = mIoU(num_classes=nc, ignore_index=step.ignore), Accuracy(num_classes=nc, ignore_index=step.ignore)
+    sizes = []
+
+    def drain(keep):
+        while step.pending() > keep:
+            vals, n = step.collect(), sizes.pop(0)
+            for mtr, v in zip(meters, vals):
+                mtr.update(v, n)                                                           # AverageMeter.update(value, batch), :457-460
+
     for (input_image, input_org), (target, _) in data_loader:
-        vals, outs = step(input_image, input_org, target, lr, momentum, weights_decay, do_train)
-        for mtr, v in zip(meters, vals):
-            mtr.update(v, input_image.shape[0])                                            # AverageMeter.update(value, batch), :457-460
+        outs = step.enqueue(input_image, input_org, target, lr, momentum, weights_decay, do_train)
+        sizes.append(input_image.shape[0])
         if not do_train and is_master_rank:
             miou.update_from_logits(outs[0], target)                                       # argmax + histograms on the device (:476-480)
             mean_accuracy.update_from_logits(outs[0], target)
+        drain(1)              # the losses of iteration k are read while iteration k+1 is already queued
+    drain(0)
     return [m() for m in meters] + [miou() if not do_train else 0.0, mean_accuracy() if not do_train else 0.0]
 

@@ -929,7 +929,7 @@ static int valid_count(int n_in, int n_out, int stride, int pad, int off) {
 }
 
 // ---- launch timing (opt-in)
-struct ProfRec { hipEvent_t a, b; int family; double flops; };
+struct ProfRec { hipEvent_t a, b; int family; double flops, bytes; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -941,9 +941,9 @@ static hipEvent_t prof_event() {
 }
 struct ProfScope {
     bool on; ProfRec r; hipStream_t s;
-    ProfScope(int family, double flops, hipStream_t st) : on(g_prof_on), s(st) {
+    ProfScope(int family, double flops, double bytes, hipStream_t st) : on(g_prof_on), s(st) {
         if (!on) return;
-        r.family = family; r.flops = flops;
+        r.family = family; r.flops = flops; r.bytes = bytes;
         r.a = prof_event(); r.b = prof_event();
         hipEventRecord(r.a, s);
     }
@@ -1134,7 +1134,7 @@ extern "C" int dsrl_conv2d_fwd(const float* x, int ldx, const float* w, const fl
     const long long xb = span_bytes((long long)N * H * W, ldx, C), wb = (long long)K * R * S * C * 4, yb = p.splits > 1 ? (long long)p.M * K * 4 : span_bytes(p.M, ldy, K);
     DSRL_REQUIRE_31(xb, "conv2d_fwd(x)"); DSRL_REQUIRE_31(wb, "conv2d_fwd(w)"); DSRL_REQUIRE_31(yb, "conv2d_fwd(y)");
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
-    ProfScope prof(prof_family(PASS_FWD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), st);
+    ProfScope prof(prof_family(PASS_FWD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
     if (p.splits > 1) {
         a.y = (float*)ws; a.ldy = K; a.bias = nullptr;
         if (int e = launch_igemm<false>(a, p.cfg, st)) return e;
@@ -1198,7 +1198,7 @@ extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, cons
         DSRL_REQUIRE_31(xb, "conv2d_dgrad(dy)"); DSRL_REQUIRE_31(wb, "conv2d_dgrad(w)"); DSRL_REQUIRE_31(yb, "conv2d_dgrad(dx)");
         a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
     }
-    ProfScope prof(prof_family(PASS_DGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), st);
+    ProfScope prof(prof_family(PASS_DGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
     if (p.splits > 1) {
         a.y = slabs; a.ldy = C; a.bias = nullptr;
         if (int e = launch_igemm<true>(a, p.cfg, st)) return e;
@@ -1294,9 +1294,9 @@ extern "C" int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int l
     a.dw = p.psplits > 1 ? (float*)ws : dw;
     a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
     dim3 grid((unsigned)(a.kctiles * p.tl.n * p.psplits));
-    ProfScope prof(prof_family(PASS_WGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), st);
+    ProfScope prof(prof_family(PASS_WGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
     launch_wgrad(a, p.cfg, p.bm, p.bn, grid, st);
-    if (int e = launch_status("conv_wgrad_f32_kernel")) return e;
+    if (int e = launch_status("conv_wgrad kernel")) return e;
     if (p.psplits > 1) {
         const long long total = (long long)K * p.tl.n * (C / 4);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st,
@@ -1336,7 +1336,7 @@ extern "C" int dsrl_conv2d_rowfold_fwd(const float* x, int ldx, const float* w, 
         DSRL_REQUIRE_31(xb, "conv2d_rowfold_fwd(x)"); DSRL_REQUIRE_31(wb, "conv2d_rowfold_fwd(w)"); DSRL_REQUIRE_31(yb, "conv2d_rowfold_fwd(y)");
         a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
     }
-    ProfScope prof(prof_family(PASS_FWD), 2.0 * (double)algorithmic_macs, st);
+    ProfScope prof(prof_family(PASS_FWD), 2.0 * (double)algorithmic_macs, 4.0 * ((double)N * H * W * ldx + (double)K * R * Cfold + (double)N * Ho * Wo * K), st);
     if (p.splits > 1) {
         a.y = (float*)ws; a.ldy = K; a.bias = nullptr;
         if (int e = launch_igemm<false>(a, p.cfg, st)) return e;
@@ -1390,9 +1390,9 @@ extern "C" int dsrl_conv2d_rowfold_wgrad(const float* x, int ldx, const float* d
     a.dw = p.psplits > 1 ? (float*)ws : dw;
     a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
     dim3 grid((unsigned)(a.kctiles * R * p.psplits));
-    ProfScope prof(prof_family(PASS_WGRAD), 2.0 * (double)algorithmic_macs, st);
+    ProfScope prof(prof_family(PASS_WGRAD), 2.0 * (double)algorithmic_macs, 4.0 * ((double)N * H * W * ldx + (double)K * R * Cfold + (double)N * Ho * Wo * K), st);
     launch_wgrad(a, p.cfg, p.bm, p.bn, grid, st);
-    if (int e = launch_status("conv_wgrad_f32_kernel")) return e;
+    if (int e = launch_status("conv_wgrad kernel")) return e;
     if (p.psplits > 1) {
         const long long total = (long long)K * R * (Cfold / 4);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st,
@@ -1434,10 +1434,19 @@ extern "C" int dsrl_prof_read(int family, int64_t* launches, double* total_ms, d
     return DSRL_OK;
 }
 
+extern "C" int dsrl_prof_read_bytes(int family, double* total_bytes) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    double b = 0;
+    for (auto& r : g_prof)
+        if (r.family == family) b += r.bytes;
+    if (total_bytes) *total_bytes = b;
+    return DSRL_OK;
+}
+
 extern "C" const char* dsrl_prof_kernel_name(int family) {
     static const char* names[9] = {
-        "conv_igemm_f32_kernel (forward)", "conv_wgrad_f32_kernel<fp32>", "conv_igemm_f32_kernel (dgrad)",
-        "conv_igemm_split_kernel<bf16x3> (forward)", "conv_wgrad_f32_kernel<bf16x3>", "conv_igemm_split_kernel<bf16x3> (dgrad)",
-        "conv_igemm_split_kernel<bf16x6> (forward)", "conv_wgrad_f32_kernel<bf16x6>", "conv_igemm_split_kernel<bf16x6> (dgrad)"};
+        "conv_igemm_f32_kernel (forward)", "conv_wgrad_f32_kernel", "conv_igemm_f32_kernel (dgrad)",
+        "conv_igemm_split_kernel<bf16x3> (forward)", "conv_wgrad_split_kernel<bf16x3>", "conv_igemm_split_kernel<bf16x3> (dgrad)",
+        "conv_igemm_split_kernel<bf16x6> (forward)", "conv_wgrad_split_kernel<bf16x6>", "conv_igemm_split_kernel<bf16x6> (dgrad)"};
     return family >= 0 && family < 9 ? names[family] : "";
 }

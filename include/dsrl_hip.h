@@ -227,6 +227,8 @@ int dsrl_nan_check(const float* x, int64_t n, int* flag, dsrl_stream_t stream);
  * ---------------------------------------------------------------------------------------------- */
 int dsrl_prof_enable(int on);
 int dsrl_prof_read(int family, int64_t* launches, double* total_ms, double* total_flops);
+/* summed ALGORITHMIC bytes of the recorded launches of a family: every operand (input, filter, output) of the conv once, fp32 */
+int dsrl_prof_read_bytes(int family, double* total_bytes);
 const char* dsrl_prof_kernel_name(int family);
 
 #ifdef __cplusplus
