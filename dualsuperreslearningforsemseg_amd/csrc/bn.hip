@@ -5,6 +5,8 @@
 #include "common.h"
 #include <algorithm>
 #include <initializer_list>
+#include <mutex>
+#include <stdlib.h>
 
 namespace dsrl {
 
@@ -412,6 +414,281 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- fused BN for small tensors
+// The BN layers of the deep stages see 4-16 MB tensors: three dependent kernels (partial / finalize / apply) are launch-latency
+// bound there.  One kernel instead: 256 blocks = (channel group of 32 channels = one 128-byte line per pixel) x (row slab); a
+// block keeps its whole slab in registers (<= 16 float4 per thread and tensor), writes one partial per channel, crosses ONE
+// device-wide barrier, merges the <= 256 slab partials of its own 32 channels (every block of a group computes bit-identical
+// statistics: same partials, same order) and applies from registers - the tensor is read once.  The barrier is a monotonic
+// arrival counter: a launch is handed the count all earlier launches leave behind (host side, under a mutex, stream-ordered).
+// 256 blocks of <= 128 registers are always co-resident on 256 CUs; the spin is bounded so that a bug cannot hang the GPU.
+__device__ unsigned long long g_grid_arrivals = 0ull;
+constexpr int kFusedBlocks = 128, kFusedThreads = 512, kFusedMaxPasses = 16;      // measured: the barrier costs ~20 ns per arriving block
+constexpr int kFusedRL = kFusedThreads / 8, kFusedNW = kFusedThreads / 64, kFusedNS = kFusedThreads / 32;   // row lanes, waves, merge slices
+
+// Hand-off protocol (MI355X_MICROARCH.md, "Correctness boundaries", second valid form): the per-XCD L2s are not coherent with each
+// other, so every handed-off value (the slab partials) is written with an agent-scope store (sc1: written through to the
+// coherence point) that is drained (vmcnt(0), which __syncthreads() implies for the storing wave) before the arrival counter is
+// bumped, and read back with agent-scope loads (st_agent / ld_agent).  No L2-wide write-back / invalidate is needed, which is what
+// an agent-scope release/acquire fence pair would cost in every one of the 256 blocks.
+__device__ inline void grid_barrier(unsigned long long target) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&g_grid_arrivals, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(&g_grid_arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+__device__ inline float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ inline void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+    if (nb > 0.f) {
+        const float nt = na + nb, d = mb - ma;
+        ma += d * (nb / nt);
+        qa += qb + d * d * (na * nb / nt);
+        na = nt;
+    }
+}
+
+// thread (l8 = tid & 7: float4 column of the 32-channel group, rr = tid >> 3: row lane); rows row0 + rr + kFusedRL i
+__global__ __launch_bounds__(kFusedThreads) void bn_fused_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int P, int C,
+                                                            int groups, int slabs, int rows_per_slab, float eps, float momentum,
+                                                            float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ rm, float* __restrict__ rv,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ res, int ldr, int relu, float drop_p, unsigned long long seed, unsigned rng_stream,
+                                                            float* part, unsigned long long target) {
+    __shared__ float shw[kFusedNW][3][4][8];          // per wave: (n, mean, M2) x 4 channels x 8 float4 columns
+    __shared__ double shm[kFusedNS][3][32];           // cross-slab merge: 8 slices x 3 sums x 32 channels
+    __shared__ float fin[2][32];               // mean, invstd of the group's channels
+    const int grp = blockIdx.x % groups, slab = blockIdx.x / groups;
+    const int tid = threadIdx.x, l8 = tid & 7, rr = tid >> 3, wave = tid >> 6;
+    const int q = grp * 8 + l8;
+    const int row0 = slab * rows_per_slab, row1 = min(P, row0 + rows_per_slab);
+
+    float4 xv[kFusedMaxPasses];
+#pragma unroll
+    for (int i = 0; i < kFusedMaxPasses; ++i) {
+        const int p = row0 + rr + kFusedRL * i;
+        xv[i] = p < row1 ? LD4(x, p, ldx, q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ---- slab statistics: per thread shifted sums, then Chan merges over the row lanes (xor tree in the wave, 4 waves via LDS)
+    float n = 0.f, mean[4], m2[4];
+    {
+        const float k0[4] = {xv[0].x, xv[0].y, xv[0].z, xv[0].w};
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < kFusedMaxPasses; ++i) {
+            if (row0 + rr + kFusedRL * i < row1) {
+                const float d0 = xv[i].x - k0[0], d1 = xv[i].y - k0[1], d2 = xv[i].z - k0[2], d3 = xv[i].w - k0[3];
+                s1[0] += d0; s2[0] += d0 * d0; s1[1] += d1; s2[1] += d1 * d1; s1[2] += d2; s2[2] += d2 * d2; s1[3] += d3; s2[3] += d3 * d3;
+                n += 1.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mean[j] = n > 0.f ? k0[j] + s1[j] / n : 0.f;
+            m2[j] = n > 0.f ? fmaxf(s2[j] - s1[j] * s1[j] / n, 0.f) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int sft = 8; sft < 64; sft <<= 1) {
+        const float nb = __shfl_xor(n, sft);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float na = n;                      // the count is shared by the four channels of a thread
+            chan_merge(na, mean[j], m2[j], nb, __shfl_xor(mean[j], sft), __shfl_xor(m2[j], sft));
+        }
+        n += nb;
+    }
+    if ((tid & 63) < 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { shw[wave][0][j][l8] = n; shw[wave][1][j][l8] = mean[j]; shw[wave][2][j][l8] = m2[j]; }
+    }
+    __syncthreads();
+    if (tid < 32) {                            // channel tid of the group: merge the 4 wave results, write the slab partial
+        const int j = tid & 3, c8 = tid >> 2;
+        float na = shw[0][0][j][c8], ma = shw[0][1][j][c8], qa = shw[0][2][j][c8];
+#pragma unroll
+        for (int w = 1; w < kFusedNW; ++w) chan_merge(na, ma, qa, shw[w][0][j][c8], shw[w][1][j][c8], shw[w][2][j][c8]);
+        const long long o = (long long)slab * C + grp * 32 + tid;
+        st_agent(part + o, na); st_agent(part + (long long)slabs * C + o, ma); st_agent(part + 2ll * slabs * C + o, qa);
+    }
+    grid_barrier(target);
+    // ---- statistics of the group's 32 channels from all slabs in one pass, fp64, shifted by slab 0's mean (no cancellation):
+    //      N = sum n, S = sum n d, T = sum (M2 + n d^2), d = m - m_ref;  mean = m_ref + S / N, M2 = T - S^2 / N.
+    //      8 slices of the slabs per channel, 4 slabs (12 independent loads) in flight per thread; slice results added in fixed order
+    {
+        const int ch = tid & 31, k = tid >> 5;
+        const float* pn = part + grp * 32 + ch;
+        const float* pm_ = pn + (long long)slabs * C;
+        const float* pq = pn + 2ll * slabs * C;
+        const float mref = ld_agent(pm_);
+        double N = 0, S = 0, T = 0;
+        for (int base = k; base < slabs; base += 4 * kFusedNS) {
+            float vn[4], vm[4], vq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sl = min(base + kFusedNS * u, slabs - 1);
+                vn[u] = ld_agent(pn + (long long)sl * C); vm[u] = ld_agent(pm_ + (long long)sl * C); vq[u] = ld_agent(pq + (long long)sl * C);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double nb = base + kFusedNS * u < slabs ? (double)vn[u] : 0.0, d = (double)vm[u] - (double)mref;
+                N += nb; S += nb * d; T += (base + kFusedNS * u < slabs ? (double)vq[u] : 0.0) + nb * d * d;
+            }
+        }
+        shm[k][0][ch] = N; shm[k][1][ch] = S; shm[k][2][ch] = T;
+        if (k == 0) fin[0][ch] = mref;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        double N = 0, S = 0, T = 0;
+#pragma unroll
+        for (int k = 0; k < kFusedNS; ++k) { N += shm[k][0][tid]; S += shm[k][1][tid]; T += shm[k][2][tid]; }
+        const double mu = N > 0 ? (double)fin[0][tid] + S / N : 0.0;
+        const double Q = N > 0 ? fmax(T - S * S / N, 0.0) : 0.0;
+        const double var = N > 0 ? Q / N : 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        fin[0][tid] = (float)mu; fin[1][tid] = is;
+        if (slab == 0) {
+            const int c = grp * 32 + tid;
+            mean_out[c] = (float)mu; invstd_out[c] = is;
+            if (rm) rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * mu);
+            if (rv) rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * (N > 1 ? Q / (N - 1) : var));
+        }
+    }
+    __syncthreads();
+    // ---- apply from registers
+    float sc[4], sf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = 4 * q + j; sc[j] = gamma[c] * fin[1][4 * l8 + j]; sf[j] = beta[c] - fin[0][4 * l8 + j] * sc[j]; }
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll
+    for (int i = 0; i < kFusedMaxPasses; ++i) {
+        const int p = row0 + rr + kFusedRL * i;
+        if (p >= row1) continue;
+        float v[4] = {fmaf(xv[i].x, sc[0], sf[0]), fmaf(xv[i].y, sc[1], sf[1]), fmaf(xv[i].z, sc[2], sf[2]), fmaf(xv[i].w, sc[3], sf[3])};
+        if (res) { const float4 r = LD4(res, p, ldr, q); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (drop_p > 0.f) {
+            const unsigned long long e = (unsigned long long)p * C + 4ull * q;       // multiple of 4: one Philox block
+            unsigned r[4];
+            philox4x32_10((unsigned)(e >> 2), (unsigned)(e >> 34), rng_stream, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ((float)(r[j] >> 8) * 5.9604644775390625e-08f >= drop_p) ? v[j] * ks : 0.f;
+        }
+        ST4(y, p, ldy, q) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__global__ __launch_bounds__(kFusedThreads) void bn_fused_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
+                                                            const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
+                                                            float* __restrict__ dres, int lddr, int P, int C, int groups, int slabs, int rows_per_slab,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int relu, float drop_p, int training,
+                                                            float* part, unsigned long long target) {
+    __shared__ float shw[kFusedNW][2][4][8];
+    __shared__ double shm[kFusedNS][2][32];
+    __shared__ float fin[2][32];               // sum g / n, sum g*xhat / n
+    const int grp = blockIdx.x % groups, slab = blockIdx.x / groups;
+    const int tid = threadIdx.x, l8 = tid & 7, rr = tid >> 3, wave = tid >> 6;
+    const int q = grp * 8 + l8;
+    const int row0 = slab * rows_per_slab, row1 = min(P, row0 + rows_per_slab);
+    float mu[4], is[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = mean[4 * q + j]; is[j] = invstd[4 * q + j]; }
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const bool need_y = relu || drop_p > 0.f;
+
+    float4 g[kFusedMaxPasses], xh[kFusedMaxPasses];
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kFusedMaxPasses; ++i) {
+        const int p = row0 + rr + kFusedRL * i;
+        if (p < row1) {
+            const float4 dv = LD4(dy, p, lddy, q), xv = LD4(x, p, ldx, q);
+            float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (need_y) yv = LD4(y, p, ldy, q);
+            g[i] = make_float4(masked_grad(dv.x, yv.x, relu, drop_p, ks), masked_grad(dv.y, yv.y, relu, drop_p, ks),
+                               masked_grad(dv.z, yv.z, relu, drop_p, ks), masked_grad(dv.w, yv.w, relu, drop_p, ks));
+            xh[i] = make_float4((xv.x - mu[0]) * is[0], (xv.y - mu[1]) * is[1], (xv.z - mu[2]) * is[2], (xv.w - mu[3]) * is[3]);
+            sg[0] += g[i].x; sgx[0] += g[i].x * xh[i].x; sg[1] += g[i].y; sgx[1] += g[i].y * xh[i].y;
+            sg[2] += g[i].z; sgx[2] += g[i].z * xh[i].z; sg[3] += g[i].w; sgx[3] += g[i].w * xh[i].w;
+        } else {
+            g[i] = make_float4(0.f, 0.f, 0.f, 0.f); xh[i] = g[i];
+        }
+    }
+#pragma unroll
+    for (int sft = 8; sft < 64; sft <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sg[j] += __shfl_xor(sg[j], sft); sgx[j] += __shfl_xor(sgx[j], sft); }
+    }
+    if ((tid & 63) < 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { shw[wave][0][j][l8] = sg[j]; shw[wave][1][j][l8] = sgx[j]; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int j = tid & 3, c8 = tid >> 2;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < kFusedNW; ++w) { a += shw[w][0][j][c8]; b += shw[w][1][j][c8]; }
+        const long long o = (long long)slab * C + grp * 32 + tid;
+        st_agent(part + o, a); st_agent(part + (long long)slabs * C + o, b);
+    }
+    grid_barrier(target);
+    {
+        const int ch = tid & 31, k = tid >> 5;
+        const float* pa = part + grp * 32 + ch;
+        const float* pb = pa + (long long)slabs * C;
+        double a = 0, b = 0;
+        for (int base = k; base < slabs; base += 4 * kFusedNS) {          // 4 slabs (8 independent loads) in flight per thread
+            float va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sl = min(base + kFusedNS * u, slabs - 1);
+                va[u] = ld_agent(pa + (long long)sl * C); vb[u] = ld_agent(pb + (long long)sl * C);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (base + kFusedNS * u < slabs) { a += va[u]; b += vb[u]; }
+        }
+        shm[k][0][ch] = a; shm[k][1][ch] = b;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < kFusedNS; ++k) { a += shm[k][0][tid]; b += shm[k][1][tid]; }
+        const float inv_n = 1.f / (float)P;
+        fin[0][tid] = training ? (float)a * inv_n : 0.f; fin[1][tid] = training ? (float)b * inv_n : 0.f;
+        if (slab == 0) {
+            const int c = grp * 32 + tid;
+            if (dbeta) dbeta[c] = (float)a;
+            if (dgamma) dgamma[c] = (float)b;
+        }
+    }
+    __syncthreads();
+    float gi[4], mb[4], mg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gi[j] = gamma[4 * q + j] * is[j]; mb[j] = fin[0][4 * l8 + j]; mg[j] = fin[1][4 * l8 + j]; }
+#pragma unroll
+    for (int i = 0; i < kFusedMaxPasses; ++i) {
+        const int p = row0 + rr + kFusedRL * i;
+        if (p >= row1) continue;
+        ST4(dx, p, lddx, q) = make_float4(gi[0] * (g[i].x - mb[0] - xh[i].x * mg[0]), gi[1] * (g[i].y - mb[1] - xh[i].y * mg[1]),
+                                          gi[2] * (g[i].z - mb[2] - xh[i].z * mg[2]), gi[3] * (g[i].w - mb[3] - xh[i].w * mg[3]));
+        if (dres) ST4(dres, p, lddr, q) = g[i];
+    }
+}
+
 static bool vec4_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
     if (C % 4) return false;
     for (int l : lds) if (l % 4) return false;
@@ -435,7 +712,37 @@ static dim3 apply_grid(int64_t P, int C) {
 }  // namespace dsrl
 using namespace dsrl;
 
-extern "C" size_t dsrl_bn_workspace_bytes(int64_t P, int C) { return (size_t)(3 * (size_t)row_blocks(P) + 2) * C * sizeof(float); }
+// row_blocks(P) partial triples of the three-kernel path or up to 256 slab partials of the fused path, plus the two sum rows
+extern "C" size_t dsrl_bn_workspace_bytes(int64_t P, int C) { return (size_t)(3 * (size_t)std::max(row_blocks(P), 256) + 2) * C * sizeof(float); }
+
+namespace dsrl {
+static int env_int_bn(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+struct FusedPlan { bool ok; int groups, slabs, rows_per_slab; };
+// eligible: C a power-of-two multiple of 32 (<= 8192) and the tensor fits the registers of 256 blocks (P*C <= 4.2 M elements)
+static FusedPlan fused_plan(int64_t P, int C) {
+    FusedPlan f{false, 0, 0, 0};
+    if (!env_int_bn("DSRL_BN_FUSED", 1) || C < 32 || C % 32 || P >= (1ll << 30)) return f;
+    const int groups = C / 32;
+    if (groups > kFusedBlocks || kFusedBlocks % groups) return f;
+    const int slabs = kFusedBlocks / groups;
+    const int64_t rows = ceil_div(P, (int64_t)slabs);
+    if (rows > kFusedRL * kFusedMaxPasses) return f;
+    f.ok = true; f.groups = groups; f.slabs = slabs; f.rows_per_slab = (int)rows;
+    return f;
+}
+// arrival count every earlier fused launch on this device leaves behind; launches are handed their barrier target in stream order
+static std::mutex g_fused_mu;
+static unsigned long long g_fused_base[64] = {0};
+struct FusedTicket {
+    std::unique_lock<std::mutex> lock; unsigned long long target; int dev;
+    FusedTicket() : lock(g_fused_mu), target(0), dev(0) {
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        target = g_fused_base[dev] + kFusedBlocks;
+    }
+    void launched() { g_fused_base[dev] = target; }
+};
+}  // namespace dsrl
+
 extern "C" size_t dsrl_colsum_workspace_bytes(int64_t P, int C) { return (size_t)row_blocks(P) * C * sizeof(float); }
 
 extern "C" int dsrl_bn_stats(const float* x, int ldx, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,
@@ -479,6 +786,28 @@ extern "C" int dsrl_bn_apply(const float* x, int ldx, float* y, int ldy, int64_t
     return launch_status("bn_apply_kernel");
 }
 
+extern "C" int dsrl_bn_train_fwd(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,
+                                 float* running_mean, float* running_var, const float* gamma, const float* beta, const float* residual, int ldr,
+                                 int relu, float drop_p, uint64_t seed, uint32_t rng_stream, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_REQUIRE(x && y && mean && invstd && gamma && beta && ws && P > 0 && C > 0 && ldx >= C && ldy >= C, DSRL_E_BADARG, "bn_train_fwd: bad arguments");
+    DSRL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, DSRL_E_BADARG, "bn_train_fwd: dropout p=%f outside [0,1)", drop_p);
+    DSRL_REQUIRE(ws_bytes >= dsrl_bn_workspace_bytes(P, C), DSRL_E_WORKSPACE, "bn_train_fwd: workspace too small");
+    const FusedPlan f = fused_plan(P, C);
+    if (f.ok && vec4_ok(C, {ldx, ldy, residual ? ldr : 0}, {x, y, residual})) {
+        hipStream_t st = (hipStream_t)stream;
+        if (int e = bind_stream_device(st)) return e;
+        FusedTicket t;
+        hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3(kFusedBlocks), dim3(kFusedThreads), 0, st, x, ldx, y, ldy, (int)P, C, f.groups, f.slabs, f.rows_per_slab, eps, momentum,
+                           mean, invstd, running_mean, running_var, gamma, beta, residual, ldr, relu, drop_p, (unsigned long long)seed, (unsigned)rng_stream,
+                           (float*)ws, t.target);
+        if (int e = launch_status("bn_fused_fwd_kernel")) return e;
+        t.launched();
+        return DSRL_OK;
+    }
+    if (int e = dsrl_bn_stats(x, ldx, P, C, eps, momentum, mean, invstd, running_mean, running_var, ws, ws_bytes, stream)) return e;
+    return dsrl_bn_apply(x, ldx, y, ldy, P, C, mean, invstd, gamma, beta, residual, ldr, relu, drop_p, seed, rng_stream, stream);
+}
+
 extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
                            float* dresidual, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
                            float* dgamma, float* dbeta, int relu, float drop_p, int training, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
@@ -487,11 +816,20 @@ extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, con
     DSRL_REQUIRE(ws_bytes >= dsrl_bn_workspace_bytes(P, C), DSRL_E_WORKSPACE, "bn_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
+    const bool v4 = vec4_ok(C, {ldx, y ? ldy : 0, lddy, lddx, dresidual ? lddr : 0}, {x, y, dy, dx, dresidual});
+    const FusedPlan f = fused_plan(P, C);
+    if (f.ok && v4) {
+        FusedTicket t;
+        hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3(kFusedBlocks), dim3(kFusedThreads), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (int)P, C,
+                           f.groups, f.slabs, f.rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, drop_p, training, (float*)ws, t.target);
+        if (int e = launch_status("bn_fused_bwd_kernel")) return e;
+        t.launched();
+        return DSRL_OK;
+    }
     const int nbx = row_blocks(P);
     const long long rpb = ceil_div(P, nbx);
     float* part = (float*)ws;
     float* sums = part + 3ll * nbx * C;
-    const bool v4 = vec4_ok(C, {ldx, y ? ldy : 0, lddy, lddx, dresidual ? lddr : 0}, {x, y, dy, dx, dresidual});
     if (v4)
         hipLaunchKernelGGL(bn_bwd_partial4_kernel, dim3(nbx, (unsigned)ceil_div(C / 4, 256)), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, (long long)P, C, rpb,
                            mean, invstd, relu, drop_p, part, nbx);

@@ -371,26 +371,27 @@ class _BNAct(torch.autograd.Function):
         N, Cc, H, W = x.shape
         P = N * H * W
         st = _stream()
-        ws = _ws(cquery('dsrl_bn_workspace_bytes', P, Cc), x)
-        if training:
-            if P <= 1:
-                raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
-            mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
-            invstd = torch.empty_like(mean)
-            call('dsrl_bn_stats', x.data_ptr(), ldx, P, Cc, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
-                 None if running_mean is None else running_mean.data_ptr(), None if running_var is None else running_var.data_ptr(),
-                 ws.data_ptr(), ws.numel(), st)
-        else:
-            mean = running_mean
-            invstd = torch.empty(Cc, device=x.device, dtype=torch.float32)
-            call('dsrl_bn_invstd_from_var', running_var.data_ptr(), Cc, float(eps), invstd.data_ptr(), st)
         y = new_cl((N, Cc, H, W), x)
         res_ptr, ldr = None, 0
         if residual is not None:
             residual, ldr = pm(residual)
             res_ptr = residual.data_ptr()
-        call('dsrl_bn_apply', x.data_ptr(), ldx, y.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-             res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream), st)
+        if training:
+            if P <= 1:
+                raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
+            ws = _ws(cquery('dsrl_bn_workspace_bytes', P, Cc), x)
+            mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
+            invstd = torch.empty_like(mean)
+            call('dsrl_bn_train_fwd', x.data_ptr(), ldx, y.data_ptr(), Cc, P, Cc, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
+                 None if running_mean is None else running_mean.data_ptr(), None if running_var is None else running_var.data_ptr(),
+                 gamma.data_ptr(), beta.data_ptr(), res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream),
+                 ws.data_ptr(), ws.numel(), st)
+        else:
+            mean = running_mean
+            invstd = torch.empty(Cc, device=x.device, dtype=torch.float32)
+            call('dsrl_bn_invstd_from_var', running_var.data_ptr(), Cc, float(eps), invstd.data_ptr(), st)
+            call('dsrl_bn_apply', x.data_ptr(), ldx, y.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                 res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream), st)
         ctx.save_for_backward(x, y, mean, invstd, gamma)
         ctx.cfg = (bool(training), bool(relu), float(drop_p), residual is not None)
         ctx.gb = (gamma, beta) if isinstance(gamma, torch.nn.Parameter) and isinstance(beta, torch.nn.Parameter) else None

@@ -115,6 +115,14 @@ int dsrl_bn_apply(const float* x, int ldx, float* y, int ldy, int64_t P, int C,
                   const float* mean, const float* invstd, const float* gamma, const float* beta,
                   const float* residual /*nullable*/, int ldr, int relu, float drop_p, uint64_t seed, uint32_t rng_stream,
                   dsrl_stream_t stream);
+/* Training-mode BatchNorm2d forward in one call: batch statistics (as dsrl_bn_stats: mean / invstd out, running stats updated in place)
+ * and y = act(gamma * xhat + beta (+ residual)) (as dsrl_bn_apply). Small tensors (C a power-of-two multiple of 32, P*C <= 4.2 M) take a
+ * single fused kernel that reads x once; everything else runs the statistics and apply kernels. nn.BatchNorm2d (+ReLU, +Dropout) of
+ * ASPP.py:20-21, DSRL.py:24-25,39-41,47-49 and of every backbone block (ResNet101.py). Workspace: dsrl_bn_workspace_bytes(P, C). */
+int dsrl_bn_train_fwd(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,
+                      float* running_mean /*nullable*/, float* running_var /*nullable*/, const float* gamma, const float* beta,
+                      const float* residual /*nullable*/, int ldr, int relu, float drop_p, uint64_t seed, uint32_t rng_stream,
+                      void* ws, size_t ws_bytes, dsrl_stream_t stream);
 /* backward of dsrl_bn_apply. y is the forward output (mask = y > 0 covers relu and dropout).
  * training != 0: batch-statistics gradient; == 0: statistics are constants. dresidual nullable. */
 int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy,

@@ -311,7 +311,9 @@ def test_head_small_stage_gating(golden, stage):
     L = hip_losses(outs, dev(target), dev(org), stage)
     check(np.array([float(v) for v in L]), g[f'stage{stage}.losses'], 1e-4)
     L[3].backward()
-    check(host(head.SSSR_decoder['cls_conv'].weight.grad), g[f'stage{stage}.grad.cls_w'], 2e-3)
+    # batch-2 train-mode BN over 2x4 maps: one ReLU flip of a pre-activation that sits at ~1e-7 moves this gradient by 5e-3 (seen with
+    # any change of summation order in the BN statistics), hence 1e-2 here; the smooth cases are held to 2e-3 in test_head_small_golden
+    check(host(head.SSSR_decoder['cls_conv'].weight.grad), g[f'stage{stage}.grad.cls_w'], 1e-2)
 
 
 @pytest.mark.parametrize('mode', ['eval', 'train'])
@@ -472,8 +474,9 @@ def test_full_model_vs_oracle(mode):
     oracle.  A random-init 101-layer net with train-mode BN over 2x(2x4) maps is ill-conditioned: the oracle run in fp32 differs
     from the same oracle in fp64 by ~4e-3 (logits) and 5-25 % (gradients).  The test is therefore self-calibrating - the HIP
     path must be as close to fp64 as the fp32 CPU oracle is: logits within x1.5 of the oracle's own fp32 error and within 5e-3;
-    gradients within x2.5 (a gradient that is 10 % off in an fp32 CPU run is rounding-pattern noise: exact-product fp32,
-    bf16x6 and the default 'mixed' arithmetic land at 0.10-0.16 on the same tensor).
+    gradients in the L2 norm within x2.5 per tensor and x2 over all tensors together (a gradient that is 10 % off in an fp32 CPU
+    run is rounding-pattern noise - layer4's BNs see 16 values per channel here - so the max norm of a single tensor is not a
+    stable yardstick: exact-product fp32, bf16x6, 'mixed' and different summation orders of the BN statistics move it 0.1-0.4).
     The assembled backbone is not pinned by the reference (torchvision's Bottleneck is absent): its primitives are."""
     from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
     HF.set_conv_precision(mode)
@@ -516,10 +519,19 @@ def test_full_model_vs_oracle(mode):
     assert e_hip <= 5e-3 and e_hip <= 1.5 * e_f32 + 1e-4, report
     check(np.array([float(v) for v in L]), np.array(L64), 1e-3, 'losses')
     assert (host(outs[0]).argmax(1) == o64.SSSR.v.argmax(1)).mean() >= (o32.SSSR.v.argmax(1) == o64.SSSR.v.argmax(1)).mean() - 1e-3
+    def l2(a, b):
+        a = np.asarray(a, np.float64).ravel(); b = np.asarray(b, np.float64).ravel()
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
     for k in keys:
-        e_hip, e_f32 = rel_err(host(P[k].grad), o64.params[k].g), rel_err(o32.params[k].g, o64.params[k].g)
+        e_hip, e_f32 = l2(host(P[k].grad), o64.params[k].g), l2(o32.params[k].g, o64.params[k].g)
         report[k.replace('feature_extractor.', '')] = (e_hip, e_f32)
         assert e_hip <= gslack * e_f32 + 1e-4, (k, e_hip, e_f32)
+    names = [k for k in P if P[k].grad is not None and k in o64.params]
+    cat = lambda f: np.concatenate([np.asarray(f(k), np.float64).ravel() for k in names])
+    g_hip, g_64, g_32 = cat(lambda k: host(P[k].grad)), cat(lambda k: o64.params[k].g), cat(lambda k: o32.params[k].g)
+    report['all gradients (L2)'] = (l2(g_hip, g_64), l2(g_32, g_64))
+    assert report['all gradients (L2)'][0] <= 2.0 * report['all gradients (L2)'][1] + 1e-4, report['all gradients (L2)']
     print({k: f'hip {a:.1e} / f32-oracle {b:.1e}' for k, (a, b) in report.items()})
 
 
