@@ -127,8 +127,10 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    PROF_STRIDE = 7         # the timed region brackets every 7th conv launch with HIP events (an event pair costs ~3 us of device time;
+                            # 7 is co-prime with the conv launches per step, so all layers are sampled evenly over the steps)
     if not args.no_prof:
-        lib.dsrl_prof_enable(1)
+        lib.dsrl_prof_enable(PROF_STRIDE)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     losses = run(args.steps)
@@ -146,7 +148,7 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), f'ranks diverged: {lo.tolist()} vs {hi.tolist()}'
 
-    def read_prof(nsteps):
+    def read_prof(nsteps, stride=1):
         fams = []
         for fam in range(9):                 # family = 3 * arithmetic + pass (include/dsrl_hip.h)
             n = ctypes.c_int64(0); ms = ctypes.c_double(0); fl = ctypes.c_double(0)
@@ -160,10 +162,10 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[arith]
         return {'achieved': round(ach, 2), 'peak': round(peak, 1), 'frac': round(ach / peak, 4), 'kernel': name, 'arithmetic': ARITH_NAME[arith],
-                'launches_per_step': n // max(nsteps, 1),
+                'launches_per_step': n * stride // max(nsteps, 1), 'launches_timed': n,
                 'avg_launch_ms': round(ms / max(n, 1), 5), 'avg_launch_gflop': round(fl / max(n, 1) / 1e9, 3),
-                'algorithmic_bytes_per_launch': int(by / max(n, 1)), 'kernel_ms_per_step': round(ms / nsteps, 3),
-                'all_mfma_kernels': {f[0]: {'ms_per_step': round(f[2] / nsteps, 3), 'tflops': round(f[3] / (f[2] * 1e-3) / 1e12, 2) if f[2] > 0 else 0.0,
+                'algorithmic_bytes_per_launch': int(by / max(n, 1)), 'kernel_ms_per_step': round(ms * stride / nsteps, 3),
+                'all_mfma_kernels': {f[0]: {'ms_per_step': round(f[2] * stride / nsteps, 3), 'tflops': round(f[3] / (f[2] * 1e-3) / 1e12, 2) if f[2] > 0 else 0.0,
                                             'peak': round(MFMA_PEAK_TFLOPS[f[4]], 1), 'algorithmic_bytes_per_launch': int(f[5] / max(f[1], 1)),
                                             'frac': round(f[3] / (f[2] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[f[4]], 4) if f[2] > 0 else 0.0}
                                      for f in fams}}
@@ -173,7 +175,7 @@ def main():
                   'mixed': 'forward bf16x6 (fp32-equivalent), dgrad/wgrad bf16x3; fp32 storage and accumulation'}[HF.get_conv_precision()]
     roof = None
     if not args.no_prof:
-        timed = read_prof(args.steps)
+        timed = read_prof(args.steps, PROF_STRIDE)
         roof = {'bound': 'mfma', 'peak': None, 'unit': 'TFLOP/s', 'traffic': None}
         if HF.overlap_wgrad:
             # In the timed region weight-gradient kernels run on a side stream concurrently with data-gradient / BN kernels, so a
@@ -188,7 +190,8 @@ def main():
             HF.overlap_wgrad = True
             roof.update(excl)
             roof['measured'] = f'{excl_steps} extra steps right after the timed region, weight-gradient side stream disabled (exclusive kernel execution)'
-            roof['timed_region_with_stream_overlap'] = {k: timed[k] for k in ('kernel', 'achieved', 'peak', 'frac', 'avg_launch_ms', 'kernel_ms_per_step', 'all_mfma_kernels')}
+            roof['timed_region_with_stream_overlap'] = {k: timed[k] for k in ('kernel', 'achieved', 'peak', 'frac', 'avg_launch_ms', 'launches_timed', 'kernel_ms_per_step', 'all_mfma_kernels')}
+            roof['timed_region_with_stream_overlap']['sampling'] = f'every {PROF_STRIDE}th conv launch of the timed region'
         else:
             roof.update(timed)
             roof['measured'] = 'timed region'

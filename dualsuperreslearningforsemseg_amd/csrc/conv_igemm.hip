@@ -931,7 +931,8 @@ static int valid_count(int n_in, int n_out, int stride, int pad, int off) {
 // ---- launch timing (opt-in)
 struct ProfRec { hipEvent_t a, b; int family; double flops, bytes; };
 static std::mutex g_prof_mu;
-static bool g_prof_on = false;
+static int g_prof_stride = 0;                    // 0 = off, n = bracket every n-th conv launch with events
+static std::atomic<unsigned> g_prof_seq{0};
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_event_pool;      // events are recycled: recording costs ~1 us, creating them much more
 static hipEvent_t prof_event() {
@@ -941,7 +942,9 @@ static hipEvent_t prof_event() {
 }
 struct ProfScope {
     bool on; ProfRec r; hipStream_t s;
-    ProfScope(int family, double flops, double bytes, hipStream_t st) : on(g_prof_on), s(st) {
+    ProfScope(int family, double flops, double bytes, hipStream_t st) : on(false), s(st) {
+        const int stride = g_prof_stride;
+        on = stride > 0 && (g_prof_seq.fetch_add(1) % (unsigned)stride) == 0;
         if (!on) return;
         r.family = family; r.flops = flops; r.bytes = bytes;
         r.a = prof_event(); r.b = prof_event();
@@ -1410,7 +1413,8 @@ extern "C" int dsrl_conv_precision(int mode) {
 
 extern "C" int dsrl_prof_enable(int on) {
     std::lock_guard<std::mutex> g(g_prof_mu);
-    g_prof_on = on != 0;
+    g_prof_stride = on > 0 ? on : 0;
+    g_prof_seq.store(0);
     if (on) {
         for (auto& r : g_prof) { g_event_pool.push_back(r.a); g_event_pool.push_back(r.b); }
         g_prof.clear();

@@ -228,8 +228,8 @@ int dsrl_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, flo
 int dsrl_nan_check(const float* x, int64_t n, int* flag, dsrl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * in-library launch timing (bench.py roofline): when enabled every MFMA conv launch is bracketed by HIP
- * events on its own stream. dsrl_prof_read() synchronises those events and reports per kernel family the launch count,
+ * in-library launch timing (bench.py roofline): dsrl_prof_enable(n) brackets every n-th MFMA conv launch (n = 1: all of them,
+ * 0: off) with HIP events on its own stream - an event pair costs ~3 us of device time, so a timed region samples. dsrl_prof_read() synchronises those events and reports per kernel family the launch count,
  * summed milliseconds and summed in-bounds FLOPs. family = 3 * arithmetic + pass, arithmetic 0 fp32 / 1 bf16x3 / 2 bf16x6
  * (see dsrl_conv_precision), pass 0 forward / 1 wgrad / 2 dgrad; dsrl_prof_kernel_name() names the kernel of a family.
  * ---------------------------------------------------------------------------------------------- */
