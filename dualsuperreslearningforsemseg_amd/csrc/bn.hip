@@ -432,15 +432,22 @@ constexpr int kFusedRL = kFusedThreads / 8, kFusedNW = kFusedThreads / 64, kFuse
 // coherence point) that is drained (vmcnt(0), which __syncthreads() implies for the storing wave) before the arrival counter is
 // bumped, and read back with agent-scope loads (st_agent / ld_agent).  No L2-wide write-back / invalidate is needed, which is what
 // an agent-scope release/acquire fence pair would cost in every one of the 256 blocks.
-__device__ inline void grid_barrier(unsigned long long target) {
+__device__ inline bool grid_barrier(unsigned long long target) {
+    __shared__ int ok_sh;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(&g_grid_arrivals, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
-        while (__hip_atomic_load(&g_grid_arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
+        bool ok = true;
+        while (__hip_atomic_load(&g_grid_arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins >= (1u << 22)) { ok = false; break; }          // ~1 s: the other blocks never arrived
+            __builtin_amdgcn_s_sleep(1);
+        }
+        ok_sh = ok ? 1 : 0;
     }
     __syncthreads();
+    return ok_sh != 0;      // false: the caller poisons its outputs with NaN, which the per-iteration NaN check reports
 }
 __device__ inline float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_fwd_kernel(const float
         const long long o = (long long)slab * C + grp * 32 + tid;
         st_agent(part + o, na); st_agent(part + (long long)slabs * C + o, ma); st_agent(part + 2ll * slabs * C + o, qa);
     }
-    grid_barrier(target);
+    const bool arrived = grid_barrier(target);
     // ---- statistics of the group's 32 channels from all slabs in one pass, fp64, shifted by slab 0's mean (no cancellation):
     //      N = sum n, S = sum n d, T = sum (M2 + n d^2), d = m - m_ref;  mean = m_ref + S / N, M2 = T - S^2 / N.
     //      8 slices of the slabs per channel, 4 slabs (12 independent loads) in flight per thread; slice results added in fixed order
@@ -553,10 +560,10 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_fwd_kernel(const float
         const double Q = N > 0 ? fmax(T - S * S / N, 0.0) : 0.0;
         const double var = N > 0 ? Q / N : 0.0;
         const float is = (float)(1.0 / sqrt(var + (double)eps));
-        fin[0][tid] = (float)mu; fin[1][tid] = is;
+        fin[0][tid] = arrived ? (float)mu : __builtin_nanf(""); fin[1][tid] = is;
         if (slab == 0) {
             const int c = grp * 32 + tid;
-            mean_out[c] = (float)mu; invstd_out[c] = is;
+            mean_out[c] = fin[0][tid]; invstd_out[c] = is;
             if (rm) rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * mu);
             if (rv) rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * (N > 1 ? Q / (N - 1) : var));
         }
@@ -643,7 +650,7 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_bwd_kernel(const float
         const long long o = (long long)slab * C + grp * 32 + tid;
         st_agent(part + o, a); st_agent(part + (long long)slabs * C + o, b);
     }
-    grid_barrier(target);
+    const bool arrived = grid_barrier(target);
     {
         const int ch = tid & 31, k = tid >> 5;
         const float* pa = part + grp * 32 + ch;
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_bwd_kernel(const float
 #pragma unroll
         for (int k = 0; k < kFusedNS; ++k) { a += shm[k][0][tid]; b += shm[k][1][tid]; }
         const float inv_n = 1.f / (float)P;
-        fin[0][tid] = training ? (float)a * inv_n : 0.f; fin[1][tid] = training ? (float)b * inv_n : 0.f;
+        fin[0][tid] = !arrived ? __builtin_nanf("") : (training ? (float)a * inv_n : 0.f); fin[1][tid] = training ? (float)b * inv_n : 0.f;
         if (slab == 0) {
             const int c = grp * 32 + tid;
             if (dbeta) dbeta[c] = (float)a;
