@@ -207,6 +207,49 @@ def test_batchnorm_relu_dropout_residual_vs_oracle(C):
     check(host(bn.weight.grad), dgo, 1e-4, 'dgamma'); check(host(bn.bias.grad), dbo, 1e-4, 'dbeta')
 
 
+@pytest.mark.parametrize('shape', [(8, 256, 16, 32), (8, 1024, 16, 32), (8, 64, 64, 128), (2, 512, 2, 4), (2, 256, 1, 1), (3, 128, 5, 7), (2, 32, 3, 3)])
+@pytest.mark.parametrize('variant', ['relu+res+drop', 'plain'])
+def test_batchnorm_fused_vs_three_kernel_path_and_oracle(shape, variant):
+    """The single-kernel BN for small tensors (bn_fused_fwd/bwd_kernel: register-resident slabs + one device-wide barrier) against
+    the statistics / finalize / apply kernels it replaces (DSRL_BN_FUSED=0 selects them per call) and against the fp64 oracle:
+    layer3 / layer4 / layer1 shapes, one row per slab (2x4 maps), the pooled ASPP branch (one pixel per image), ragged row counts."""
+    N, C, H, W = shape
+    rs = np.random.RandomState(sum(shape))
+    x = (rs.standard_normal(shape) * 2 + 0.5).astype(np.float32); res = rs.standard_normal(shape).astype(np.float32)
+    gamma = rs.uniform(0.5, 1.5, C).astype(np.float32); beta = rs.standard_normal(C).astype(np.float32)
+    dy = rs.standard_normal(shape).astype(np.float32)
+    full = variant != 'plain'
+    out = {}
+    for fused in ('1', '0'):
+        os.environ['DSRL_BN_FUSED'] = fused
+        try:
+            bn = D.nn_modules.HipBatchNorm2d(C).to(DEV)
+            with torch.no_grad():
+                bn.weight.copy_(dev(gamma)); bn.bias.copy_(dev(beta))
+            bn.train()
+            xt = dev(x).requires_grad_(True); rt = dev(res).requires_grad_(True) if full else None
+            y = HF.batch_norm_act(xt, bn, relu=full, drop_p=0.2 if full else 0.0, seed=77, rng_stream=5, residual=rt)
+            y.backward(dev(dy))
+            out[fused] = [host(y), host(xt.grad), host(bn.weight.grad), host(bn.bias.grad), host(bn.running_mean), host(bn.running_var)] + \
+                         ([host(rt.grad)] if full else [])
+        finally:
+            os.environ.pop('DSRL_BN_FUSED', None)
+    for a, b, name in zip(out['1'], out['0'], ('y', 'dx', 'dgamma', 'dbeta', 'running_mean', 'running_var', 'dres')):
+        check(a, b, 2e-5 if name in ('y', 'running_mean', 'running_var', 'dres') else 2e-4, 'fused vs three-kernel ' + name)
+    yo, (mean, invstd), (rm, rv) = O.batchnorm_train(x.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64), np.zeros(C), np.ones(C))
+    if full:
+        keep = O.dropout_mask(x.shape, 0.2, 77, 5)
+        act = np.maximum(yo + res, 0)
+        yo = act * keep / 0.8
+        gpre = dy.astype(np.float64) * keep / 0.8 * (act > 0)
+    else:
+        gpre = dy.astype(np.float64)
+    dxo, dgo, dbo = O.batchnorm_train_bwd(x.astype(np.float64), gamma.astype(np.float64), mean, invstd, gpre)
+    y, dx, dg, db = out['1'][:4]
+    check(y, yo, 2e-5, 'y'); check(dx, dxo, 2e-4, 'dx'); check(dg, dgo, 2e-4, 'dgamma'); check(db, dbo, 2e-4, 'dbeta')
+    check(out['1'][4], rm, 1e-5, 'running_mean'); check(out['1'][5], rv, 1e-5, 'running_var')
+
+
 def test_dropout_matches_oracle_philox():
     x = np.random.RandomState(3).standard_normal((2, 19, 16, 32)).astype(np.float32)
     xt = dev(x).requires_grad_(True)
