@@ -424,7 +424,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
 // arrival counter: a launch is handed the count all earlier launches leave behind (host side, under a mutex, stream-ordered).
 // 256 blocks of <= 128 registers are always co-resident on 256 CUs; the spin is bounded so that a bug cannot hang the GPU.
 __device__ unsigned long long g_grid_arrivals = 0ull;
-constexpr int kFusedBlocks = 128, kFusedThreads = 512, kFusedMaxPasses = 16;      // measured: the barrier costs ~20 ns per arriving block
+constexpr int kFusedBlocks = 128, kFusedBlocksBig = 256, kFusedThreads = 512, kFusedMaxPasses = 16;   // measured: the barrier costs ~20 ns per arriving block,
+                                                                                                   // so 128 blocks unless the tensor needs the registers of 256
 constexpr int kFusedRL = kFusedThreads / 8, kFusedNW = kFusedThreads / 64, kFusedNS = kFusedThreads / 32;   // row lanes, waves, merge slices
 
 // Hand-off protocol (MI355X_MICROARCH.md, "Correctness boundaries", second valid form): the per-XCD L2s are not coherent with each
@@ -724,17 +725,21 @@ extern "C" size_t dsrl_bn_workspace_bytes(int64_t P, int C) { return (size_t)(3 
 
 namespace dsrl {
 static int env_int_bn(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
-struct FusedPlan { bool ok; int groups, slabs, rows_per_slab; };
-// eligible: C a power-of-two multiple of 32 (<= 8192) and the tensor fits the registers of 256 blocks (P*C <= 4.2 M elements)
+struct FusedPlan { bool ok; int blocks, groups, slabs, rows_per_slab; };
+// eligible: C a power-of-two multiple of 32 and the tensor fits the registers of 128 (P*C <= 4.2 M elements) or 256 blocks (8.4 M)
 static FusedPlan fused_plan(int64_t P, int C) {
-    FusedPlan f{false, 0, 0, 0};
+    FusedPlan f{false, 0, 0, 0, 0};
     if (!env_int_bn("DSRL_BN_FUSED", 1) || C < 32 || C % 32 || P >= (1ll << 30)) return f;
     const int groups = C / 32;
-    if (groups > kFusedBlocks || kFusedBlocks % groups) return f;
-    const int slabs = kFusedBlocks / groups;
-    const int64_t rows = ceil_div(P, (int64_t)slabs);
-    if (rows > kFusedRL * kFusedMaxPasses) return f;
-    f.ok = true; f.groups = groups; f.slabs = slabs; f.rows_per_slab = (int)rows;
+    for (int blocks : {kFusedBlocks, kFusedBlocksBig}) {
+        if (groups > blocks || blocks % groups) continue;
+        if (blocks == kFusedBlocksBig && !env_int_bn("DSRL_BN_FUSED_BIG", 1)) continue;
+        const int slabs = blocks / groups;
+        const int64_t rows = ceil_div(P, (int64_t)slabs);
+        if (rows > kFusedRL * kFusedMaxPasses) continue;
+        f.ok = true; f.blocks = blocks; f.groups = groups; f.slabs = slabs; f.rows_per_slab = (int)rows;
+        return f;
+    }
     return f;
 }
 // arrival count every earlier fused launch on this device leaves behind; launches are handed their barrier target in stream order
@@ -742,9 +747,9 @@ static std::mutex g_fused_mu;
 static unsigned long long g_fused_base[64] = {0};
 struct FusedTicket {
     std::unique_lock<std::mutex> lock; unsigned long long target; int dev;
-    FusedTicket() : lock(g_fused_mu), target(0), dev(0) {
+    explicit FusedTicket(int blocks) : lock(g_fused_mu), target(0), dev(0) {
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-        target = g_fused_base[dev] + kFusedBlocks;
+        target = g_fused_base[dev] + (unsigned long long)blocks;
     }
     void launched() { g_fused_base[dev] = target; }
 };
@@ -803,8 +808,8 @@ extern "C" int dsrl_bn_train_fwd(const float* x, int ldx, float* y, int ldy, int
     if (f.ok && vec4_ok(C, {ldx, ldy, residual ? ldr : 0}, {x, y, residual})) {
         hipStream_t st = (hipStream_t)stream;
         if (int e = bind_stream_device(st)) return e;
-        FusedTicket t;
-        hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3(kFusedBlocks), dim3(kFusedThreads), 0, st, x, ldx, y, ldy, (int)P, C, f.groups, f.slabs, f.rows_per_slab, eps, momentum,
+        FusedTicket t(f.blocks);
+        hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3(f.blocks), dim3(kFusedThreads), 0, st, x, ldx, y, ldy, (int)P, C, f.groups, f.slabs, f.rows_per_slab, eps, momentum,
                            mean, invstd, running_mean, running_var, gamma, beta, residual, ldr, relu, drop_p, (unsigned long long)seed, (unsigned)rng_stream,
                            (float*)ws, t.target);
         if (int e = launch_status("bn_fused_fwd_kernel")) return e;
@@ -826,8 +831,8 @@ extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, con
     const bool v4 = vec4_ok(C, {ldx, y ? ldy : 0, lddy, lddx, dresidual ? lddr : 0}, {x, y, dy, dx, dresidual});
     const FusedPlan f = fused_plan(P, C);
     if (f.ok && v4) {
-        FusedTicket t;
-        hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3(kFusedBlocks), dim3(kFusedThreads), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (int)P, C,
+        FusedTicket t(f.blocks);
+        hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3(f.blocks), dim3(kFusedThreads), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (int)P, C,
                            f.groups, f.slabs, f.rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, drop_p, training, (float*)ws, t.target);
         if (int e = launch_status("bn_fused_bwd_kernel")) return e;
         t.launched();
