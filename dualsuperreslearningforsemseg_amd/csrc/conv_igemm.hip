@@ -42,6 +42,7 @@ struct ConvArgs {
     long long slab;          // floats per split slab (M*K) when splits > 1
     unsigned x_bytes, w_bytes, y_bytes;   // extents of the three buffers (< 2^31): buffer loads/stores bounds-check against them
     int mtiles, ntiles, xcd_remap;        // 1-D launch of mtiles*ntiles blocks (x splits in z); XCD-aware tile order when xcd_remap
+    int kg;                               // split kernels: K groups per block (1, 2 or 4)
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (private L2 each). Remap the linear block id so that every XCD works on a contiguous
@@ -284,19 +285,23 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
 //     half-step interleaved between them (one convert step = one bf16 plane of one staged float4), one barrier;
 //   * LDS rows are 32 B (16 bf16) per plane, unpadded, with the two 16-byte halves swapped on rows with bit 3 set: the b64
 //     writes (8 rows x 32 B per 32 lanes) and the b128 fragment reads (16 rows per 16 lanes) are both bank-conflict-free;
-//   * the loads of chunk q+2 are issued when the registers of chunk q are drained: two half-steps of flight time.
-template <int MR, int NR, int WGM, int WGN, bool DGRAD, int NPL>
-__global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvArgs a) {
+//   * the loads of chunk q+2 are issued when the registers of chunk q are drained: two half-steps of flight time;
+//   * KG > 1 ("K groups", for grids of at most ~1.5 tiles per CU): the block has KG groups of 4 waves, group g runs the same pipeline
+//     on chunks g, g+KG, ... with its own two LDS stages, and the KG accumulator sets are summed through LDS in a fixed order at the
+//     end - the latency-hiding of split-K (more waves per SIMD) without slab traffic or a reduce launch.
+template <int MR, int NR, int WGM, int WGN, bool DGRAD, int NPL, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_kernel(const ConvArgs a) {
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
     constexpr int A_IT = (BM + 63) / 64, B_IT = (BN + 63) / 64;      // 64 rows per staging pass (4 lanes per row)
     constexpr int NV = A_IT + B_IT;
     constexpr int ROWB = 32;
     constexpr int STAGE = (BM + BN) * NPL * ROWB;                     // bytes
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* const S0 = reinterpret_cast<char*>(smem);
+    const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+    char* const S0 = reinterpret_cast<char*>(smem) + grp * 2 * STAGE;
     char* const S1 = S0 + STAGE;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;          // thread within its K group
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
@@ -364,7 +369,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvArgs
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    int cc = 0, tap = 0;
+    // iterator over (tap, channel chunk), positioned at this group's first chunk q0 + grp
+    int cc = 0, tap = 0, pos = q0;
     unsigned long long rem_mask = tapmask;
     if (q0 < q1) {
         int skip = q0 / a.cchunks;
@@ -372,6 +378,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvArgs
         while (skip--) rem_mask &= rem_mask - 1;
         tap = __builtin_ctzll(rem_mask);
     }
+    auto advance = [&](int n) {                 // wave-uniform; only ever asked to step onto an existing chunk
+        for (int i = 0; i < n; ++i, ++pos)
+            if (++cc == a.cchunks) { cc = 0; rem_mask &= rem_mask - 1; tap = __builtin_ctzll(rem_mask); }
+    };
     unsigned a_off[A_IT];
     auto set_tap = [&](int t) {
         const int r = t / a.S, s = t - r * a.S;
@@ -405,12 +415,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvArgs
             for (int i = 0; i < B_IT; ++i) R[A_IT + i][hf] = buf_load4(wr, b_off[i] + woff);
         }
     };
-    int issued = q0;
+    int nextq = q0 + grp, tap_set = -1;         // next chunk of this group; tap whose a_off[] is current
     auto issue = [&](float4 (*R)[2]) {
-        if (issued >= q1) return;
-        if (issued > q0 && ++cc == a.cchunks) { cc = 0; rem_mask &= rem_mask - 1; tap = __builtin_ctzll(rem_mask); set_tap(tap); }
+        if (nextq >= q1) {
+            if (KG > 1) {                           // an exhausted group keeps iterating with the others: feed it zeros
+#pragma unroll
+                for (int v = 0; v < NV; ++v) R[v][0] = R[v][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
+        advance(nextq - pos);
+        if (tap != tap_set) { set_tap(tap); tap_set = tap; }
         gload(R, tap, cc);
-        ++issued;
+        nextq += KG;
     };
 
     // ---- LDS addressing (swizzle: 16-byte half h of row r lives at half h ^ bit3(r))
@@ -467,27 +484,55 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvArgs
         for (int c = (NMFMA + MPS - 1) / MPS; c < CSTEPS; ++c) cstep(nxt, R, hf, c);
     };
 
+    const int nloc = (q1 - q0 + KG - 1) / KG;   // pipeline iterations: the same for every group (barriers are block-wide)
     if (q0 < q1) {
-        set_tap(tap);
         issue(R0);
         issue(R1);
 #pragma unroll
         for (int c = 0; c < CSTEPS; ++c) cstep(S0, R0, 0, c);
         __syncthreads();
     }
-    for (int q = q0; q < q1; q += 2) {
-        pipe(S0, S1, R0, 1);            // MFMAs of chunk q / half 0, convert chunk q / half 1
-        issue(R0);                      // chunk q+2
+    for (int q = 0; q < nloc; q += 2) {
+        pipe(S0, S1, R0, 1);            // MFMAs of local chunk q / half 0, convert chunk q / half 1
+        issue(R0);                      // local chunk q+2
         __syncthreads();
-        pipe(S1, S0, R1, 0);            // MFMAs of chunk q / half 1, convert chunk q+1 / half 0 (stale registers past the end: unused)
+        pipe(S1, S0, R1, 0);            // MFMAs of chunk q / half 1, convert chunk q+1 / half 0 (past the end: stale for KG = 1 and unused, zeros for KG > 1)
         __syncthreads();
-        if (q + 1 < q1) {
+        if (q + 1 < nloc) {
             pipe(S0, S1, R1, 1);
-            issue(R1);                  // chunk q+3
+            issue(R1);                  // local chunk q+3
             __syncthreads();
             pipe(S1, S0, R0, 0);
             __syncthreads();
         }
+    }
+    if constexpr (KG > 1) {
+        // ---- sum the KG accumulator sets through LDS (the stages are free now), fixed order g = 1 .. KG-1; group 0 stores
+        float4* red = reinterpret_cast<float4*>(smem);
+        constexpr int NQ = MR * NR * 4;         // float4 per thread
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4)
+                        red[((grp - 1) * NQ + (i * NR + j) * 4 + e4) * 256 + tid] =
+                            make_float4(acc[i][j][4 * e4], acc[i][j][4 * e4 + 1], acc[i][j][4 * e4 + 2], acc[i][j][4 * e4 + 3]);
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 1; g < KG; ++g)
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const float4 v = red[((g - 1) * NQ + (i * NR + j) * 4 + e4) * 256 + tid];
+                        acc[i][j][4 * e4] += v.x; acc[i][j][4 * e4 + 1] += v.y; acc[i][j][4 * e4 + 2] += v.z; acc[i][j][4 * e4 + 3] += v.w;
+                    }
     }
 
     // ---- epilogue: D[row][col], col = lane&31 (out channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); bounds by the descriptor
@@ -1047,7 +1092,32 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
     const int npl = conv_planes(DGRAD ? PASS_DGRAD : PASS_FWD);
     const long long nblocks = (long long)grid.x * grid.y * grid.z;
     if (npl) {
-        const size_t lds2 = (size_t)2 * (bm + bn) * npl * 32;      // two stages of 32-byte rows: <= 60 KiB for every tile
+        const int kg = a.kg > 1 ? a.kg : 1;
+        const size_t stages = (size_t)2 * (bm + bn) * npl * 32;      // two stages of 32-byte rows per K group: <= 60 KiB for every tile
+        if (kg > 1) {
+            // K groups (64x64 tiles: 2 or 4 groups, 128x64 / 64x128: 2): block of 256*kg threads, LDS = kg stage pairs or the (kg-1)
+            // accumulator sets of the final reduction, whichever is larger (up to 96 KiB: opt-in attribute, set once per instantiation)
+            grid = dim3((unsigned)(a.mtiles * a.ntiles), 1u, 1u);
+            const size_t lds = std::max(stages * kg, (size_t)(kg - 1) * (bm / 32) * (bn / 32) / 4 * 16384);
+#define DSRL_LAUNCH_KG(a_, b_, c_, d_, NPL_, KG_)                                                                                     \
+            {                                                                                                                          \
+                static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_>, \
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);            \
+                (void)attr;                                                                                                            \
+                hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_>), grid, dim3(256 * KG_), lds, st, a);      \
+            }
+            if (cfg == T64x64) {
+                if (kg == 4) { if (npl == 2) DSRL_LAUNCH_KG(1, 1, 2, 2, 2, 4) else DSRL_LAUNCH_KG(1, 1, 2, 2, 3, 4) }
+                else { if (npl == 2) DSRL_LAUNCH_KG(1, 1, 2, 2, 2, 2) else DSRL_LAUNCH_KG(1, 1, 2, 2, 3, 2) }
+            } else if (cfg == T128x64) {
+                if (npl == 2) DSRL_LAUNCH_KG(2, 1, 2, 2, 2, 2) else DSRL_LAUNCH_KG(2, 1, 2, 2, 3, 2)
+            } else {
+                if (npl == 2) DSRL_LAUNCH_KG(1, 2, 2, 2, 2, 2) else DSRL_LAUNCH_KG(1, 2, 2, 2, 3, 2)
+            }
+#undef DSRL_LAUNCH_KG
+            return launch_status("conv_igemm_split_kernel<K groups>");
+        }
+        const size_t lds2 = stages;
 #define DSRL_LAUNCH_SPLIT(a_, b_, c_, d_)                                                                                    \
         if (npl == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2>), grid, dim3(256), lds2, st, a); \
         else hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 3>), grid, dim3(256), lds2, st, a);
@@ -1090,14 +1160,32 @@ static int check_conv(const void* p0, const void* p1, const void* p2, int N, int
 
 static long long span_bytes(long long pixels, int ld, int c) { return ((pixels - 1) * ld + c) * 4ll; }
 #define DSRL_REQUIRE_31(bytes, what) DSRL_REQUIRE((bytes) > 0 && (bytes) < (1ll << 31), DSRL_E_UNSUPPORTED, what ": tensor of %lld bytes exceeds the 2 GiB buffer-descriptor range", (long long)(bytes))
-struct FwdPlan { int Ho, Wo, M, cchunks, splits; TileCfg cfg; size_t ws; };
-static FwdPlan plan_fwd(int N, int Hin, int Win, int Cin, int Kout, int R, int S, int Ho, int Wo) {
+struct FwdPlan { int Ho, Wo, M, cchunks, splits, kg; TileCfg cfg; size_t ws; };
+// K groups per block for the split-precision kernels (measured on the M = 4096 backbone layers): when the grid has at most ~1.5 tiles
+// per CU a block runs 2 or 4 groups of 4 waves over interleaved chunks and sums them in LDS - no slabs, no reduce launch.
+static int pick_kg(long long tiles, int nq, TileCfg cfg, int npl) {
+    if (!npl) return 1;
+    const int forced = env_int("DSRL_FORCE_KG", 0);
+    const int maxkg = cfg == T64x64 ? 4 : ((cfg == T128x64 || cfg == T64x128) ? 2 : 1);
+    if (forced > 0) return std::min(forced >= 4 ? 4 : (forced >= 2 ? 2 : 1), maxkg);
+    if (tiles * 2 > 3 * kNumCU) return 1;
+    int kg = 1;
+    while (kg * 2 <= maxkg && nq >= 6 * kg * 2) kg *= 2;
+    return kg;
+}
+static FwdPlan plan_fwd(int N, int Hin, int Win, int Cin, int Kout, int R, int S, int Ho, int Wo, int npl) {
     FwdPlan p; p.Ho = Ho; p.Wo = Wo; p.M = N * Ho * Wo; p.cchunks = (int)ceil_div(Cin, BK);
     p.cfg = pick_cfg(p.M, Kout);
     int bm, bn; cfg_dims(p.cfg, bm, bn);
-    p.splits = pick_splits(ceil_div(p.M, bm) * ceil_div(Kout, bn), R * S * p.cchunks);
+    const long long tiles = ceil_div(p.M, bm) * ceil_div(Kout, bn);
+    p.kg = pick_kg(tiles, R * S * p.cchunks, p.cfg, npl);
+    p.splits = p.kg > 1 ? 1 : pick_splits(tiles, R * S * p.cchunks);
     p.ws = p.splits > 1 ? (size_t)p.splits * p.M * Kout * sizeof(float) : 0;
     return p;
+}
+// workspace queries do not know which arithmetic the launch will run in: the larger of the two plans
+static size_t plan_fwd_ws(int N, int Hin, int Win, int Cin, int Kout, int R, int S, int Ho, int Wo) {
+    return std::max(plan_fwd(N, Hin, Win, Cin, Kout, R, S, Ho, Wo, 0).ws, plan_fwd(N, Hin, Win, Cin, Kout, R, S, Ho, Wo, 3).ws);
 }
 
 }  // namespace dsrl
@@ -1116,7 +1204,7 @@ extern "C" int64_t dsrl_conv2d_inbounds_macs(int N, int H, int W, int C, int K, 
 extern "C" size_t dsrl_conv2d_fwd_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
     const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
     if (Ho <= 0 || Wo <= 0) return 0;
-    return plan_fwd(N, H, W, C, K, R, S, Ho, Wo).ws;
+    return plan_fwd_ws(N, H, W, C, K, R, S, Ho, Wo);
 }
 
 extern "C" int dsrl_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
@@ -1129,11 +1217,11 @@ extern "C" int dsrl_conv2d_fwd(const float* x, int ldx, const float* w, const fl
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
     const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
-    const FwdPlan p = plan_fwd(N, H, W, C, K, R, S, Ho, Wo);
+    const FwdPlan p = plan_fwd(N, H, W, C, K, R, S, Ho, Wo, conv_planes(PASS_FWD));
     DSRL_REQUIRE(ws_bytes >= p.ws && (p.ws == 0 || ws), DSRL_E_WORKSPACE, "conv2d_fwd: workspace %zu < %zu", ws_bytes, p.ws);
     ConvArgs a{};
     a.x = x; a.w = w; a.ldx = ldx; a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = Ho; a.Wo = Wo;
-    a.stride = stride; a.pad = pad; a.dil = dil; a.M = p.M; a.cchunks = p.cchunks; a.splits = p.splits; a.slab = (long long)p.M * K;
+    a.stride = stride; a.pad = pad; a.dil = dil; a.M = p.M; a.cchunks = p.cchunks; a.splits = p.splits; a.kg = p.kg; a.slab = (long long)p.M * K;
     const long long xb = span_bytes((long long)N * H * W, ldx, C), wb = (long long)K * R * S * C * 4, yb = p.splits > 1 ? (long long)p.M * K * 4 : span_bytes(p.M, ldy, K);
     DSRL_REQUIRE_31(xb, "conv2d_fwd(x)"); DSRL_REQUIRE_31(wb, "conv2d_fwd(w)"); DSRL_REQUIRE_31(yb, "conv2d_fwd(y)");
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
@@ -1158,7 +1246,7 @@ static size_t dgrad_wt_bytes(int C, int K, int R, int S) { return align_up((size
 extern "C" size_t dsrl_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
     const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
     if (Ho <= 0 || Wo <= 0) return 0;
-    return dgrad_wt_bytes(C, K, R, S) + plan_fwd(N, Ho, Wo, pad4(K), C, R, S, H, W).ws;
+    return dgrad_wt_bytes(C, K, R, S) + plan_fwd_ws(N, Ho, Wo, pad4(K), C, R, S, H, W);
 }
 
 extern "C" size_t dsrl_conv2d_transposed_filter_floats(int C, int K, int R, int S) { return (size_t)C * R * S * pad4(K); }
@@ -1182,7 +1270,7 @@ extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, cons
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
     const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
-    const FwdPlan p = plan_fwd(N, Ho, Wo, Kp, C, R, S, H, W);
+    const FwdPlan p = plan_fwd(N, Ho, Wo, Kp, C, R, S, H, W, conv_planes(PASS_DGRAD));
     const size_t wtb = dgrad_wt_bytes(C, K, R, S);
     DSRL_REQUIRE(ws && ws_bytes >= wtb + p.ws, DSRL_E_WORKSPACE, "conv2d_dgrad: workspace %zu < %zu", ws_bytes, wtb + p.ws);
     const float* wt = wt_in;
@@ -1195,7 +1283,7 @@ extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, cons
     }
     ConvArgs a{};
     a.x = dy; a.w = wt; a.ldx = lddy; a.N = N; a.H = Ho; a.W = Wo; a.C = Kp; a.K = C; a.R = R; a.S = S; a.Ho = H; a.Wo = W;
-    a.stride = stride; a.pad = pad; a.dil = dil; a.M = p.M; a.cchunks = p.cchunks; a.splits = p.splits; a.slab = (long long)p.M * C;
+    a.stride = stride; a.pad = pad; a.dil = dil; a.M = p.M; a.cchunks = p.cchunks; a.splits = p.splits; a.kg = p.kg; a.slab = (long long)p.M * C;
     {
         const long long xb = span_bytes((long long)N * Ho * Wo, lddy, Kp), wb = (long long)C * R * S * Kp * 4, yb = p.splits > 1 ? (long long)p.M * C * 4 : span_bytes(p.M, lddx, C);
         DSRL_REQUIRE_31(xb, "conv2d_dgrad(dy)"); DSRL_REQUIRE_31(wb, "conv2d_dgrad(w)"); DSRL_REQUIRE_31(yb, "conv2d_dgrad(dx)");
@@ -1320,7 +1408,7 @@ static int check_rowfold(const void* a, const void* b, const void* c, int ldx, i
 }
 extern "C" size_t dsrl_conv2d_rowfold_fwd_workspace_bytes(int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo) {
     (void)stride;
-    return plan_fwd(N, H, W, Cfold, K, R, 1, Ho, Wo).ws;
+    return plan_fwd_ws(N, H, W, Cfold, K, R, 1, Ho, Wo);
 }
 extern "C" int dsrl_conv2d_rowfold_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                                        int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo, int64_t algorithmic_macs,
@@ -1329,11 +1417,11 @@ extern "C" int dsrl_conv2d_rowfold_fwd(const float* x, int ldx, const float* w, 
     DSRL_REQUIRE(ldy >= K && ((uintptr_t)w % 16) == 0, DSRL_E_BADARG, "conv2d_rowfold_fwd: bad ldy / unaligned filter");
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
-    const FwdPlan p = plan_fwd(N, H, W, Cfold, K, R, 1, Ho, Wo);
+    const FwdPlan p = plan_fwd(N, H, W, Cfold, K, R, 1, Ho, Wo, conv_planes(PASS_FWD));
     DSRL_REQUIRE(ws_bytes >= p.ws && (p.ws == 0 || ws), DSRL_E_WORKSPACE, "conv2d_rowfold_fwd: workspace %zu < %zu", ws_bytes, p.ws);
     ConvArgs a{};
     a.x = x; a.w = w; a.ldx = ldx; a.N = N; a.H = H; a.W = W; a.C = Cfold; a.K = K; a.R = R; a.S = 1; a.Ho = Ho; a.Wo = Wo;
-    a.stride = stride; a.pad = 0; a.dil = 1; a.M = p.M; a.cchunks = p.cchunks; a.splits = p.splits; a.slab = (long long)p.M * K;
+    a.stride = stride; a.pad = 0; a.dil = 1; a.M = p.M; a.cchunks = p.cchunks; a.splits = p.splits; a.kg = p.kg; a.slab = (long long)p.M * K;
     {
         const long long xb = (long long)N * H * W * ldx * 4, wb = (long long)K * R * Cfold * 4, yb = p.splits > 1 ? (long long)p.M * K * 4 : span_bytes(p.M, ldy, K);
         DSRL_REQUIRE_31(xb, "conv2d_rowfold_fwd(x)"); DSRL_REQUIRE_31(wb, "conv2d_rowfold_fwd(w)"); DSRL_REQUIRE_31(yb, "conv2d_rowfold_fwd(y)");
