@@ -90,6 +90,7 @@ class TrainStep:
         if do_train:
             flat.zero_grad()                                                               # optimizer.zero_grad(), :418
             flat.sync_buffers()
+            flat.refresh_transposed_filters()     # one launch: the [C][R][S][K] filter copies every dgrad of this step reads
         self.flag.zero_()
         with t.set_grad_enabled(do_train):
             outs = self.model(input_image)                                                 # :420

@@ -586,6 +586,36 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// The same for every conv filter of the model in ONE launch: table[i] = {w, wt, K, Kp, RS, C, first tile, tiles along C} as int64;
+// blockIdx.x = global 32x32 tile index, located in the table by bisection on the first-tile column.
+__global__ void weight_transpose_batched_kernel(const long long* __restrict__ table, int n) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n - 1;
+    const long long b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 8 + 6] <= b) lo = mid; else hi = mid - 1;
+    }
+    const long long* e = table + lo * 8;
+    const float* w = reinterpret_cast<const float*>(e[0]);
+    float* wt = reinterpret_cast<float*>(e[1]);
+    const int K = (int)e[2], Kp = (int)e[3], RS = (int)e[4], C = (int)e[5], ct = (int)e[7];
+    const int kt = (Kp + 31) / 32;
+    int t = (int)(b - e[6]);
+    const int tap = t / (ct * kt); t -= tap * ct * kt;
+    const int k0 = (t / ct) * 32, c0 = (t % ct) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, c = c0 + tx;
+        tile[r][tx] = (k < K && c < C) ? w[((long long)k * RS + tap) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, k = k0 + tx;
+        if (c < C && k < Kp) wt[((long long)c * RS + tap) * Kp + k] = tile[tx][r];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ wgrad
 struct WgradArgs {
     const float* x; const float* dy; float* dw;     // dw or slabs
@@ -1257,6 +1287,14 @@ extern "C" int dsrl_conv2d_transpose_filter(const float* w, float* wt, int C, in
     const int Kp = pad4(K);
     hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)ceil_div(C, 32), (unsigned)ceil_div(Kp, 32), (unsigned)(R * S)), dim3(256), 0, st, w, wt, K, Kp, R * S, C);
     return launch_status("weight_transpose_kernel");
+}
+
+extern "C" int dsrl_conv2d_transpose_filters_batched(const int64_t* table, int n, int64_t total_tiles, dsrl_stream_t stream) {
+    DSRL_REQUIRE(table && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31), DSRL_E_BADARG, "conv2d_transpose_filters_batched: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, (const long long*)table, n);
+    return launch_status("weight_transpose_batched_kernel");
 }
 
 extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,

@@ -15,6 +15,8 @@ Replaces what the reference gets from `torch.nn.parallel.DistributedDataParallel
 One process per GPU; `torch.distributed` backend 'nccl' is RCCL on ROCm.  With world size 1 (or no process group) the
 collectives are skipped and only the arena + fused optimiser remain.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -88,6 +90,7 @@ class FlatParams:
         self._claimed = set()
         for p in self.params:
             p._dsrl_arena = self
+        self._build_transposed_filters()
         if self.world > 1:
             dist.broadcast(self.p_flat, 0, group=self.pg)          # DDP constructor semantics: rank 0's weights win
             dist.broadcast(self.b_flat, 0, group=self.pg)
@@ -124,6 +127,44 @@ class FlatParams:
                 HF.join_side_streams()      # the chunk may hold weight gradients produced on the side stream
             self._works.append(dist.all_reduce(self.g_flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
+    # ------------------------------------------------------------------ transposed conv filters for the data-gradient kernels
+    def _build_transposed_filters(self):
+        """One arena with the [C][R][S][K padded to 4] transpose of every conv filter the dgrad kernel reads, refreshed by ONE
+        launch per training step (dsrl_conv2d_transpose_filters_batched) instead of one launch inside every dgrad call."""
+        from .nn_modules import HipConv2d
+        self.wt_valid, self._wt_table, self._wt_tiles = False, None, 0
+        if self.device.type != 'cuda':
+            return
+        mine = {id(p) for p in self.params}
+        entries, floats = [], 0
+        for m in self.model.modules():
+            if not isinstance(m, HipConv2d):
+                continue
+            w = m.weight
+            K, C, R, S = w.shape
+            if id(w) not in mine or C % 4 != 0 or not HF._is_krsc(w):
+                continue            # the RGB stem (C = 3) and the C -> 1 feature transformers never run the implicit-GEMM dgrad
+            Kp = (K + 3) & ~3
+            entries.append((w, K, Kp, R * S, C, floats))
+            floats += _align(C * R * S * Kp)
+        if not entries:
+            return
+        self.wt_flat = torch.empty(floats, device=self.device, dtype=torch.float32)
+        rows, tiles = [], 0
+        for w, K, Kp, RS, C, off in entries:
+            wt = self.wt_flat[off:off + C * RS * Kp]
+            w._dsrl_wt = wt
+            ct = (C + 31) // 32
+            rows.append([w.data_ptr(), wt.data_ptr(), K, Kp, RS, C, tiles, ct])
+            tiles += RS * ct * ((Kp + 31) // 32)
+        self._wt_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        self._wt_rows, self._wt_tiles = len(rows), tiles
+
+    def refresh_transposed_filters(self):
+        if self._wt_table is not None and os.environ.get('DSRL_BATCHED_TRANSPOSE', '1') != '0':
+            HF.call('dsrl_conv2d_transpose_filters_batched', self._wt_table.data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
+            self.wt_valid = True
+
     def zero_grad(self):
         self.g_flat.zero_()
         self._claimed.clear()
@@ -155,6 +196,7 @@ class FlatParams:
         """torch.optim.SGD(momentum, weight_decay).step() on the whole arena; gradients are averaged over ranks here."""
         self.finish_reduction()
         HF.sgd_step_(self.p_flat, self.g_flat, self.m_flat, lr, momentum, weight_decay, 1.0 / self.world)
+        self.wt_valid = False               # the filters changed: the transposed copies are stale until the next refresh
 
     def state_dict(self):
         return {'momentum_arena': self.m_flat.clone(), 'numel': self.numel}

@@ -297,6 +297,11 @@ class _Conv2d(torch.autograd.Function):
                 torch.cuda.current_stream().wait_event(ev)
                 wt.record_stream(torch.cuda.current_stream())
                 wt_ptr = wt.data_ptr()
+            elif ctx.wparam is not None:
+                # ddp.FlatParams keeps a transposed copy of every filter, refreshed by one batched launch per training step
+                arena, wt = getattr(ctx.wparam, '_dsrl_arena', None), getattr(ctx.wparam, '_dsrl_wt', None)
+                if wt is not None and arena is not None and arena.wt_valid:
+                    wt_ptr = wt.data_ptr()
             call('dsrl_conv2d_dgrad', dy.data_ptr(), lddy, w.data_ptr(), wt_ptr, dx.data_ptr(), Cc, *shp, ws.data_ptr(), ws.numel(), st)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             P = dy.shape[0] * dy.shape[2] * dy.shape[3]

@@ -55,6 +55,10 @@ int dsrl_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias /
  * dsrl_conv2d_transpose_filter (e.g. built during the forward pass on another stream) or NULL to have it built here in `ws`. */
 size_t dsrl_conv2d_transposed_filter_floats(int C, int K, int R, int S);
 int dsrl_conv2d_transpose_filter(const float* w, float* wt, int C, int K, int R, int S, dsrl_stream_t stream);
+/* The same for n filters in one launch (once per training step instead of once per layer): table is a DEVICE array of n rows of eight
+ * int64 {w pointer, wt pointer, K, Kp = K rounded up to 4, R*S, C, index of the row's first 32x32 tile, ceil(C/32)}, rows ordered by
+ * first tile; total_tiles = sum over rows of R*S * ceil(C/32) * ceil(Kp/32). */
+int dsrl_conv2d_transpose_filters_batched(const int64_t* table, int n, int64_t total_tiles, dsrl_stream_t stream);
 size_t dsrl_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, const float* wt /*nullable*/, float* dx, int lddx,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

@@ -510,6 +510,34 @@ def test_gradient_sink_matches_autograd_accumulation():
     assert not bad, bad
 
 
+def test_batched_filter_transposes_match_per_layer_path():
+    """ddp.FlatParams.refresh_transposed_filters (one dsrl_conv2d_transpose_filters_batched launch for every conv filter of the
+    model) feeds the dgrad kernels the same transposed filters as the per-call transpose: bit-identical gradients; the copies
+    are marked stale by the SGD update."""
+    from dualsuperreslearningforsemseg_amd.ddp import FlatParams
+    x16, x4, target, org = gen.make_head_inputs(202, 2, 2, 4, gen.SMALL)
+    grads = []
+    for batched in (False, True):
+        head, _ = make_head(gen.SMALL, 3, 101, True)
+        flat = FlatParams(head)
+        assert flat._wt_rows >= 10 and not flat.wt_valid
+        flat.zero_grad()
+        if batched:
+            flat.refresh_transposed_filters()
+            assert flat.wt_valid
+        a = dev(x16).requires_grad_(True); b = dev(x4).requires_grad_(True)
+        outs = head(a, b)
+        hip_losses(outs, dev(target), dev(org), 3)[3].backward()
+        flat.finish_reduction()
+        g = {k: host(p.grad) for k, p in head.named_parameters()}
+        g['x16'], g['x4'] = host(a.grad), host(b.grad)
+        grads.append(g)
+        flat.sgd_step(0.01, 0.9, 5e-4)
+        assert not flat.wt_valid
+    bad = {k: float(np.abs(grads[0][k] - grads[1][k]).max()) for k in grads[0] if not np.array_equal(grads[0][k], grads[1][k])}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize('mode', ['mixed', 'bf16x6'])
 def test_full_model_vs_oracle(mode):
     """Whole DSRL (ResNet-101 OS16 backbone + head) at 32x64, B=2, train-mode BN, dropout off: every kernel family in one graph
