@@ -43,6 +43,7 @@ struct ConvArgs {
     unsigned x_bytes, w_bytes, y_bytes;   // extents of the three buffers (< 2^31): buffer loads/stores bounds-check against them
     int mtiles, ntiles, xcd_remap;        // 1-D launch of mtiles*ntiles blocks (x splits in z); XCD-aware tile order when xcd_remap
     int kg;                               // split kernels: K groups per block (1, 2 or 4)
+    int accumulate;                       // epilogue: y += result (only without slabs: a split-K launch accumulates in its reduce)
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (private L2 each). Remap the linear block id so that every XCD works on a contiguous
@@ -271,7 +272,9 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
             for (int e = 0; e < 16; ++e) {
                 const int m = mb + (e & 3) + 8 * (e >> 2);
                 const unsigned off = (kok && m < a.M) ? ((unsigned)m * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e] + bv), yr, (int)off, 0, 0);
+                float v = acc[i][j][e] + bv;
+                if (a.accumulate && a.splits == 1) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, (int)off, 0, 0));     // out-of-bounds offsets read 0
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)off, 0, 0);
             }
         }
     }
@@ -551,7 +554,9 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
             for (int e = 0; e < 16; ++e) {
                 const int m = mb + (e & 3) + 8 * (e >> 2);
                 const unsigned off = (kok && m < a.M) ? ((unsigned)m * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e] + bv), yr, (int)off, 0, 0);
+                float v = acc[i][j][e] + bv;
+                if (a.accumulate && a.splits == 1) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, (int)off, 0, 0));     // out-of-bounds offsets read 0
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)off, 0, 0);
             }
         }
     }
@@ -559,13 +564,15 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
 
 // y[m*ldy + k] = sum_z slab[z][m][k] + bias[k]
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long slab, int M, int K,
-                                     const float* __restrict__ bias, float* __restrict__ y, int ldy) {
+                                     const float* __restrict__ bias, float* __restrict__ y, int ldy, int accumulate = 0) {
     const long long total = (long long)M * K;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int zz = 0; zz < splits; ++zz) s += slabs[zz * slab + e];
         const int m = (int)(e / K), k = (int)(e - (long long)m * K);
-        y[(long long)m * ldy + k] = s + (bias ? bias[k] : 0.f);
+        float* o = y + (long long)m * ldy + k;
+        const float v = s + (bias ? bias[k] : 0.f);
+        *o = accumulate ? v + *o : v;
     }
 }
 
@@ -1297,9 +1304,9 @@ extern "C" int dsrl_conv2d_transpose_filters_batched(const int64_t* table, int n
     return launch_status("weight_transpose_batched_kernel");
 }
 
-extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
-                                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                                 void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
+                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                      void* ws, size_t ws_bytes, dsrl_stream_t stream, int accumulate) {
     if (int e = check_conv(dy, w, dx, N, H, W, C, K, R, S, stride, pad, dil)) return e;
     const int Kp = pad4(K);     // K % 4 != 0 (cls_conv, 19 classes): dy must be padded to lddy >= Kp with finite pad values
     DSRL_REQUIRE(lddy % 4 == 0 && ((uintptr_t)dy % 16) == 0, DSRL_E_UNSUPPORTED,
@@ -1333,11 +1340,22 @@ extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, cons
         if (int e = launch_igemm<true>(a, p.cfg, st)) return e;
         const long long total = (long long)p.M * C;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st,
-                           (const float*)slabs, p.splits, a.slab, p.M, C, (const float*)nullptr, dx, lddx);
+                           (const float*)slabs, p.splits, a.slab, p.M, C, (const float*)nullptr, dx, lddx, accumulate);
         return launch_status("splitk_reduce_kernel");
     }
-    a.y = dx; a.ldy = lddx; a.bias = nullptr;
+    a.y = dx; a.ldy = lddx; a.bias = nullptr; a.accumulate = accumulate;
     return launch_igemm<true>(a, p.cfg, st);
+}
+
+extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
+                                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                 void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, 0);
+}
+extern "C" int dsrl_conv2d_dgrad_accumulate(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
+                                            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                            void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, 1);
 }
 
 static void make_magic(int d, unsigned& m, unsigned& sh) {

@@ -225,10 +225,42 @@ def current_seed():
     return _rng_state['current']
 
 
+# ------------------------------------------------------------------------------------------------ shared gradient buffers
+# A tensor that feeds two branches (the input of a ResNet bottleneck: conv1 and the residual add / the downsample conv) receives two
+# gradient contributions that autograd would sum with an extra elementwise kernel.  With a GradSlot the first contribution's buffer
+# is published and the later data-gradient kernel accumulates into it in its epilogue (dsrl_conv2d_dgrad_accumulate) and reports
+# no gradient of its own.  Only sound when EVERY consumer of the tensor takes part, hence fork(): an alias node whose output is
+# consumed inside the block only; other users of the original tensor see one ordinary gradient.  Any case the protocol does not
+# cover falls back to returning a separate gradient (closed slot), which autograd sums as usual.
+grad_slots_enabled = os.environ.get('DSRL_GRAD_SLOTS', '1') != '0'
+
+
+class GradSlot:
+    __slots__ = ('buf', 'closed')
+
+    def __init__(self):
+        self.buf, self.closed = None, False
+
+
+class _Fork(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def fork(x):
+    return _Fork.apply(x)
+
+
 # ------------------------------------------------------------------------------------------------ conv2d
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil):
+    def forward(ctx, x, w, bias, stride, pad, dil, gslot=None):
+        ctx.gslot = gslot
         x, ldx = pm_vec4(x)
         w_param = w
         w = w_cl(w)
@@ -289,7 +321,10 @@ class _Conv2d(torch.autograd.Function):
                     ctx.wparam._dsrl_arena.written(ctx.wparam)
                     dw = None
         if ctx.needs_input_grad[0]:
-            dx = new_cl((N, Cc, H, W), x)
+            slot = ctx.gslot
+            acc = (slot is not None and not slot.closed and slot.buf is not None and tuple(slot.buf.shape) == (N, Cc, H, W)
+                   and slot.buf.is_contiguous(memory_format=CL))
+            dx = slot.buf if acc else new_cl((N, Cc, H, W), x)
             ws = _ws(cquery('dsrl_conv2d_dgrad_workspace_bytes', *shp), x)
             wt_ptr = None
             if ctx.wt is not None:
@@ -302,13 +337,21 @@ class _Conv2d(torch.autograd.Function):
                 arena, wt = getattr(ctx.wparam, '_dsrl_arena', None), getattr(ctx.wparam, '_dsrl_wt', None)
                 if wt is not None and arena is not None and arena.wt_valid:
                     wt_ptr = wt.data_ptr()
-            call('dsrl_conv2d_dgrad', dy.data_ptr(), lddy, w.data_ptr(), wt_ptr, dx.data_ptr(), Cc, *shp, ws.data_ptr(), ws.numel(), st)
+            call('dsrl_conv2d_dgrad_accumulate' if acc else 'dsrl_conv2d_dgrad', dy.data_ptr(), lddy, w.data_ptr(), wt_ptr, dx.data_ptr(), Cc, *shp,
+                 ws.data_ptr(), ws.numel(), st)
+            if acc:
+                dx = None                   # the contribution went into the buffer autograd already holds for this input
+            elif slot is not None:
+                if slot.buf is None:
+                    slot.buf = dx
+                else:
+                    slot.closed = True      # a separate gradient is on its way to autograd: nobody may touch the published buffer any more
         if ctx.has_bias and ctx.needs_input_grad[2]:
             P = dy.shape[0] * dy.shape[2] * dy.shape[3]
             db = torch.empty(K, device=x.device, dtype=torch.float32)
             ws = _ws(cquery('dsrl_colsum_workspace_bytes', P, K), x)
             call('dsrl_colsum', dy.data_ptr(), lddy, P, K, db.data_ptr(), ws.data_ptr(), ws.numel(), st)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class _StemConv(torch.autograd.Function):
@@ -356,21 +399,23 @@ class _StemConv(torch.autograd.Function):
         return None, dw, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, grad_slot=None):
     """nn.Conv2d arithmetic (square stride/padding/dilation) on the MFMA implicit-GEMM kernels."""
     if x.shape[1] < 4 and bias is None and dilation == 1 and not x.requires_grad:
         return _StemConv.apply(x, weight, int(stride), int(padding))
     if x.shape[1] % 4 != 0:
+        grad_slot = None
         padc = 4 - x.shape[1] % 4           # generic fallback: pad input and filter channels to a multiple of 4 (zeros contribute nothing)
         x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, padc))
         weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, padc))
-    return _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation))
+    return _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation), grad_slot)
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm (+res, relu, dropout)
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, drop_p, seed, rng_stream, residual):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, drop_p, seed, rng_stream, residual, rslot=None):
+        ctx.rslot = rslot
         x, ldx = pm(x)
         _need_gpu(gamma, beta, running_mean, running_var)
         N, Cc, H, W = x.shape
@@ -426,17 +471,22 @@ class _BNAct(torch.autograd.Function):
             ctx.gb[0]._dsrl_arena.written(ctx.gb[0]); dgamma = None
         if sb is not None:
             ctx.gb[1]._dsrl_arena.written(ctx.gb[1]); dbeta = None
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, dres
+        if dres is not None and ctx.rslot is not None:
+            if ctx.rslot.buf is None:
+                ctx.rslot.buf = dres            # published: a later dgrad of the same input accumulates into it (GradSlot)
+            else:
+                ctx.rslot.closed = True
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, dres, None
 
 
-def batch_norm_act(x, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual=None):
+def batch_norm_act(x, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual=None, residual_grad_slot=None):
     """BatchNorm2d `bn` (an nn.BatchNorm2d holding the parameters/buffers) + optional residual add, ReLU, Dropout."""
     training = bn.training or bn.running_mean is None
     if training and bn.running_mean is not None:
         bn._dsrl_batches = getattr(bn, '_dsrl_batches', 0) + 1      # flushed into num_batches_tracked by HipBatchNorm2d.state_dict
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, relu,
-                        drop_p if training or drop_p == 0.0 else 0.0, seed, rng_stream, residual)
+                        drop_p if training or drop_p == 0.0 else 0.0, seed, rng_stream, residual, residual_grad_slot if residual is not None else None)
 
 
 class _Dropout(torch.autograd.Function):

@@ -31,10 +31,23 @@ class Bottleneck(t.nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = HF.batch_norm_act(self.conv1(x), self.bn1, relu=True)
+        # the block input feeds conv1 and the residual branch: both gradient contributions land in one buffer (HF.GradSlot) instead of
+        # being summed by a separate elementwise kernel; fork() isolates the pair from any other user of x
+        slot = None
+        if HF.grad_slots_enabled and x.requires_grad and t.is_grad_enabled():
+            x, slot = HF.fork(x), HF.GradSlot()
+        if self.downsample is None:
+            identity = x
+        elif slot is not None and len(self.downsample) == 2 and isinstance(self.downsample[0], HipConv2d) and self.downsample[0].bias is None:
+            ds = self.downsample[0]
+            identity = HF.batch_norm_act(HF.conv2d(x, ds.weight, None, ds.stride[0], ds.padding[0], ds.dilation[0], grad_slot=slot), self.downsample[1])
+        else:
+            identity = self.downsample(x)
+        c1 = self.conv1
+        out = HF.batch_norm_act(HF.conv2d(x, c1.weight, None, c1.stride[0], c1.padding[0], c1.dilation[0], grad_slot=slot), self.bn1, relu=True)
         out = HF.batch_norm_act(self.conv2(out), self.bn2, relu=True)
-        return HF.batch_norm_act(self.conv3(out), self.bn3, relu=True, residual=identity)      # bn3 + identity, then ReLU
+        return HF.batch_norm_act(self.conv3(out), self.bn3, relu=True, residual=identity,              # bn3 + identity, then ReLU
+                                 residual_grad_slot=slot if self.downsample is None else None)
 
 
 class ResNet101(t.nn.Module):

@@ -63,6 +63,11 @@ size_t dsrl_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int 
 int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, const float* wt /*nullable*/, float* dx, int lddx,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                       void* ws, size_t ws_bytes, dsrl_stream_t stream);
+/* dx += dgrad(dy, w): the same computation accumulated onto the existing contents of dx (a tensor that feeds two branches receives
+ * both gradient contributions in one buffer, e.g. the input of a ResNet bottleneck: ResNet101.py residual add + conv1). */
+int dsrl_conv2d_dgrad_accumulate(const float* dy, int lddy, const float* w, const float* wt /*nullable*/, float* dx, int lddx,
+                                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                 void* ws, size_t ws_bytes, dsrl_stream_t stream);
 /* dw [K][R][S][C] from x and dy */
 size_t dsrl_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,

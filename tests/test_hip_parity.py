@@ -538,6 +538,38 @@ def test_batched_filter_transposes_match_per_layer_path():
     assert not bad, bad
 
 
+def test_grad_slots_match_autograd_accumulation():
+    """Bottleneck inputs: the residual-branch gradient and conv1's (or the downsample conv's) data gradient accumulated in one buffer
+    by the dgrad epilogue (functional.GradSlot, dsrl_conv2d_dgrad_accumulate) equal autograd's separate sum, bit for bit (a + b is
+    commutative), on the whole backbone + head; and the step really drops the elementwise adds."""
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((2, 3, 32, 64)).astype(np.float32)
+    tg = rs.randint(0, 19, (2, 64, 128)).astype(np.uint8)
+    org = rs.standard_normal((2, 3, 64, 128)).astype(np.float32)
+    grads, logits = [], []
+    old = HF.grad_slots_enabled
+    try:
+        for enabled in (False, True):
+            HF.grad_slots_enabled = enabled
+            torch.manual_seed(3)
+            model = D.DSRL(3, cs).to(DEV).to(memory_format=torch.channels_last).train()
+            for m in model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.eval()
+            outs = model(dev(x, cl=False))
+            L = hip_losses(outs, dev(tg), dev(org), 3)
+            (L[0] + L[1]).backward()
+            torch.cuda.synchronize()
+            grads.append({k: host(p.grad) for k, p in model.named_parameters() if p.grad is not None})
+            logits.append(host(outs[0]))
+    finally:
+        HF.grad_slots_enabled = old
+    assert np.array_equal(logits[0], logits[1])
+    bad = {k: float(np.abs(grads[0][k] - grads[1][k]).max()) for k in grads[0] if not np.array_equal(grads[0][k], grads[1][k])}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize('mode', ['mixed', 'bf16x6'])
 def test_full_model_vs_oracle(mode):
     """Whole DSRL (ResNet-101 OS16 backbone + head) at 32x64, B=2, train-mode BN, dropout off: every kernel family in one graph
