@@ -268,13 +268,22 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
             const int mb = m0 + (wm * MR + i) * 32 + rq;
+            if (a.accumulate && a.splits == 1) {        // y += result: all 16 old values of the tile are fetched before the first store
+                float old[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + (e & 3) + 8 * (e >> 2);
+                    const unsigned off = (kok && m < a.M) ? ((unsigned)m * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
+                    old[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, (int)off, 0, 0));     // out-of-bounds offsets read 0
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += old[e];
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = mb + (e & 3) + 8 * (e >> 2);
                 const unsigned off = (kok && m < a.M) ? ((unsigned)m * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
-                float v = acc[i][j][e] + bv;
-                if (a.accumulate && a.splits == 1) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, (int)off, 0, 0));     // out-of-bounds offsets read 0
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e] + bv), yr, (int)off, 0, 0);
             }
         }
     }
@@ -550,13 +559,22 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
             const int mb = m0 + (wm * MR + i) * 32 + rq;
+            if (a.accumulate && a.splits == 1) {        // y += result: all 16 old values of the tile are fetched before the first store
+                float old[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + (e & 3) + 8 * (e >> 2);
+                    const unsigned off = (kok && m < a.M) ? ((unsigned)m * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
+                    old[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, (int)off, 0, 0));     // out-of-bounds offsets read 0
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += old[e];
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = mb + (e & 3) + 8 * (e >> 2);
                 const unsigned off = (kok && m < a.M) ? ((unsigned)m * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
-                float v = acc[i][j][e] + bv;
-                if (a.accumulate && a.splits == 1) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, (int)off, 0, 0));     // out-of-bounds offsets read 0
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, (int)off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e] + bv), yr, (int)off, 0, 0);
             }
         }
     }
