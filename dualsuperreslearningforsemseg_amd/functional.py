@@ -401,10 +401,12 @@ class _StemConv(torch.autograd.Function):
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, grad_slot=None):
     """nn.Conv2d arithmetic (square stride/padding/dilation) on the MFMA implicit-GEMM kernels."""
+    if grad_slot is not None and x.shape[1] % 4 != 0:
+        grad_slot.closed = True             # the padded-channel fallback reports its own gradient: the shared buffer must not be used
+        grad_slot = None
     if x.shape[1] < 4 and bias is None and dilation == 1 and not x.requires_grad:
         return _StemConv.apply(x, weight, int(stride), int(padding))
     if x.shape[1] % 4 != 0:
-        grad_slot = None
         padc = 4 - x.shape[1] % 4           # generic fallback: pad input and filter channels to a multiple of 4 (zeros contribute nothing)
         x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, padc))
         weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, padc))

@@ -96,7 +96,12 @@ class DSRL(BaseModel):
         aspp_features = HF.upsample_bilinear_ac(aspp_features, (4 * h, 4 * w))                 # DSRL.py:163
         lowlevel_features = fe['shortcut_conv'](lowlevel_features)                            # DSRL.py:164
         cat_features = HF.cat_channels([aspp_features, lowlevel_features])                    # DSRL.py:165
-        SSSR_output = self.SSSR_decoder['cat_conv'](cat_features)                             # DSRL.py:168
+        # cat_features feeds cat_conv.0 and (stage > 1) the SISR conv: both data gradients accumulate in one buffer (HF.GradSlot)
+        slot = None
+        if (HF.grad_slots_enabled and self.stage > 1 and cat_features.requires_grad and t.is_grad_enabled()
+                and isinstance(self.SSSR_decoder['cat_conv'], HipSequential) and isinstance(self.SISR_decoder, HipSequential)):
+            cat_features, slot = HF.fork(cat_features), HF.GradSlot()
+        SSSR_output = self.SSSR_decoder['cat_conv'](cat_features, grad_slot=slot) if slot is not None else self.SSSR_decoder['cat_conv'](cat_features)   # DSRL.py:168
         SSSR_output = self.SSSR_decoder['cls_conv'](SSSR_output)                              # DSRL.py:169
         SSSR_output = self.SSSR_decoder['upsample16_pred'](SSSR_output)                       # DSRL.py:170
         # DSRL.py:172-174: unused outputs are CPU zeros(1) whatever the model device
@@ -104,7 +109,7 @@ class DSRL(BaseModel):
         SSSR_transform_output = t.zeros(1, requires_grad=False)
         SISR_transform_output = t.zeros(1, requires_grad=False)
         if self.stage > 1:
-            SISR_output = self.SISR_decoder(cat_features)                                     # DSRL.py:177
+            SISR_output = self.SISR_decoder(cat_features, grad_slot=slot) if slot is not None else self.SISR_decoder(cat_features)   # DSRL.py:177
             if self.stage > 2:
                 SSSR_transform_output = self.SSSR_feature_transformer(SSSR_output)            # DSRL.py:181
                 SISR_transform_output = self.SISR_feature_transformer(SISR_output)            # DSRL.py:184

@@ -19,13 +19,16 @@ def _single(v):
 
 
 class HipConv2d(nn.Conv2d):
-    def forward(self, x):
+    def forward(self, x, grad_slot=None):
+        """grad_slot: functional.GradSlot shared with the other consumers of x (all of them convs or a residual BN), see functional.fork."""
         if self.groups != 1 or self.padding_mode != 'zeros':
             raise HF.DsrlHipError('HipConv2d: groups=1 and zero padding only')
         k = self.kernel_size
         if self.out_channels == 1 and k == (1, 1) and self.bias is None and self.in_channels % 4 != 0:
+            if grad_slot is not None:
+                grad_slot.closed = True         # this consumer reports its own gradient: nobody may accumulate into a shared buffer
             return HF.pointwise_strided(x, self.weight, _single(self.stride))          # feature transformers, DSRL.py:88-93
-        return HF.conv2d(x, self.weight, self.bias, _single(self.stride), _single(self.padding), _single(self.dilation))
+        return HF.conv2d(x, self.weight, self.bias, _single(self.stride), _single(self.padding), _single(self.dilation), grad_slot=grad_slot)
 
 
 class HipBatchNorm2d(nn.BatchNorm2d):
@@ -94,9 +97,12 @@ class HipMaxPool2d(nn.MaxPool2d):
 class HipSequential(nn.Sequential):
     """nn.Sequential that runs Conv2d -> BatchNorm2d -> ReLU -> Dropout as conv + one fused BN/activation pass."""
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, grad_slot=None):
+        """grad_slot goes to the first module when that is a HipConv2d (the consumer of x)."""
         mods = list(self)
         i, n = 0, len(mods)
+        if grad_slot is not None and not (n and isinstance(mods[0], HipConv2d)):
+            grad_slot.closed = True             # nobody here can honour the slot
         seed = HF.current_seed()
         while i < n:
             m = mods[i]
@@ -114,6 +120,6 @@ class HipSequential(nn.Sequential):
             elif isinstance(m, nn.ReLU):
                 raise HF.DsrlHipError('HipSequential: ReLU must follow a BatchNorm2d')
             else:
-                x = m(x)
+                x = m(x, grad_slot=grad_slot) if (i == 0 and grad_slot is not None and isinstance(m, HipConv2d)) else m(x)
                 i += 1
         return x

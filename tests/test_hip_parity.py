@@ -540,8 +540,8 @@ def test_batched_filter_transposes_match_per_layer_path():
 
 def test_grad_slots_match_autograd_accumulation():
     """Bottleneck inputs: the residual-branch gradient and conv1's (or the downsample conv's) data gradient accumulated in one buffer
-    by the dgrad epilogue (functional.GradSlot, dsrl_conv2d_dgrad_accumulate) equal autograd's separate sum, bit for bit (a + b is
-    commutative), on the whole backbone + head; and the step really drops the elementwise adds."""
+    by the dgrad epilogue (functional.GradSlot, dsrl_conv2d_dgrad_accumulate) equal autograd's separate sum on the whole backbone +
+    head (also the ASPP input and the concatenated decoder features, which use the same mechanism)."""
     from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
     rs = np.random.RandomState(5)
     x = rs.standard_normal((2, 3, 32, 64)).astype(np.float32)
@@ -566,8 +566,12 @@ def test_grad_slots_match_autograd_accumulation():
     finally:
         HF.grad_slots_enabled = old
     assert np.array_equal(logits[0], logits[1])
-    bad = {k: float(np.abs(grads[0][k] - grads[1][k]).max()) for k in grads[0] if not np.array_equal(grads[0][k], grads[1][k])}
+    # two contributions sum bit-identically (a + b is commutative); the ASPP input has five, whose order differs from autograd's,
+    # and that rounding difference reaches every earlier layer: equality to fp32 rounding, amplified by the batch-2 BNs
+    bad = {k: rel_err(grads[1][k], grads[0][k]) for k in grads[0] if rel_err(grads[1][k], grads[0][k]) > 2e-4}
     assert not bad, bad
+    for k in ('SSSR_decoder.cls_conv.weight', 'SSSR_decoder.cat_conv.0.weight', 'SISR_decoder.0.weight', 'feature_extractor.aspp.branches.5.0.weight'):
+        assert np.array_equal(grads[0][k], grads[1][k]), k          # downstream of every shared buffer: untouched
 
 
 @pytest.mark.parametrize('mode', ['mixed', 'bf16x6'])
