@@ -1228,13 +1228,38 @@ static int pick_kg(long long tiles, int nq, TileCfg cfg, int npl) {
     while (kg * 2 <= maxkg && nq >= 6 * kg * 2) kg *= 2;
     return kg;
 }
+// Tile / split-K / K-group choice for the split-precision kernels, from tools/sweep_igemm2.py on the step's layer shapes
+// (profiles/round1_sweep_igemm_split_kernel_v2.txt).  Starting from the generic pick (largest tile with >= 3 blocks per CU, else 64x64):
+//   a) a larger tile already pays at >= 2 blocks per CU (layer1 3x3: 128x64, layer4 / layer2 wide 1x1: 128x128);
+//   b) when even 64x64 tiles do not fill the chip, 128x128 tiles with split-K <= 4 beat 64x64 K groups if they reach >= 512 blocks
+//      (layer4, M = 4096 and N >= 512), or >= 256 blocks on very long K loops (dilated ASPP convs);
+//   c) 385..767 tiles of 64x64 (layer2 3x3): a 64x128 / 128x64 tile with two K groups.
+static void pick_split_plan(long long M, int N, int nq, TileCfg& cfg, int& splits, int& kg) {
+    const bool forced = env_int("DSRL_FORCE_CFG", -1) >= 0 || env_int("DSRL_FORCE_SPLITS", 0) > 0 || env_int("DSRL_FORCE_KG", 0) > 0;
+    if (forced || N <= 32 || !env_int("DSRL_SPLIT_PLAN", 1)) return;
+    const int r = N % 128;
+    const bool narrow = N <= 64 || (r > 0 && r <= 64);
+    const TileCfg wide[2] = {T128x128, T128x64}, nar[2] = {T256x64, T128x64};
+    for (TileCfg c : (narrow ? nar : wide))                                         // a)
+        if (cfg_blocks(c, M, N) >= 2 * kNumCU) { cfg = c; splits = 1; kg = 1; return; }
+    const long long t64 = cfg_blocks(T64x64, M, N), t128 = cfg_blocks(T128x128, M, N);
+    if (!narrow && t64 < 3 * kNumCU) {                                              // b)
+        for (int sp = 2; sp <= 4; sp *= 2)
+            if (nq >= 12 * sp && (t128 * sp >= 2 * kNumCU || (nq >= 256 && t128 * sp >= kNumCU))) { cfg = T128x128; splits = sp; kg = 1; return; }
+    }
+    if (t64 * 2 > 3 * kNumCU && t64 < 3 * kNumCU && nq >= 24) {                     // c)
+        cfg = (N % 128 == 0) ? T64x128 : T128x64; splits = 1; kg = 2;
+    }
+}
 static FwdPlan plan_fwd(int N, int Hin, int Win, int Cin, int Kout, int R, int S, int Ho, int Wo, int npl) {
     FwdPlan p; p.Ho = Ho; p.Wo = Wo; p.M = N * Ho * Wo; p.cchunks = (int)ceil_div(Cin, BK);
     p.cfg = pick_cfg(p.M, Kout);
     int bm, bn; cfg_dims(p.cfg, bm, bn);
     const long long tiles = ceil_div(p.M, bm) * ceil_div(Kout, bn);
-    p.kg = pick_kg(tiles, R * S * p.cchunks, p.cfg, npl);
-    p.splits = p.kg > 1 ? 1 : pick_splits(tiles, R * S * p.cchunks);
+    const int nq = R * S * p.cchunks;
+    p.kg = pick_kg(tiles, nq, p.cfg, npl);
+    p.splits = p.kg > 1 ? 1 : pick_splits(tiles, nq);
+    if (npl) pick_split_plan(p.M, Kout, nq, p.cfg, p.splits, p.kg);
     p.ws = p.splits > 1 ? (size_t)p.splits * p.M * Kout * sizeof(float) : 0;
     return p;
 }
