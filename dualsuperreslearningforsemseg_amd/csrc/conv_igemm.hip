@@ -655,6 +655,7 @@ struct WgradArgs {
     int xcd_remap;              // pixel-range-major block order per XCD (blocks of one pixel range share dy / x chunks)
     int kctiles;                // ktiles * ctiles
     unsigned mHW, sHW, mW, sW;  // magic multipliers / shifts: p / (Ho*Wo) and rem / Wo for p < 2^31 (fast_div)
+    int kg;                     // split kernel: pixel groups per block (1, 2 or 4)
 };
 
 template <int MR, int NR, int WGM, int WGN>
@@ -793,8 +794,10 @@ __device__ __forceinline__ int fast_div(int n, unsigned m, unsigned s) { return 
 // ([16 px][BM | BN] bf16 per plane, row stride + 64 B) and the K-contiguous MFMA operands are gathered with
 // ds_read_b64_tr_b16 (per 16-lane group: lane 4q+p addresses row q / columns 4p..4p+3, lane i receives column i of the 4 rows).
 // The pixel -> (n, ho, wo) decomposition of every staged x row uses magic-number division (two mul-hi instead of two divides).
-template <int MR, int NR, int WGM, int WGN, int NPL>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArgs a) {
+// KG > 1 (pixel groups): KG groups of 4 waves per block, group g takes the 32-pixel chunks g, g+KG, ... of the block's pixel range with
+// its own two LDS stages; the KG accumulator sets are summed through LDS in a fixed order - KG times fewer slabs to write and reduce.
+template <int MR, int NR, int WGM, int WGN, int NPL, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_wgrad_split_kernel(const WgradArgs a) {
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
     constexpr int A_V = BM / 4, B_V = BN / 4;                 // float4 per pixel row
     constexpr int A_RP = 256 / A_V, B_RP = 256 / B_V;          // pixel rows per staging pass
@@ -804,10 +807,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
     constexpr int SA = BM * 2 + 64, SB = BN * 2 + 64;          // LDS row strides in bytes
     constexpr int PLA = 16 * SA, PLB = 16 * SB, OFF_B = NPL * PLA, STAGE = NPL * (PLA + PLB);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* const S0 = reinterpret_cast<char*>(smem);
+    const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+    char* const S0 = reinterpret_cast<char*>(smem) + grp * 2 * STAGE;
     char* const S1 = S0 + STAGE;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x & 255, lane = tid & 63;         // thread within its pixel group
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
     const int per_z = a.ntaps * a.kctiles;
@@ -952,26 +956,89 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const WgradArg
         for (int c = (NMFMA + MPS - 1) / MPS; c < CSTEPS; ++c) cstep(nxt, ra, rb, hf, c);
     };
 
-    bool v0 = issue(RA0, RB0);
-    bool v1 = v0 && issue(RA1, RB1);
-    if (v0) {
+    if constexpr (KG == 1) {
+        bool v0 = issue(RA0, RB0);
+        bool v1 = v0 && issue(RA1, RB1);
+        if (v0) {
 #pragma unroll
-        for (int c = 0; c < CSTEPS; ++c) cstep(S0, RA0, RB0, 0, c);
+            for (int c = 0; c < CSTEPS; ++c) cstep(S0, RA0, RB0, 0, c);
+            __syncthreads();
+        }
+        while (v0) {
+            pipe(S0, S1, RA0, RB0, 1);                     // MFMAs of chunk A / half 0, convert chunk A / half 1
+            const bool n0 = v1 && issue(RA0, RB0);         // chunk A+2
+            __syncthreads();
+            pipe(S1, S0, RA1, RB1, 0);                     // MFMAs of chunk A / half 1, convert chunk B / half 0 (stale if !v1: unused)
+            __syncthreads();
+            if (!v1) break;
+            pipe(S0, S1, RA1, RB1, 1);
+            const bool n1 = n0 && issue(RA1, RB1);         // chunk B+2
+            __syncthreads();
+            pipe(S1, S0, RA0, RB0, 0);
+            __syncthreads();
+            v0 = n0; v1 = n1;
+        }
+    } else {
+        // every group runs the same number of pipeline iterations (the barriers are block-wide); a chunk past the group's share or
+        // one that only sees zero padding is fed as zeros instead of being skipped
+        const int nloc = (ch1 - ch0 + KG - 1) / KG;
+        int itn = 0;                                   // next local chunk of this group
+        auto issue_g = [&](float4* ra, float4* rb) {
+            const int ch = ch0 + grp + itn * KG;
+            ++itn;
+            if (ch < ch1 && chunk_live(ch)) { gload(ra, rb, ch); return; }
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        if (nloc > 0) {
+            issue_g(RA0, RB0);
+            issue_g(RA1, RB1);
+#pragma unroll
+            for (int c = 0; c < CSTEPS; ++c) cstep(S0, RA0, RB0, 0, c);
+            __syncthreads();
+        }
+        for (int q = 0; q < nloc; q += 2) {
+            pipe(S0, S1, RA0, RB0, 1);
+            issue_g(RA0, RB0);
+            __syncthreads();
+            pipe(S1, S0, RA1, RB1, 0);
+            __syncthreads();
+            if (q + 1 < nloc) {
+                pipe(S0, S1, RA1, RB1, 1);
+                issue_g(RA1, RB1);
+                __syncthreads();
+                pipe(S1, S0, RA0, RB0, 0);
+                __syncthreads();
+            }
+        }
+        // ---- sum the KG accumulator sets through LDS (stages are free now), fixed order g = 1 .. KG-1; group 0 stores
+        float4* red = reinterpret_cast<float4*>(smem);
+        constexpr int NQ = MR * NR * 4;
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4)
+                        red[((grp - 1) * NQ + (i * NR + j) * 4 + e4) * 256 + tid] =
+                            make_float4(acc[i][j][4 * e4], acc[i][j][4 * e4 + 1], acc[i][j][4 * e4 + 2], acc[i][j][4 * e4 + 3]);
+        }
         __syncthreads();
-    }
-    while (v0) {
-        pipe(S0, S1, RA0, RB0, 1);                     // MFMAs of chunk A / half 0, convert chunk A / half 1
-        const bool n0 = v1 && issue(RA0, RB0);         // chunk A+2
-        __syncthreads();
-        pipe(S1, S0, RA1, RB1, 0);                     // MFMAs of chunk A / half 1, convert chunk B / half 0 (stale if !v1: unused)
-        __syncthreads();
-        if (!v1) break;
-        pipe(S0, S1, RA1, RB1, 1);
-        const bool n1 = n0 && issue(RA1, RB1);         // chunk B+2
-        __syncthreads();
-        pipe(S1, S0, RA0, RB0, 0);
-        __syncthreads();
-        v0 = n0; v1 = n1;
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 1; g < KG; ++g)
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const float4 v = red[((g - 1) * NQ + (i * NR + j) * 4 + e4) * 256 + tid];
+                        acc[i][j][4 * e4] += v.x; acc[i][j][4 * e4 + 1] += v.y; acc[i][j][4 * e4 + 2] += v.z; acc[i][j][4 * e4 + 3] += v.w;
+                    }
     }
 
     float* out = a.dw + (a.psplits > 1 ? (long long)zsplit * a.slab : 0ll);
@@ -1415,7 +1482,27 @@ static void launch_wgrad(const WgradArgs& a_in, TileCfg cfg, int bm, int bn, dim
         WgradArgs a = a_in;
         make_magic(a.Ho * a.Wo, a.mHW, a.sHW);
         make_magic(a.Wo, a.mW, a.sW);
-        const size_t lds = (size_t)2 * npl * 16 * ((bm * 2 + 64) + (bn * 2 + 64));        // two stages: <= 60 KiB for every tile
+        const size_t stages = (size_t)2 * npl * 16 * ((bm * 2 + 64) + (bn * 2 + 64));     // two stages: <= 60 KiB for every tile
+        const int kg = a.kg > 1 ? a.kg : 1;
+        if (kg > 1) {
+            const size_t lds = std::max(stages * kg, (size_t)(kg - 1) * (bm / 32) * (bn / 32) / 4 * 16384);
+#define DSRL_LAUNCH_WKG(a_, b_, c_, d_, NPL_, KG_)                                                                                  \
+            {                                                                                                                        \
+                static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_split_kernel<a_, b_, c_, d_, NPL_, KG_>,  \
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);          \
+                (void)attr;                                                                                                          \
+                hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, NPL_, KG_>), grid, dim3(256 * KG_), lds, st, a);         \
+            }
+#define DSRL_WKG_BY_NPL(a_, b_, c_, d_, KG_) { if (npl == 2) DSRL_LAUNCH_WKG(a_, b_, c_, d_, 2, KG_) else DSRL_LAUNCH_WKG(a_, b_, c_, d_, 3, KG_) }
+            if (cfg == T64x64) { if (kg == 4) DSRL_WKG_BY_NPL(1, 1, 2, 2, 4) else DSRL_WKG_BY_NPL(1, 1, 2, 2, 2) }
+            else if (cfg == T128x64) { if (kg == 4) DSRL_WKG_BY_NPL(2, 1, 2, 2, 4) else DSRL_WKG_BY_NPL(2, 1, 2, 2, 2) }
+            else if (cfg == T64x128) { if (kg == 4) DSRL_WKG_BY_NPL(1, 2, 2, 2, 4) else DSRL_WKG_BY_NPL(1, 2, 2, 2, 2) }
+            else DSRL_WKG_BY_NPL(2, 2, 2, 2, 2)
+#undef DSRL_WKG_BY_NPL
+#undef DSRL_LAUNCH_WKG
+            return;
+        }
+        const size_t lds = stages;
 #define DSRL_LAUNCH_WGRAD(a_, b_, c_, d_)                                                                           \
         if (npl == 2) hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, 2>), grid, dim3(256), lds, st, a); \
         else hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, 3>), grid, dim3(256), lds, st, a);
@@ -1481,16 +1568,29 @@ extern "C" int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int l
     }
     a.ntaps = p.tl.n;
     for (int i = 0; i < p.tl.n; ++i) a.taps[i] = p.tl.taps[i];
-    a.dw = p.psplits > 1 ? (float*)ws : dw;
+    // pixel groups (split kernels): two groups of 4 waves share a block and half of the planned slabs remain.  Measured
+    // (tools/wgrad_kg.py): 1x1 convs gain 5-20 %, 3x3 convs lose (each of their taps already has its own blocks), four groups always lose.
+    int psplits = p.psplits, kg = 1;
+    if (conv_planes(PASS_WGRAD) && env_int("DSRL_WGRAD_KG", 1)) {
+        const int npl = conv_planes(PASS_WGRAD);
+        const int maxkg = (p.cfg == T64x64 || p.cfg == T128x64 || p.cfg == T64x128) ? 4 : (p.cfg == T128x128 ? 2 : 1);
+        const int forced = env_int("DSRL_FORCE_WGRAD_KG", 0);
+        kg = forced > 0 ? std::min(forced, maxkg) : ((RS == 1 && psplits >= 4) ? std::min(2, maxkg) : 1);
+        if (kg == 3) kg = 2;
+        while (kg > 1 && (size_t)kg * 2 * npl * 16 * ((p.bm * 2 + 64) + (p.bn * 2 + 64)) > 144 * 1024) kg /= 2;      // LDS: kg stage pairs
+        psplits = (int)ceil_div(psplits, kg);
+    }
+    a.psplits = psplits; a.kg = kg;
+    a.dw = psplits > 1 ? (float*)ws : dw;
     a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
-    dim3 grid((unsigned)(a.kctiles * p.tl.n * p.psplits));
+    dim3 grid((unsigned)(a.kctiles * p.tl.n * psplits));
     ProfScope prof(prof_family(PASS_WGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
     launch_wgrad(a, p.cfg, p.bm, p.bn, grid, st);
     if (int e = launch_status("conv_wgrad kernel")) return e;
-    if (p.psplits > 1) {
+    if (psplits > 1) {
         const long long total = (long long)K * p.tl.n * (C / 4);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st,
-                           (const float*)ws, p.psplits, a.slab, dw, K, RS, C, p.tl);
+                           (const float*)ws, psplits, a.slab, dw, K, RS, C, p.tl);
         return launch_status("wgrad_reduce_kernel");
     }
     return DSRL_OK;
