@@ -76,6 +76,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if os.environ.get('DSRL_ALL_RANKS_ON_GPU0'):                       # rehearsal of the multi-rank path on a one-GPU box
         local = 0
+        os.environ['DSRL_BN_FUSED'] = '0'     # several processes on one GPU: the fused BN kernels' device-wide barrier needs the GPU to itself
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f'--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`')

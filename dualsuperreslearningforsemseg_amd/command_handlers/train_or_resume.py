@@ -119,6 +119,10 @@ class TrainStep:
         vals = [float(v) for v in host]
         self._free.append((host, ev))
         if vals[4] != 0:
+            stuck = HF.bn_fused_barrier_timeouts()
+            if stuck:
+                raise RuntimeError(f'{stuck} blocks of the fused BatchNorm kernels timed out at their device-wide barrier and poisoned their outputs: '
+                                   'is another process using this GPU? (functional.set_bn_fused_max_blocks(0) selects the three-kernel path)')
             raise AssertionError("network output contains 'NaN' values and so cannot continue.")
         return vals[:4]
 

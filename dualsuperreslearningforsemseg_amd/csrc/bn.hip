@@ -5,6 +5,7 @@
 #include "common.h"
 #include <algorithm>
 #include <initializer_list>
+#include <atomic>
 #include <mutex>
 #include <stdlib.h>
 
@@ -424,6 +425,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
 // arrival counter: a launch is handed the count all earlier launches leave behind (host side, under a mutex, stream-ordered).
 // 256 blocks of <= 128 registers are always co-resident on 256 CUs; the spin is bounded so that a bug cannot hang the GPU.
 __device__ unsigned long long g_grid_arrivals = 0ull;
+__device__ unsigned int g_grid_timeouts = 0u;           // blocks that gave up waiting (dsrl_bn_fused_barrier_timeouts)
 constexpr int kFusedBlocks = 128, kFusedBlocksBig = 256, kFusedThreads = 512, kFusedMaxPasses = 16;   // measured: the barrier costs ~20 ns per arriving block,
                                                                                                    // so 128 blocks unless the tensor needs the registers of 256
 constexpr int kFusedRL = kFusedThreads / 8, kFusedNW = kFusedThreads / 64, kFusedNS = kFusedThreads / 32;   // row lanes, waves, merge slices
@@ -442,7 +444,11 @@ __device__ inline bool grid_barrier(unsigned long long target) {
         unsigned spins = 0;
         bool ok = true;
         while (__hip_atomic_load(&g_grid_arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins >= (1u << 22)) { ok = false; break; }          // ~1 s: the other blocks never arrived
+            if (++spins >= (1u << 25)) {                                 // seconds: the other blocks never became resident
+                ok = false;
+                __hip_atomic_fetch_add(&g_grid_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
         ok_sh = ok ? 1 : 0;
@@ -725,15 +731,17 @@ extern "C" size_t dsrl_bn_workspace_bytes(int64_t P, int C) { return (size_t)(3 
 
 namespace dsrl {
 static int env_int_bn(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static std::atomic<int> g_fused_max_blocks{-1};      // dsrl_bn_fused_max_blocks(); -1 = DSRL_BN_FUSED / DSRL_BN_FUSED_BIG from the environment
 struct FusedPlan { bool ok; int blocks, groups, slabs, rows_per_slab; };
 // eligible: C a power-of-two multiple of 32 and the tensor fits the registers of 128 (P*C <= 4.2 M elements) or 256 blocks (8.4 M)
 static FusedPlan fused_plan(int64_t P, int C) {
     FusedPlan f{false, 0, 0, 0, 0};
-    if (!env_int_bn("DSRL_BN_FUSED", 1) || C < 32 || C % 32 || P >= (1ll << 30)) return f;
+    int max_blocks = g_fused_max_blocks.load();
+    if (max_blocks < 0) max_blocks = !env_int_bn("DSRL_BN_FUSED", 1) ? 0 : (env_int_bn("DSRL_BN_FUSED_BIG", 1) ? kFusedBlocksBig : kFusedBlocks);
+    if (max_blocks < kFusedBlocks || C < 32 || C % 32 || P >= (1ll << 30)) return f;
     const int groups = C / 32;
     for (int blocks : {kFusedBlocks, kFusedBlocksBig}) {
-        if (groups > blocks || blocks % groups) continue;
-        if (blocks == kFusedBlocksBig && !env_int_bn("DSRL_BN_FUSED_BIG", 1)) continue;
+        if (blocks > max_blocks || groups > blocks || blocks % groups) continue;
         const int slabs = blocks / groups;
         const int64_t rows = ceil_div(P, (int64_t)slabs);
         if (rows > kFusedRL * kFusedMaxPasses) continue;
@@ -796,6 +804,20 @@ extern "C" int dsrl_bn_apply(const float* x, int ldx, float* y, int ldy, int64_t
         hipLaunchKernelGGL(bn_apply_kernel, apply_grid(P, C), dim3(256), 0, st, x, ldx, y, ldy, (long long)P, C, mean, invstd, gamma, beta, residual, ldr,
                            relu, drop_p, (unsigned long long)seed, (unsigned)rng_stream);
     return launch_status("bn_apply_kernel");
+}
+
+extern "C" int dsrl_bn_fused_max_blocks(int max_blocks) {
+    const int prev = g_fused_max_blocks.load();
+    if (max_blocks >= -1) g_fused_max_blocks.store(max_blocks);
+    return prev;
+}
+
+extern "C" int dsrl_bn_fused_barrier_timeouts(int64_t* count) {
+    DSRL_REQUIRE(count, DSRL_E_BADARG, "bn_fused_barrier_timeouts: null pointer");
+    unsigned int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_grid_timeouts), sizeof(v)) != hipSuccess) return launch_status("hipMemcpyFromSymbol(g_grid_timeouts)");
+    *count = (int64_t)v;
+    return DSRL_OK;
 }
 
 extern "C" int dsrl_bn_train_fwd(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,

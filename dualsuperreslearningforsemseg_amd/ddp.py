@@ -91,6 +91,10 @@ class FlatParams:
         for p in self.params:
             p._dsrl_arena = self
         self._build_transposed_filters()
+        if self.world > 1 and self.device.type == 'cuda' and os.environ.get('DSRL_BN_FUSED_BIG') is None:
+            # RCCL kernels hold CUs while they wait for their peers: a 256-block fused-BN launch (one block on EVERY CU) could stall behind
+            # them, the 128-block variant cannot
+            HF.set_bn_fused_max_blocks(128)
         if self.world > 1:
             dist.broadcast(self.p_flat, 0, group=self.pg)          # DDP constructor semantics: rank 0's weights win
             dist.broadcast(self.b_flat, 0, group=self.pg)

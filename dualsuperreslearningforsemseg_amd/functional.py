@@ -60,6 +60,20 @@ def get_conv_precision():
     return [k for k, v in CONV_PRECISION_MODES.items() if v == code][0]
 
 
+def set_bn_fused_max_blocks(n):
+    """Block budget of the single-kernel BatchNorm (include/dsrl_hip.h: dsrl_bn_fused_max_blocks): 0 = off, 128, 256; None = follow the
+    environment. Its device-wide barrier needs all blocks resident at once, i.e. no other process on the GPU."""
+    return int(_lib.load().dsrl_bn_fused_max_blocks(-1 if n is None else int(n)))
+
+
+def bn_fused_barrier_timeouts():
+    """Blocks of fused BN launches that gave up waiting at the barrier so far (their outputs were poisoned with NaN). Synchronises."""
+    import ctypes
+    n = ctypes.c_int64(0)
+    _lib.check(_lib.load().dsrl_bn_fused_barrier_timeouts(ctypes.byref(n)), 'dsrl_bn_fused_barrier_timeouts')
+    return int(n.value)
+
+
 def side_stream(device):
     st = _side.get(device)
     if st is None:

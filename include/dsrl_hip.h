@@ -124,6 +124,14 @@ int dsrl_bn_apply(const float* x, int ldx, float* y, int ldy, int64_t P, int C,
                   const float* mean, const float* invstd, const float* gamma, const float* beta,
                   const float* residual /*nullable*/, int ldr, int relu, float drop_p, uint64_t seed, uint32_t rng_stream,
                   dsrl_stream_t stream);
+/* The fused small-tensor BN kernels (dsrl_bn_train_fwd / dsrl_bn_bwd) cross a device-wide barrier: all blocks of a launch (128, or
+ * 256 for tensors of 4.2-8.4 M elements; one 512-thread block per CU) must become resident together, so they assume that the process
+ * has the GPU to itself apart from its own streams. dsrl_bn_fused_max_blocks: 0 = never use them, 128 = the 128-block variant only (what
+ * ddp.FlatParams selects when RCCL kernels share the device), 256 = both, -1 = follow DSRL_BN_FUSED / DSRL_BN_FUSED_BIG; other values
+ * change nothing; returns the previous setting. A block that waits for seconds gives up, poisons its outputs with NaN and counts in
+ * dsrl_bn_fused_barrier_timeouts (synchronous read). */
+int dsrl_bn_fused_max_blocks(int max_blocks);
+int dsrl_bn_fused_barrier_timeouts(int64_t* count);
 /* Training-mode BatchNorm2d forward in one call: batch statistics (as dsrl_bn_stats: mean / invstd out, running stats updated in place)
  * and y = act(gamma * xhat + beta (+ residual)) (as dsrl_bn_apply). Small tensors (C a power-of-two multiple of 32, P*C <= 4.2 M) take a
  * single fused kernel that reads x once; everything else runs the statistics and apply kernels. nn.BatchNorm2d (+ReLU, +Dropout) of

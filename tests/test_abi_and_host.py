@@ -140,3 +140,13 @@ def test_conv_precision_api_roundtrip():
         HF.set_conv_precision('fp8')
     HF.set_conv_precision(None)
     assert HF.get_conv_precision() == default
+
+
+def test_bn_fused_block_budget_roundtrip():
+    """functional.set_bn_fused_max_blocks drives dsrl_bn_fused_max_blocks (0 = off, 128, 256, None = environment); no GPU needed."""
+    from dualsuperreslearningforsemseg_amd import functional as HF
+    first = HF.set_bn_fused_max_blocks(128)
+    assert HF.set_bn_fused_max_blocks(0) == 128
+    assert HF.set_bn_fused_max_blocks(256) == 0
+    assert HF.set_bn_fused_max_blocks(None) == 256
+    assert HF.set_bn_fused_max_blocks(first if first >= 0 else None) == -1

@@ -250,6 +250,23 @@ def test_batchnorm_fused_vs_three_kernel_path_and_oracle(shape, variant):
     check(out['1'][4], rm, 1e-5, 'running_mean'); check(out['1'][5], rv, 1e-5, 'running_var')
 
 
+def test_batchnorm_fused_budget_and_timeout_counter():
+    """Budget 0 selects the three-kernel path, 128 keeps the 256-block variant off; no launch of this suite ever timed out at the barrier."""
+    rs = np.random.RandomState(11)
+    x = rs.standard_normal((8, 512, 32, 64)).astype(np.float32)          # 8.4 M elements: 256-block variant when allowed
+    outs = []
+    try:
+        for budget in (256, 128, 0):
+            HF.set_bn_fused_max_blocks(budget)
+            bn = D.nn_modules.HipBatchNorm2d(512).to(DEV).train()
+            outs.append(host(HF.batch_norm_act(dev(x), bn, relu=True)))
+    finally:
+        HF.set_bn_fused_max_blocks(None)
+    check(outs[0], outs[2], 2e-5); check(outs[1], outs[2], 2e-5)
+    assert np.array_equal(outs[1], outs[2])          # budget 128 cannot hold this tensor: both ran the three-kernel path
+    assert HF.bn_fused_barrier_timeouts() == 0
+
+
 def test_dropout_matches_oracle_philox():
     x = np.random.RandomState(3).standard_normal((2, 19, 16, 32)).astype(np.float32)
     xt = dev(x).requires_grad_(True)
