@@ -206,6 +206,18 @@ def main():
         except Exception:
             pass
 
+    # the same step under the stricter conv arithmetics, a few steps each (single GPU only): fp32-equivalent bf16x6 everywhere and
+    # exact-product fp32 MFMA.  The headline `value` is the default 'mixed' mode (bf16x6 forward, bf16x3 backward), see DESIGN.md 3b.
+    by_arith = None
+    if world == 1 and not args.no_prof and HF.get_conv_precision() == 'mixed':
+        by_arith = {}
+        for mode in ('bf16x6', 'fp32'):
+            HF.set_conv_precision(mode)
+            run(3); torch.cuda.synchronize()
+            t1 = time.perf_counter(); run(10); torch.cuda.synchronize()
+            by_arith[mode] = round(args.batch * 10 / (time.perf_counter() - t1), 1)
+        HF.set_conv_precision(None)
+
     if rank == 0:
         gb = args.batch * world
         line = {
@@ -213,7 +225,7 @@ def main():
                       else f'stage-{args.stage} train images/sec at {args.height}x{args.width}',
             'value': round(gb * args.steps / elapsed, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'host_enqueue_ms_per_step': round(sorted(host_ms[args.warmup:args.warmup + args.steps])[args.steps // 2], 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'conv_arithmetic': conv_arith, 'data': 'synthetic',
+            'dtype': 'f32', 'conv_arithmetic': conv_arith, 'images_per_s_by_conv_arithmetic': by_arith, 'data': 'synthetic',
             'config': {'workload': f'DSRL stage {args.stage} (ResNet-101 OS16 + ASPP + SSSR/SISR decoders + FA loss), full train step, '
                                    f'random-init weights, {args.height}x{args.width} input -> {2 * args.height}x{2 * args.width} logits',
                        'global_batch': gb, 'per_gpu_batch': args.batch, 'parallelism': f'dp{world}', 'optimizer': 'SGD m0.9 wd5e-4 lr0.006',

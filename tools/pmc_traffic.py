@@ -12,7 +12,7 @@ def family(name):
     m = re.search(r'conv_igemm_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)(?:, \d+)?>', name)
     if m:
         return f"conv_igemm_split_kernel<{'bf16x3' if m.group(6) == '2' else 'bf16x6'}> ({'dgrad' if m.group(5) == 'true' else 'forward'})"
-    m = re.search(r'conv_wgrad_split_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>', name)
+    m = re.search(r'conv_wgrad_split_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, \d+)?>', name)
     if m:
         return f"conv_wgrad_split_kernel<{'bf16x3' if m.group(5) == '2' else 'bf16x6'}>"
     m = re.search(r'conv_igemm_f32_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)', name)
