@@ -250,6 +250,31 @@ def test_batchnorm_fused_vs_three_kernel_path_and_oracle(shape, variant):
     check(out['1'][4], rm, 1e-5, 'running_mean'); check(out['1'][5], rv, 1e-5, 'running_var')
 
 
+@pytest.mark.parametrize('C', [256, 48])
+def test_batchnorm_frozen_statistics_backward(C):
+    """--freeze-batch-norm training (train_or_resume.py:379-382): BN modules in eval mode, gradients still flow.  C = 256 takes the fused
+    backward kernel (training = 0: no batch-statistics terms), C = 48 the three-kernel path; both against the oracle."""
+    rs = np.random.RandomState(C)
+    x = (rs.standard_normal((4, C, 16, 32)) * 1.5 + 0.3).astype(np.float32)
+    gamma = rs.uniform(0.5, 1.5, C).astype(np.float32); beta = rs.standard_normal(C).astype(np.float32)
+    rm = rs.standard_normal(C).astype(np.float32) * 0.2; rv = rs.uniform(0.5, 2.0, C).astype(np.float32)
+    dy = rs.standard_normal(x.shape).astype(np.float32)
+    bn = D.nn_modules.HipBatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(dev(gamma)); bn.bias.copy_(dev(beta)); bn.running_mean.copy_(dev(rm)); bn.running_var.copy_(dev(rv))
+    bn.eval()
+    xt = dev(x).requires_grad_(True)
+    y = HF.batch_norm_act(xt, bn, relu=True)
+    y.backward(dev(dy))
+    invstd = 1.0 / np.sqrt(rv.astype(np.float64) + bn.eps)
+    yo = (x.astype(np.float64) - rm.reshape(1, -1, 1, 1)) * (invstd * gamma).reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)
+    g = dy.astype(np.float64) * (yo > 0)
+    dxo, dgo, dbo = O.batchnorm_eval_bwd(x.astype(np.float64), gamma.astype(np.float64), rm.astype(np.float64), invstd, g)
+    check(host(y), np.maximum(yo, 0), 1e-5, 'y'); check(host(xt.grad), dxo, 1e-5, 'dx')
+    check(host(bn.weight.grad), dgo, 1e-4, 'dgamma'); check(host(bn.bias.grad), dbo, 1e-4, 'dbeta')
+    check(host(bn.running_mean), rm, 0.0); check(host(bn.running_var), rv, 0.0)
+
+
 def test_batchnorm_fused_budget_and_timeout_counter():
     """Budget 0 selects the three-kernel path, 128 keeps the 256-block variant off; no launch of this suite ever timed out at the barrier."""
     rs = np.random.RandomState(11)
