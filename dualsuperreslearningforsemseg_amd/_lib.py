@@ -28,6 +28,8 @@ PROTOTYPES = {
     'dsrl_device_check': (i32, [C.POINTER(i32)]),
     'dsrl_conv2d_fwd_workspace_bytes': (sz, _conv_shape),
     'dsrl_conv2d_fwd': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, stream_t]),
+    'dsrl_conv2d_fwd_stats_parts': (i32, _conv_shape),
+    'dsrl_conv2d_fwd_stats': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, stream_t]),
     'dsrl_conv2d_dgrad_workspace_bytes': (sz, _conv_shape),
     'dsrl_conv2d_transposed_filter_floats': (sz, [i32] * 4),
     'dsrl_conv2d_transpose_filter': (i32, [fp, fp, i32, i32, i32, i32, stream_t]),
@@ -51,6 +53,7 @@ PROTOTYPES = {
     'dsrl_bn_apply': (i32, [fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, stream_t]),
     'dsrl_bn_fused_max_blocks': (i32, [i32]),
     'dsrl_bn_fused_barrier_timeouts': (i32, [C.POINTER(i64)]),
+    'dsrl_bn_train_fwd_from_stats': (i32, [fp, i32, fp, i32, i64, i32, f32, f32, fp, fp, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, fp, i32, stream_t]),
     'dsrl_bn_train_fwd': (i32, [fp, i32, fp, i32, i64, i32, f32, f32, fp, fp, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, fp, sz, stream_t]),
     'dsrl_bn_bwd': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, f32, i32, fp, sz, stream_t]),
     'dsrl_dropout_fwd': (i32, [fp, i32, fp, i32, i64, i32, f32, u64, u32, stream_t]),

@@ -703,6 +703,89 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_bwd_kernel(const float
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- BN forward from conv-epilogue partials
+// The producing conv already wrote (n, mean, M2) per (row block, channel) of its output (conv_igemm_split_kernel epilogue), so the
+// statistics pass and the device-wide barrier of bn_fused_fwd_kernel disappear: a block = (32-channel group) x (row slab) merges
+// the <= 256 partials of its own 32 channels (fp64, fixed order: every block of a group gets bit-identical statistics) and streams
+// x -> y once.  Any number of blocks; slab-0 blocks publish mean / invstd and update the running statistics.
+__global__ __launch_bounds__(256) void bn_stats_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int P, int C,
+                                                              int groups, int rows_per_slab, float eps, float momentum,
+                                                              float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ rm, float* __restrict__ rv,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ res, int ldr, int relu, float drop_p, unsigned long long seed, unsigned rng_stream,
+                                                              const float* __restrict__ part, int nparts) {
+    __shared__ double shm[8][3][32];
+    __shared__ float fin[2][32];
+    const int grp = blockIdx.x % groups, slab = blockIdx.x / groups;
+    const int tid = threadIdx.x, l8 = tid & 7, rr = tid >> 3;
+    const int q = grp * 8 + l8;
+    {
+        const int ch = tid & 31, k = tid >> 5;
+        const float* pn = part + grp * 32 + ch;
+        const float* pm_ = pn + (long long)nparts * C;
+        const float* pq = pn + 2ll * nparts * C;
+        const float mref = pm_[0];
+        double N = 0, S = 0, T = 0;
+        for (int base = k; base < nparts; base += 32) {
+            float vn[4], vm[4], vq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sl = min(base + 8 * u, nparts - 1);
+                vn[u] = pn[(long long)sl * C]; vm[u] = pm_[(long long)sl * C]; vq[u] = pq[(long long)sl * C];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double nb = base + 8 * u < nparts ? (double)vn[u] : 0.0, d = (double)vm[u] - (double)mref;
+                N += nb; S += nb * d; T += (base + 8 * u < nparts ? (double)vq[u] : 0.0) + nb * d * d;
+            }
+        }
+        shm[k][0][ch] = N; shm[k][1][ch] = S; shm[k][2][ch] = T;
+        if (k == 0) fin[0][ch] = mref;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        double N = 0, S = 0, T = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { N += shm[k][0][tid]; S += shm[k][1][tid]; T += shm[k][2][tid]; }
+        const double mu = N > 0 ? (double)fin[0][tid] + S / N : 0.0;
+        const double Q = N > 0 ? fmax(T - S * S / N, 0.0) : 0.0;
+        const double var = N > 0 ? Q / N : 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        fin[0][tid] = (float)mu; fin[1][tid] = is;
+        if (slab == 0) {
+            const int c = grp * 32 + tid;
+            mean_out[c] = (float)mu; invstd_out[c] = is;
+            if (rm) rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * mu);
+            if (rv) rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * (N > 1 ? Q / (N - 1) : var));
+        }
+    }
+    __syncthreads();
+    float sc[4], sf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = 4 * q + j; sc[j] = gamma[c] * fin[1][4 * l8 + j]; sf[j] = beta[c] - fin[0][4 * l8 + j] * sc[j]; }
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const int row0 = slab * rows_per_slab, row1 = min(P, row0 + rows_per_slab);
+#pragma unroll 4
+    for (int p = row0 + rr; p < row1; p += 32) {
+        const float4 xv = LD4(x, p, ldx, q);
+        float v[4] = {fmaf(xv.x, sc[0], sf[0]), fmaf(xv.y, sc[1], sf[1]), fmaf(xv.z, sc[2], sf[2]), fmaf(xv.w, sc[3], sf[3])};
+        if (res) { const float4 r = LD4(res, p, ldr, q); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (drop_p > 0.f) {
+            const unsigned long long e = (unsigned long long)p * C + 4ull * q;
+            unsigned r[4];
+            philox4x32_10((unsigned)(e >> 2), (unsigned)(e >> 34), rng_stream, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ((float)(r[j] >> 8) * 5.9604644775390625e-08f >= drop_p) ? v[j] * ks : 0.f;
+        }
+        ST4(y, p, ldy, q) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 static bool vec4_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
     if (C % 4) return false;
     for (int l : lds) if (l % 4) return false;
@@ -840,6 +923,25 @@ extern "C" int dsrl_bn_train_fwd(const float* x, int ldx, float* y, int ldy, int
     }
     if (int e = dsrl_bn_stats(x, ldx, P, C, eps, momentum, mean, invstd, running_mean, running_var, ws, ws_bytes, stream)) return e;
     return dsrl_bn_apply(x, ldx, y, ldy, P, C, mean, invstd, gamma, beta, residual, ldr, relu, drop_p, seed, rng_stream, stream);
+}
+
+extern "C" int dsrl_bn_train_fwd_from_stats(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,
+                                            float* running_mean, float* running_var, const float* gamma, const float* beta, const float* residual, int ldr,
+                                            int relu, float drop_p, uint64_t seed, uint32_t rng_stream, const float* stats, int stats_parts, dsrl_stream_t stream) {
+    DSRL_REQUIRE(x && y && mean && invstd && gamma && beta && stats && P > 0 && P < (1ll << 31) && C > 0 && ldx >= C && ldy >= C, DSRL_E_BADARG, "bn_train_fwd_from_stats: bad arguments");
+    DSRL_REQUIRE(stats_parts > 0 && stats_parts <= 256, DSRL_E_BADARG, "bn_train_fwd_from_stats: %d row blocks of partials (1..256)", stats_parts);
+    DSRL_REQUIRE(C % 32 == 0 && vec4_ok(C, {ldx, ldy, residual ? ldr : 0}, {x, y, residual}), DSRL_E_UNSUPPORTED,
+                 "bn_train_fwd_from_stats: C (%d) must be a multiple of 32, strides multiples of 4, pointers 16-byte aligned", C);
+    DSRL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, DSRL_E_BADARG, "bn_train_fwd_from_stats: dropout p=%f outside [0,1)", drop_p);
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const int groups = C / 32;
+    int slabs = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(P, 32), ceil_div(4 * 256, groups)));     // ~4 blocks per CU, >= 32 rows each
+    const int rows_per_slab = (int)ceil_div(P, (int64_t)slabs);
+    slabs = (int)ceil_div(P, (int64_t)rows_per_slab);
+    hipLaunchKernelGGL(bn_stats_apply_kernel, dim3((unsigned)(groups * slabs)), dim3(256), 0, st, x, ldx, y, ldy, (int)P, C, groups, rows_per_slab, eps, momentum,
+                       mean, invstd, running_mean, running_var, gamma, beta, residual, ldr, relu, drop_p, (unsigned long long)seed, (unsigned)rng_stream, stats, stats_parts);
+    return launch_status("bn_stats_apply_kernel");
 }
 
 extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,

@@ -44,6 +44,7 @@ struct ConvArgs {
     int mtiles, ntiles, xcd_remap;        // 1-D launch of mtiles*ntiles blocks (x splits in z); XCD-aware tile order when xcd_remap
     int kg;                               // split kernels: K groups per block (1, 2 or 4)
     int accumulate;                       // epilogue: y += result (only without slabs: a split-K launch accumulates in its reduce)
+    float* stats;                         // split kernels, forward: per (row block, channel) BatchNorm partials (n, mean, M2) of the output, or null
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (private L2 each). Remap the linear block id so that every XCD works on a contiguous
@@ -575,6 +576,37 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
                 const int m = mb + (e & 3) + 8 * (e >> 2);
                 const unsigned off = (kok && m < a.M) ? ((unsigned)m * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e] + bv), yr, (int)off, 0, 0);
+            }
+        }
+    }
+    // ---- BatchNorm partials of the tile this wave just wrote: for every output channel (n, mean, M2) over the wave's 32*MR rows,
+    //      two passes over the registers (exact centred second moment), the two lanes that share a channel combined with one shuffle.
+    //      Layout [3][mtiles * WGM][K] = what bn_partial4_kernel writes, consumed by dsrl_bn_train_fwd_from_stats.
+    if (a.stats != nullptr && a.splits == 1) {
+        const int nparts = a.mtiles * WGM, part = (tile / a.ntiles) * WGM + wm;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int k = n0 + (wn * NR + j) * 32 + col;
+            const bool kok = k < a.K;
+            const float bv = (a.bias != nullptr && kok) ? a.bias[k] : 0.f;
+            float n = 0.f, sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (m0 + (wm * MR + i) * 32 + rq + (e & 3) + 8 * (e >> 2) < a.M) { n += 1.f; sum += acc[i][j][e] + bv; }
+            n += __shfl_xor(n, 32); sum += __shfl_xor(sum, 32);
+            const float mean = n > 0.f ? sum / n : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (m0 + (wm * MR + i) * 32 + rq + (e & 3) + 8 * (e >> 2) < a.M) { const float d = acc[i][j][e] + bv - mean; q += d * d; }
+            q += __shfl_xor(q, 32);
+            if (lane < 32 && kok) {
+                float* o = a.stats + (long long)part * a.K + k;
+                o[0] = n; o[(long long)nparts * a.K] = mean; o[2ll * nparts * a.K] = q;
             }
         }
     }
@@ -1354,9 +1386,25 @@ extern "C" size_t dsrl_conv2d_fwd_workspace_bytes(int N, int H, int W, int C, in
     return plan_fwd_ws(N, H, W, C, K, R, S, Ho, Wo);
 }
 
-extern "C" int dsrl_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
-                               int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                               void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+// rows blocks of BatchNorm partials a forward launch of this shape writes in the current arithmetic mode (0 = it cannot: fp32 kernels,
+// split-K slabs, or more than 256 row blocks)
+static int fwd_stats_parts(const FwdPlan& p, int npl) {
+    if (!npl || p.splits > 1) return 0;
+    int bm, bn; cfg_dims(p.cfg, bm, bn);
+    static const int kWGM[kNumCfg] = {2, 4, 4, 2, 2, 2, 4};          // waves along M per block tile, DSRL_CFG_SWITCH order
+    const long long parts = ceil_div(p.M, bm) * kWGM[p.cfg];
+    return parts <= 256 ? (int)parts : 0;
+}
+extern "C" int dsrl_conv2d_fwd_stats_parts(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
+    const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
+    if (Ho <= 0 || Wo <= 0 || C % 4) return 0;
+    const int npl = conv_planes(PASS_FWD);
+    return fwd_stats_parts(plan_fwd(N, H, W, C, K, R, S, Ho, Wo, npl), npl);
+}
+
+static int fwd_impl(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                    int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                    void* ws, size_t ws_bytes, dsrl_stream_t stream, float* stats, int stats_parts) {
     if (int e = check_conv(x, w, y, N, H, W, C, K, R, S, stride, pad, dil)) return e;
     DSRL_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, DSRL_E_UNSUPPORTED,
                  "conv2d_fwd: C (%d) and ldx (%d) must be multiples of 4 and x,w 16-byte aligned", C, ldx);
@@ -1381,8 +1429,26 @@ extern "C" int dsrl_conv2d_fwd(const float* x, int ldx, const float* w, const fl
                            (const float*)ws, p.splits, a.slab, p.M, K, bias, y, ldy);
         return launch_status("splitk_reduce_kernel");
     }
+    if (stats != nullptr) {
+        DSRL_REQUIRE(fwd_stats_parts(p, conv_planes(PASS_FWD)) == stats_parts && stats_parts > 0, DSRL_E_BADARG,
+                     "conv2d_fwd_stats: this launch writes %d row blocks of partials, the caller expects %d (dsrl_conv2d_fwd_stats_parts)",
+                     fwd_stats_parts(p, conv_planes(PASS_FWD)), stats_parts);
+        a.stats = stats;
+    }
     a.y = y; a.ldy = ldy; a.bias = bias;
     return launch_igemm<false>(a, p.cfg, st);
+}
+
+extern "C" int dsrl_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                               int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                               void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    return fwd_impl(x, ldx, w, bias, y, ldy, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, nullptr, 0);
+}
+extern "C" int dsrl_conv2d_fwd_stats(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                     void* ws, size_t ws_bytes, float* stats, int stats_parts, dsrl_stream_t stream) {
+    DSRL_REQUIRE(stats != nullptr, DSRL_E_BADARG, "conv2d_fwd_stats: null statistics buffer");
+    return fwd_impl(x, ldx, w, bias, y, ldy, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, stats, stats_parts);
 }
 
 // dgrad = the same implicit GEMM with dy as the input tensor, the transposed filter wt[c][tap][k] and the

@@ -291,7 +291,7 @@ def fork(x):
 # ------------------------------------------------------------------------------------------------ conv2d
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil, gslot=None):
+    def forward(ctx, x, w, bias, stride, pad, dil, gslot=None, stats_parts=0):
         ctx.gslot = gslot
         x, ldx = pm_vec4(x)
         w_param = w
@@ -306,8 +306,14 @@ class _Conv2d(torch.autograd.Function):
         ws = _ws(cquery('dsrl_conv2d_fwd_workspace_bytes', *shp), x)
         if bias is not None:
             _need_gpu(bias)
-        call('dsrl_conv2d_fwd', x.data_ptr(), ldx, w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), K,
-             *shp, ws.data_ptr(), ws.numel(), _stream())
+        stats = None
+        if stats_parts > 0:         # BatchNorm partials of y from the conv epilogue (include/dsrl_hip.h: dsrl_conv2d_fwd_stats)
+            stats = torch.empty(3 * stats_parts * K, device=x.device, dtype=torch.float32)
+            call('dsrl_conv2d_fwd_stats', x.data_ptr(), ldx, w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), K,
+                 *shp, ws.data_ptr(), ws.numel(), stats.data_ptr(), int(stats_parts), _stream())
+        else:
+            call('dsrl_conv2d_fwd', x.data_ptr(), ldx, w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), K,
+                 *shp, ws.data_ptr(), ws.numel(), _stream())
         ctx.save_for_backward(x, w)
         ctx.shp = shp
         ctx.has_bias = bias is not None
@@ -324,10 +330,13 @@ class _Conv2d(torch.autograd.Function):
                 ev.record(side)
             w.record_stream(side)
             ctx.wt = (wt, ev)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         x, w = ctx.saved_tensors
         shp = ctx.shp
         N, H, W, Cc, K, R, S, stride, pad, dil = shp
@@ -383,7 +392,7 @@ class _Conv2d(torch.autograd.Function):
             db = torch.empty(K, device=x.device, dtype=torch.float32)
             ws = _ws(cquery('dsrl_colsum_workspace_bytes', P, K), x)
             call('dsrl_colsum', dy.data_ptr(), lddy, P, K, db.data_ptr(), ws.data_ptr(), ws.numel(), st)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class _StemConv(torch.autograd.Function):
@@ -448,7 +457,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, grad_slot=None
 # ------------------------------------------------------------------------------------------------ BatchNorm (+res, relu, dropout)
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, drop_p, seed, rng_stream, residual, rslot=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, drop_p, seed, rng_stream, residual, rslot=None,
+                stats=None, stats_parts=0):
         ctx.rslot = rslot
         x, ldx = pm(x)
         _need_gpu(gamma, beta, running_mean, running_var)
@@ -466,10 +476,16 @@ class _BNAct(torch.autograd.Function):
             ws = _ws(cquery('dsrl_bn_workspace_bytes', P, Cc), x)
             mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
             invstd = torch.empty_like(mean)
-            call('dsrl_bn_train_fwd', x.data_ptr(), ldx, y.data_ptr(), Cc, P, Cc, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
-                 None if running_mean is None else running_mean.data_ptr(), None if running_var is None else running_var.data_ptr(),
-                 gamma.data_ptr(), beta.data_ptr(), res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream),
-                 ws.data_ptr(), ws.numel(), st)
+            if stats is not None and stats_parts > 0:
+                call('dsrl_bn_train_fwd_from_stats', x.data_ptr(), ldx, y.data_ptr(), Cc, P, Cc, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
+                     None if running_mean is None else running_mean.data_ptr(), None if running_var is None else running_var.data_ptr(),
+                     gamma.data_ptr(), beta.data_ptr(), res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream),
+                     stats.data_ptr(), int(stats_parts), st)
+            else:
+                call('dsrl_bn_train_fwd', x.data_ptr(), ldx, y.data_ptr(), Cc, P, Cc, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
+                     None if running_mean is None else running_mean.data_ptr(), None if running_var is None else running_var.data_ptr(),
+                     gamma.data_ptr(), beta.data_ptr(), res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream),
+                     ws.data_ptr(), ws.numel(), st)
         else:
             mean = running_mean
             invstd = torch.empty(Cc, device=x.device, dtype=torch.float32)
@@ -510,17 +526,40 @@ class _BNAct(torch.autograd.Function):
                 ctx.rslot.buf = dres            # published: a later dgrad of the same input accumulates into it (GradSlot)
             else:
                 ctx.rslot.closed = True
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, dres, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, dres, None, None, None
 
 
-def batch_norm_act(x, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual=None, residual_grad_slot=None):
+def batch_norm_act(x, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual=None, residual_grad_slot=None, stats=None):
     """BatchNorm2d `bn` (an nn.BatchNorm2d holding the parameters/buffers) + optional residual add, ReLU, Dropout."""
     training = bn.training or bn.running_mean is None
     if training and bn.running_mean is not None:
         bn._dsrl_batches = getattr(bn, '_dsrl_batches', 0) + 1      # flushed into num_batches_tracked by HipBatchNorm2d.state_dict
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, relu,
-                        drop_p if training or drop_p == 0.0 else 0.0, seed, rng_stream, residual, residual_grad_slot if residual is not None else None)
+                        drop_p if training or drop_p == 0.0 else 0.0, seed, rng_stream, residual, residual_grad_slot if residual is not None else None,
+                        stats[0] if (stats is not None and training) else None, stats[1] if (stats is not None and training) else 0)
+
+
+# BatchNorm statistics from the conv epilogue: the conv that feeds a training-mode BN leaves (n, mean, M2) partials of its output, and
+# the BN becomes one streaming kernel without a statistics pass (dsrl_conv2d_fwd_stats + dsrl_bn_train_fwd_from_stats)
+conv_bn_stats_enabled = os.environ.get('DSRL_CONV_BN_STATS', '1') != '0'
+
+
+def conv2d_bn_act(x, weight, bias, stride, padding, dilation, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual=None,
+                  grad_slot=None, residual_grad_slot=None):
+    """batch_norm_act(conv2d(x, ...), bn, ...) with the BN batch statistics taken from the conv epilogue when the launch can provide
+    them (split-precision kernels, no split-K, <= 256 row blocks, out channels a multiple of 32)."""
+    training = bn.training or bn.running_mean is None
+    K, C = weight.shape[0], x.shape[1]
+    if conv_bn_stats_enabled and training and x.is_cuda and C % 4 == 0 and K % 32 == 0:
+        N, _, H, W = x.shape
+        parts = int(query('dsrl_conv2d_fwd_stats_parts', N, H, W, C, K, weight.shape[2], weight.shape[3], int(stride), int(padding), int(dilation)))
+        if parts > 0:
+            y, stats = _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation), grad_slot, parts)
+            return batch_norm_act(y, bn, relu=relu, drop_p=drop_p, seed=seed, rng_stream=rng_stream, residual=residual,
+                                  residual_grad_slot=residual_grad_slot, stats=(stats, parts))
+    return batch_norm_act(conv2d(x, weight, bias, stride, padding, dilation, grad_slot=grad_slot), bn, relu=relu, drop_p=drop_p, seed=seed,
+                          rng_stream=rng_stream, residual=residual, residual_grad_slot=residual_grad_slot)
 
 
 class _Dropout(torch.autograd.Function):

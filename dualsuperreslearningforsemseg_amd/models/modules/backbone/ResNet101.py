@@ -38,16 +38,18 @@ class Bottleneck(t.nn.Module):
             x, slot = HF.fork(x), HF.GradSlot()
         if self.downsample is None:
             identity = x
-        elif slot is not None and len(self.downsample) == 2 and isinstance(self.downsample[0], HipConv2d) and self.downsample[0].bias is None:
+        elif len(self.downsample) == 2 and isinstance(self.downsample[0], HipConv2d) and self.downsample[0].bias is None:
             ds = self.downsample[0]
-            identity = HF.batch_norm_act(HF.conv2d(x, ds.weight, None, ds.stride[0], ds.padding[0], ds.dilation[0], grad_slot=slot), self.downsample[1])
+            identity = HF.conv2d_bn_act(x, ds.weight, None, ds.stride[0], ds.padding[0], ds.dilation[0], self.downsample[1], grad_slot=slot)
         else:
+            if slot is not None:
+                slot.closed = True
             identity = self.downsample(x)
-        c1 = self.conv1
-        out = HF.batch_norm_act(HF.conv2d(x, c1.weight, None, c1.stride[0], c1.padding[0], c1.dilation[0], grad_slot=slot), self.bn1, relu=True)
-        out = HF.batch_norm_act(self.conv2(out), self.bn2, relu=True)
-        return HF.batch_norm_act(self.conv3(out), self.bn3, relu=True, residual=identity,              # bn3 + identity, then ReLU
-                                 residual_grad_slot=slot if self.downsample is None else None)
+        c1, c2, c3 = self.conv1, self.conv2, self.conv3
+        out = HF.conv2d_bn_act(x, c1.weight, None, c1.stride[0], c1.padding[0], c1.dilation[0], self.bn1, relu=True, grad_slot=slot)
+        out = HF.conv2d_bn_act(out, c2.weight, None, c2.stride[0], c2.padding[0], c2.dilation[0], self.bn2, relu=True)
+        return HF.conv2d_bn_act(out, c3.weight, None, c3.stride[0], c3.padding[0], c3.dilation[0], self.bn3, relu=True, residual=identity,   # bn3 + identity, ReLU
+                                residual_grad_slot=slot if self.downsample is None else None)
 
 
 class ResNet101(t.nn.Module):

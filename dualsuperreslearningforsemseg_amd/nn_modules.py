@@ -119,6 +119,20 @@ class HipSequential(nn.Sequential):
                 i = j
             elif isinstance(m, nn.ReLU):
                 raise HF.DsrlHipError('HipSequential: ReLU must follow a BatchNorm2d')
+            elif (isinstance(m, HipConv2d) and i + 1 < n and isinstance(mods[i + 1], nn.BatchNorm2d) and m.groups == 1 and m.padding_mode == 'zeros'
+                  and not (m.out_channels == 1 and m.kernel_size == (1, 1) and m.bias is None and m.in_channels % 4 != 0)):
+                # conv -> BN (-> ReLU -> Dropout): the conv epilogue provides the BN statistics when it can (HF.conv2d_bn_act)
+                bn = mods[i + 1]
+                relu = i + 2 < n and isinstance(mods[i + 2], nn.ReLU)
+                j = i + (3 if relu else 2)
+                p, stream = 0.0, 0
+                if relu and j < n and isinstance(mods[j], nn.Dropout):
+                    if mods[j].training and mods[j].p > 0:
+                        p, stream = mods[j].p, getattr(mods[j], 'rng_stream', 0)
+                    j += 1
+                x = HF.conv2d_bn_act(x, m.weight, m.bias, _single(m.stride), _single(m.padding), _single(m.dilation), bn, relu=relu, drop_p=p, seed=seed,
+                                     rng_stream=stream, residual=residual if j >= n else None, grad_slot=grad_slot if i == 0 else None)
+                i = j
             else:
                 x = m(x, grad_slot=grad_slot) if (i == 0 and grad_slot is not None and isinstance(m, HipConv2d)) else m(x)
                 i += 1

@@ -51,6 +51,14 @@ size_t dsrl_conv2d_fwd_workspace_bytes(int N, int H, int W, int C, int K, int R,
 int dsrl_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias /*nullable*/, float* y, int ldy,
                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                     void* ws, size_t ws_bytes, dsrl_stream_t stream);
+/* The same conv that additionally leaves BatchNorm partials of its output in `stats`: [3][parts][K] floats = (count, mean, centred
+ * second moment) per (block of output rows, output channel), parts = dsrl_conv2d_fwd_stats_parts(shape) for the current arithmetic mode
+ * (0: this launch cannot provide them - exact-fp32 kernels, split-K slabs, more than 256 row blocks). The BatchNorm that follows
+ * (ASPP.py:19-20, DSRL.py:22-24,36-40,44-48, every ResNet block) then skips its own statistics pass: dsrl_bn_train_fwd_from_stats. */
+int dsrl_conv2d_fwd_stats_parts(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
+int dsrl_conv2d_fwd_stats(const float* x, int ldx, const float* w, const float* bias /*nullable*/, float* y, int ldy,
+                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                          void* ws, size_t ws_bytes, float* stats, int stats_parts, dsrl_stream_t stream);
 /* dx (N,H,W,C) from dy (N,Ho,Wo,K). The kernel reads the filter as wt[c][tap][k] (k padded to a multiple of 4): pass `wt` from
  * dsrl_conv2d_transpose_filter (e.g. built during the forward pass on another stream) or NULL to have it built here in `ws`. */
 size_t dsrl_conv2d_transposed_filter_floats(int C, int K, int R, int S);
@@ -124,6 +132,12 @@ int dsrl_bn_apply(const float* x, int ldx, float* y, int ldy, int64_t P, int C,
                   const float* mean, const float* invstd, const float* gamma, const float* beta,
                   const float* residual /*nullable*/, int ldr, int relu, float drop_p, uint64_t seed, uint32_t rng_stream,
                   dsrl_stream_t stream);
+/* dsrl_bn_train_fwd with the batch statistics taken from the partials a preceding dsrl_conv2d_fwd_stats left behind (C a multiple of 32):
+ * one streaming kernel, no statistics pass over x, no device-wide barrier. Same outputs as dsrl_bn_train_fwd. */
+int dsrl_bn_train_fwd_from_stats(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,
+                                 float* running_mean /*nullable*/, float* running_var /*nullable*/, const float* gamma, const float* beta,
+                                 const float* residual /*nullable*/, int ldr, int relu, float drop_p, uint64_t seed, uint32_t rng_stream,
+                                 const float* stats, int stats_parts, dsrl_stream_t stream);
 /* The fused small-tensor BN kernels (dsrl_bn_train_fwd / dsrl_bn_bwd) cross a device-wide barrier: all blocks of a launch (128, or
  * 256 for tensors of 4.2-8.4 M elements; one 512-thread block per CU) must become resident together, so they assume that the process
  * has the GPU to itself apart from its own streams. dsrl_bn_fused_max_blocks: 0 = never use them, 128 = the 128-block variant only (what

@@ -275,6 +275,39 @@ def test_batchnorm_frozen_statistics_backward(C):
     check(host(bn.running_mean), rm, 0.0); check(host(bn.running_var), rv, 0.0)
 
 
+@pytest.mark.parametrize('shape', [(8, 256, 16, 32, 256, 3, 1, 1, 1), (3, 64, 33, 47, 96, 3, 2, 1, 1), (2, 128, 9, 13, 64, 1, 1, 0, 1), (8, 64, 64, 128, 64, 3, 1, 1, 1)])
+def test_conv_epilogue_bn_statistics(shape):
+    """conv2d_bn_act: BatchNorm batch statistics from the conv epilogue (dsrl_conv2d_fwd_stats -> dsrl_bn_train_fwd_from_stats) against
+    the separate conv + BN path and the oracle; ragged row counts (33x47 maps), channel tails of the last tile (96 = 64 + 32), a shape
+    with more than 256 row blocks (falls back by itself), residual + ReLU, and the backward pass through both."""
+    N, C, H, W, K, R, stride, pad, dil = shape
+    rs = np.random.RandomState(sum(shape))
+    x = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rs.standard_normal((K, C, R, R)) / np.sqrt(C * R * R)).astype(np.float32)
+    gamma = rs.uniform(0.5, 1.5, K).astype(np.float32); beta = rs.standard_normal(K).astype(np.float32)
+    yo = O.conv2d(x.astype(np.float64), w.astype(np.float64), None, stride, pad, dil)
+    res = rs.standard_normal(yo.shape).astype(np.float32); dy = rs.standard_normal(yo.shape).astype(np.float32)
+    out = {}
+    old = HF.conv_bn_stats_enabled
+    try:
+        for enabled in (True, False):
+            HF.conv_bn_stats_enabled = enabled
+            bn = D.nn_modules.HipBatchNorm2d(K).to(DEV).train()
+            with torch.no_grad():
+                bn.weight.copy_(dev(gamma)); bn.bias.copy_(dev(beta))
+            xt = dev(x).requires_grad_(True); wt = torch.nn.Parameter(dev(w)); rt = dev(res).requires_grad_(True)
+            y = HF.conv2d_bn_act(xt, wt, None, stride, pad, dil, bn, relu=True, residual=rt)
+            y.backward(dev(dy))
+            out[enabled] = [host(v) for v in (y, xt.grad, wt.grad, rt.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)]
+    finally:
+        HF.conv_bn_stats_enabled = old
+    names = ('y', 'dx', 'dw', 'dres', 'dgamma', 'dbeta', 'running_mean', 'running_var')
+    for a, b, name in zip(out[True], out[False], names):
+        check(a, b, 2e-5 if name in ('y', 'dres', 'running_mean', 'running_var') else 5e-4, 'epilogue statistics vs separate path: ' + name)
+    bo, (mean, invstd), (rm, rv) = O.batchnorm_train(yo, gamma.astype(np.float64), beta.astype(np.float64), np.zeros(K), np.ones(K))
+    check(out[True][0], np.maximum(bo + res, 0), 2e-5, 'y vs oracle'); check(out[True][6], rm, 1e-5, 'running_mean'); check(out[True][7], rv, 1e-5, 'running_var')
+
+
 def test_batchnorm_fused_budget_and_timeout_counter():
     """Budget 0 selects the three-kernel path, 128 keeps the 256-block variant off; no launch of this suite ever timed out at the barrier."""
     rs = np.random.RandomState(11)
