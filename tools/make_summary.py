@@ -22,8 +22,9 @@ tot = sum(float(r['TotalDurationNs']) for r in rows) / 1e6 / steps
 groups = [('conv_igemm_split_kernel<bf16x6> (forward)', lambda n: 'conv_igemm_split' in n and 'false, 3' in n),
           ('conv_wgrad_split_kernel<bf16x3>', lambda n: 'conv_wgrad_split' in n),
           ('conv_igemm_split_kernel<bf16x3> (dgrad)', lambda n: 'conv_igemm_split' in n and 'true, 2' in n),
-          ('bn_fused_fwd_kernel / bn_fused_bwd_kernel (105 layers)', lambda n: 'bn_fused' in n),
-          ('bn_* three-kernel path (8 large / odd-width layers)', lambda n: 'bn_' in n and 'bn_fused' not in n),
+          ('bn_stats_apply_kernel (forward, statistics from the conv epilogue: 83 layers)', lambda n: 'bn_stats_apply' in n),
+          ('bn_fused_fwd_kernel (22 layers) / bn_fused_bwd_kernel (105 layers)', lambda n: 'bn_fused' in n),
+          ('bn_* three-kernel path (8 large / odd-width layers)', lambda n: 'bn_' in n and 'bn_fused' not in n and 'bn_stats_apply' not in n),
           ('wgrad_reduce_kernel', lambda n: 'wgrad_reduce' in n),
           ('torch elementwise add (remaining gradient accumulation)', lambda n: 'CUDAFunctor_add' in n),
           ('weight_transpose_batched_kernel (1 launch/step)', lambda n: 'weight_transpose' in n),
@@ -60,7 +61,7 @@ bench.py HIP events, exclusive pass (library bracket = kernel + its slab-reduce 
 for k, v in r['all_mfma_kernels'].items():
     txt += f"* {k}: {v['ms_per_step']} ms/step, {v['tflops']} algorithmic TFLOP/s = {v['frac']:.3f} of {v['peak']} TF; algorithmic bytes/launch {v['algorithmic_bytes_per_launch']/1e6:.1f} MB\n"
 txt += '\nHBM traffic per launch (PMC, FETCH_SIZE x2 + WRITE_SIZE): ' + '; '.join(f"{k}: {v['hbm_bytes_per_launch']/1e6:.1f} MB" for k, v in pm.items()) + '\n'
-fw, wg, dg, rd = g[groups[0][0]], g[groups[1][0]], g[groups[2][0]], g[groups[5][0]]
+fw, wg, dg, rd = g[groups[0][0]], g[groups[1][0]], g[groups[2][0]], g['wgrad_reduce_kernel']
 txt += f'''
 rocprofv3 average durations vs the event brackets: forward {fw[2]:.1f} us (bracket {1e3*r['all_mfma_kernels'][groups[0][0]]['ms_per_step']/115:.1f} us incl. split-K reduces),
 wgrad {wg[2]:.1f} us + {rd[2]:.1f} us reduce (bracket {1e3*r['all_mfma_kernels'][groups[1][0]]['ms_per_step']/115:.1f} us), dgrad {dg[2]:.1f} us (bracket {1e3*r['all_mfma_kernels'][groups[2][0]]['ms_per_step']/114:.1f} us).
