@@ -13,7 +13,9 @@
  *   - Conv weights are [K][R][S][C] (= torch (K,C,R,S) in channels_last), ConvTranspose weights are the
  *     plain torch layout (Cin,Cout,2,2).
  *   - Every function enqueues on `stream` (a hipStream_t) and returns immediately; no allocation, no host
- *     synchronisation, no global mutable state: re-entrant from the autograd worker thread.
+ *     synchronisation (the two read-out functions dsrl_prof_read and dsrl_bn_fused_barrier_timeouts excepted); re-entrant from
+ *     the autograd worker thread. Process-wide state is limited to three settings (dsrl_conv_precision, dsrl_bn_fused_max_blocks,
+ *     dsrl_prof_enable) and the arrival counter of the fused BatchNorm kernels' device-wide barrier.
  *   - The caller owns all buffers including `ws` (workspace, >= the matching *_workspace_bytes()).
  *   - Return 0 on success, a negative DSRL_E_* otherwise; dsrl_last_error() has the message (thread-local).
  */
@@ -43,7 +45,8 @@ const char* dsrl_last_error(void);
 int dsrl_device_check(int* cu_count);
 
 /* ------------------------------------------------------------------------------------------------
- * conv2d: implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).
+ * conv2d: implicit GEMM on the matrix cores; fp32 in / out / accumulate, products formed as dsrl_conv_precision selects
+ * (default: split-precision bf16 MFMAs, bf16x6 forward = fp32-equivalent, bf16x3 backward; mode 0: v_mfma_f32_32x32x2_f32).
  * replaces nn.Conv2d forward/backward at ASPP.py:10-15,19; DSRL.py:19-23,34-38,42-46,50,78-83 and the
  * ResNet101.py convolutions; x (N,H,W,C) -> y (N,Ho,Wo,K).
  * ---------------------------------------------------------------------------------------------- */
