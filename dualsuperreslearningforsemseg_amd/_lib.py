@@ -35,6 +35,8 @@ PROTOTYPES = {
     'dsrl_conv2d_transpose_filter': (i32, [fp, fp, i32, i32, i32, i32, stream_t]),
     'dsrl_conv2d_transpose_filters_batched': (i32, [fp, i32, i64, stream_t]),
     'dsrl_conv2d_dgrad': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, stream_t]),
+    'dsrl_conv2d_dgrad_stats_parts': (i32, _conv_shape),
+    'dsrl_conv2d_dgrad_bnstats': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, fp, i32, fp, fp, i32, fp, i32, stream_t]),
     'dsrl_conv2d_dgrad_accumulate': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv2d_wgrad_workspace_bytes': (sz, _conv_shape),
     'dsrl_conv2d_wgrad': (i32, [fp, i32, fp, i32, fp] + _conv_shape + [fp, sz, stream_t]),
@@ -56,6 +58,7 @@ PROTOTYPES = {
     'dsrl_bn_train_fwd_from_stats': (i32, [fp, i32, fp, i32, i64, i32, f32, f32, fp, fp, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, fp, i32, stream_t]),
     'dsrl_bn_train_fwd': (i32, [fp, i32, fp, i32, i64, i32, f32, f32, fp, fp, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, fp, sz, stream_t]),
     'dsrl_bn_bwd': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, f32, i32, fp, sz, stream_t]),
+    'dsrl_bn_bwd_from_stats': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, i32, fp, i32, stream_t]),
     'dsrl_dropout_fwd': (i32, [fp, i32, fp, i32, i64, i32, f32, u64, u32, stream_t]),
     'dsrl_dropout_bwd': (i32, [fp, i32, fp, i32, i64, i32, f32, u64, u32, stream_t]),
     'dsrl_bilinear_ac_fwd': (i32, [fp, i32, fp, i32, i32, i32, i32, i32, i32, i32, stream_t]),

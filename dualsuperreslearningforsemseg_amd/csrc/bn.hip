@@ -786,6 +786,73 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(const float* __rest
     }
 }
 
+
+// BN backward from dgrad-epilogue partials: the conv whose data gradient IS this BatchNorm's output gradient already left
+// sum(g) and sum(g * xhat) per (row block, channel) (conv_igemm_split_kernel, DGRAD epilogue); merge them for the block's 32
+// channels (fp64, fixed order) and stream x, y, dy -> dx once.  No reduction pass, no device-wide barrier.
+__global__ __launch_bounds__(256) void bn_bwd_stats_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
+                                                                  const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
+                                                                  float* __restrict__ dres, int lddr, int P, int C, int groups, int rows_per_slab,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int relu, int training,
+                                                                  const float* __restrict__ part, int nparts) {
+    __shared__ double shm[8][2][32];
+    __shared__ float fin[2][32];
+    const int grp = blockIdx.x % groups, slab = blockIdx.x / groups;
+    const int tid = threadIdx.x, l8 = tid & 7, rr = tid >> 3;
+    const int q = grp * 8 + l8;
+    {
+        const int ch = tid & 31, k = tid >> 5;
+        const float* pa = part + grp * 32 + ch;
+        const float* pb = pa + (long long)nparts * C;
+        double a = 0, b = 0;
+        for (int base = k; base < nparts; base += 32) {
+            float va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sl = min(base + 8 * u, nparts - 1);
+                va[u] = pa[(long long)sl * C]; vb[u] = pb[(long long)sl * C];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (base + 8 * u < nparts) { a += va[u]; b += vb[u]; }
+        }
+        shm[k][0][ch] = a; shm[k][1][ch] = b;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a += shm[k][0][tid]; b += shm[k][1][tid]; }
+        const float inv_n = 1.f / (float)P;
+        fin[0][tid] = training ? (float)a * inv_n : 0.f; fin[1][tid] = training ? (float)b * inv_n : 0.f;
+        if (slab == 0) {
+            const int c = grp * 32 + tid;
+            if (dbeta) dbeta[c] = (float)a;
+            if (dgamma) dgamma[c] = (float)b;
+        }
+    }
+    __syncthreads();
+    float mu[4], is[4], gi[4], mb[4], mg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * q + j;
+        mu[j] = mean[c]; is[j] = invstd[c]; gi[j] = gamma[c] * is[j]; mb[j] = fin[0][4 * l8 + j]; mg[j] = fin[1][4 * l8 + j];
+    }
+    const int row0 = slab * rows_per_slab, row1 = min(P, row0 + rows_per_slab);
+#pragma unroll 2
+    for (int p = row0 + rr; p < row1; p += 32) {
+        const float4 dv = LD4(dy, p, lddy, q), xv = LD4(x, p, ldx, q);
+        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (relu) yv = LD4(y, p, ldy, q);
+        const float g0 = masked_grad(dv.x, yv.x, relu, 0.f, 1.f), g1 = masked_grad(dv.y, yv.y, relu, 0.f, 1.f);
+        const float g2 = masked_grad(dv.z, yv.z, relu, 0.f, 1.f), g3 = masked_grad(dv.w, yv.w, relu, 0.f, 1.f);
+        ST4(dx, p, lddx, q) = make_float4(gi[0] * (g0 - mb[0] - (xv.x - mu[0]) * is[0] * mg[0]), gi[1] * (g1 - mb[1] - (xv.y - mu[1]) * is[1] * mg[1]),
+                                          gi[2] * (g2 - mb[2] - (xv.z - mu[2]) * is[2] * mg[2]), gi[3] * (g3 - mb[3] - (xv.w - mu[3]) * is[3] * mg[3]));
+        if (dres) ST4(dres, p, lddr, q) = make_float4(g0, g1, g2, g3);
+    }
+}
+
 static bool vec4_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
     if (C % 4) return false;
     for (int l : lds) if (l % 4) return false;
@@ -982,6 +1049,25 @@ extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, con
         hipLaunchKernelGGL(bn_bwd_apply_kernel, apply_grid(P, C), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (long long)P, C,
                            mean, invstd, gamma, (const float*)sums, relu, drop_p, training);
     return launch_status("bn_bwd_apply_kernel");
+}
+
+extern "C" int dsrl_bn_bwd_from_stats(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
+                                      float* dresidual, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
+                                      float* dgamma, float* dbeta, int relu, int training, const float* stats, int stats_parts, dsrl_stream_t stream) {
+    DSRL_REQUIRE(x && dy && dx && mean && invstd && gamma && stats && P > 0 && P < (1ll << 31) && C > 0, DSRL_E_BADARG, "bn_bwd_from_stats: bad arguments");
+    DSRL_REQUIRE(y || !relu, DSRL_E_BADARG, "bn_bwd_from_stats: forward output needed for the relu mask");
+    DSRL_REQUIRE(stats_parts > 0 && stats_parts <= 256, DSRL_E_BADARG, "bn_bwd_from_stats: %d row blocks of partials (1..256)", stats_parts);
+    DSRL_REQUIRE(C % 32 == 0 && vec4_ok(C, {ldx, y ? ldy : 0, lddy, lddx, dresidual ? lddr : 0}, {x, y, dy, dx, dresidual}), DSRL_E_UNSUPPORTED,
+                 "bn_bwd_from_stats: C (%d) must be a multiple of 32, strides multiples of 4, pointers 16-byte aligned", C);
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const int groups = C / 32;
+    int slabs = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(P, 32), ceil_div(4 * 256, groups)));
+    const int rows_per_slab = (int)ceil_div(P, (int64_t)slabs);
+    slabs = (int)ceil_div(P, (int64_t)rows_per_slab);
+    hipLaunchKernelGGL(bn_bwd_stats_apply_kernel, dim3((unsigned)(groups * slabs)), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (int)P, C,
+                       groups, rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, training, stats, stats_parts);
+    return launch_status("bn_bwd_stats_apply_kernel");
 }
 
 extern "C" int dsrl_colsum(const float* x, int ld, int64_t P, int C, float* out, void* ws, size_t ws_bytes, dsrl_stream_t stream) {

@@ -45,6 +45,10 @@ struct ConvArgs {
     int kg;                               // split kernels: K groups per block (1, 2 or 4)
     int accumulate;                       // epilogue: y += result (only without slabs: a split-K launch accumulates in its reduce)
     float* stats;                         // split kernels, forward: per (row block, channel) BatchNorm partials (n, mean, M2) of the output, or null
+    // split kernels, dgrad: the output is the gradient w.r.t. the output y = relu(bn(x)) of a BatchNorm; the epilogue leaves the
+    // partial sums of g = dy * [y > 0] and g * xhat per (row block, channel) in bstats [2][parts][K] (null: off)
+    const float* bn_x; const float* bn_y; const float* bn_mean; const float* bn_invstd; float* bstats;
+    int bn_ldx, bn_ldy, bn_relu;
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (private L2 each). Remap the linear block id so that every XCD works on a contiguous
@@ -582,6 +586,41 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
     // ---- BatchNorm partials of the tile this wave just wrote: for every output channel (n, mean, M2) over the wave's 32*MR rows,
     //      two passes over the registers (exact centred second moment), the two lanes that share a channel combined with one shuffle.
     //      Layout [3][mtiles * WGM][K] = what bn_partial4_kernel writes, consumed by dsrl_bn_train_fwd_from_stats.
+    if (DGRAD && a.bstats != nullptr && a.splits == 1) {
+        // BatchNorm-backward partials of the gradient tile just written (values as stored: acc, no bias in a dgrad)
+        const int nparts = a.mtiles * WGM, part = (tile / a.ntiles) * WGM + wm;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int k = n0 + (wn * NR + j) * 32 + col;
+            const bool kok = k < a.K;
+            const float mu = kok ? a.bn_mean[k] : 0.f, is = kok ? a.bn_invstd[k] : 0.f;
+            float sg = 0.f, sgx = 0.f;
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                float xv[16], yv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {          // all loads of the tile first
+                    const int m = m0 + (wm * MR + i) * 32 + rq + (e & 3) + 8 * (e >> 2);
+                    const bool ok = kok && m < a.M;
+                    xv[e] = ok ? a.bn_x[(long long)m * a.bn_ldx + k] : 0.f;
+                    yv[e] = (ok && a.bn_relu) ? a.bn_y[(long long)m * a.bn_ldy + k] : 1.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + (wm * MR + i) * 32 + rq + (e & 3) + 8 * (e >> 2);
+                    if (kok && m < a.M) {
+                        const float g = (a.bn_relu && !(yv[e] > 0.f)) ? 0.f : acc[i][j][e];
+                        sg += g; sgx += g * ((xv[e] - mu) * is);
+                    }
+                }
+            }
+            sg += __shfl_xor(sg, 32); sgx += __shfl_xor(sgx, 32);
+            if (lane < 32 && kok) {
+                float* o = a.bstats + (long long)part * a.K + k;
+                o[0] = sg; o[(long long)nparts * a.K] = sgx;
+            }
+        }
+    }
     if (a.stats != nullptr && a.splits == 1) {
         const int nparts = a.mtiles * WGM, part = (tile / a.ntiles) * WGM + wm;
 #pragma unroll
@@ -1480,9 +1519,10 @@ extern "C" int dsrl_conv2d_transpose_filters_batched(const int64_t* table, int n
     return launch_status("weight_transpose_batched_kernel");
 }
 
+struct DgradBn { const float* x; const float* y; const float* mean; const float* invstd; float* stats; int ldx, ldy, relu; };
 static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                      void* ws, size_t ws_bytes, dsrl_stream_t stream, int accumulate) {
+                      void* ws, size_t ws_bytes, dsrl_stream_t stream, int accumulate, const DgradBn* bn = nullptr) {
     if (int e = check_conv(dy, w, dx, N, H, W, C, K, R, S, stride, pad, dil)) return e;
     const int Kp = pad4(K);     // K % 4 != 0 (cls_conv, 19 classes): dy must be padded to lddy >= Kp with finite pad values
     DSRL_REQUIRE(lddy % 4 == 0 && ((uintptr_t)dy % 16) == 0, DSRL_E_UNSUPPORTED,
@@ -1520,6 +1560,7 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
         return launch_status("splitk_reduce_kernel");
     }
     a.y = dx; a.ldy = lddx; a.bias = nullptr; a.accumulate = accumulate;
+    if (bn) { a.bn_x = bn->x; a.bn_y = bn->y; a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bstats = bn->stats; a.bn_ldx = bn->ldx; a.bn_ldy = bn->ldy; a.bn_relu = bn->relu; }
     return launch_igemm<true>(a, p.cfg, st);
 }
 
@@ -1527,6 +1568,24 @@ extern "C" int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, cons
                                  int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                                  void* ws, size_t ws_bytes, dsrl_stream_t stream) {
     return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, 0);
+}
+// row blocks of BatchNorm-backward partials a dgrad launch of this shape writes in the current arithmetic mode (0 = it cannot)
+extern "C" int dsrl_conv2d_dgrad_stats_parts(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
+    const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
+    if (Ho <= 0 || Wo <= 0) return 0;
+    const int npl = conv_planes(PASS_DGRAD);
+    return fwd_stats_parts(plan_fwd(N, Ho, Wo, pad4(K), C, R, S, H, W, npl), npl);
+}
+extern "C" int dsrl_conv2d_dgrad_bnstats(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
+                                         int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                         void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y, int bn_ldy,
+                                         const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats, int stats_parts, dsrl_stream_t stream) {
+    DSRL_REQUIRE(bn_x && bn_mean && bn_invstd && bstats && (bn_y || !bn_relu) && bn_ldx >= C && (!bn_relu || bn_ldy >= C), DSRL_E_BADARG, "conv2d_dgrad_bnstats: bad BatchNorm arguments");
+    DSRL_REQUIRE(dsrl_conv2d_dgrad_stats_parts(N, H, W, C, K, R, S, stride, pad, dil) == stats_parts && stats_parts > 0, DSRL_E_BADARG,
+                 "conv2d_dgrad_bnstats: this launch writes %d row blocks of partials, the caller expects %d",
+                 dsrl_conv2d_dgrad_stats_parts(N, H, W, C, K, R, S, stride, pad, dil), stats_parts);
+    DgradBn bn{bn_x, bn_y, bn_mean, bn_invstd, bstats, bn_ldx, bn_ldy, bn_relu};
+    return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, 0, &bn);
 }
 extern "C" int dsrl_conv2d_dgrad_accumulate(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
                                             int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

@@ -274,6 +274,21 @@ class GradSlot:
         self.buf, self.closed = None, False
 
 
+# Backward counterpart of conv2d_bn_act: when y = relu(bn(x)) feeds exactly one conv, that conv's data-gradient kernel produces the
+# gradient of y in registers and can leave the BatchNorm-backward partial sums with it (dsrl_conv2d_dgrad_bnstats); the BN backward
+# then runs as one streaming kernel (dsrl_bn_bwd_from_stats).  A BNLink carries what the conv needs from the BN's forward and the
+# partials back; the BN only trusts them if the gradient it receives is the very buffer that conv wrote.
+bn_bwd_stats_enabled = os.environ.get('DSRL_BN_BWD_STATS', '1') != '0'
+
+
+class BNLink:
+    __slots__ = ('x', 'y', 'mean', 'invstd', 'relu', 'valid', 'stats', 'parts', 'dx_ptr')
+
+    def __init__(self):
+        self.x = self.y = self.mean = self.invstd = self.stats = None
+        self.relu, self.valid, self.parts, self.dx_ptr = False, False, 0, 0
+
+
 class _Fork(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -291,8 +306,9 @@ def fork(x):
 # ------------------------------------------------------------------------------------------------ conv2d
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil, gslot=None, stats_parts=0):
+    def forward(ctx, x, w, bias, stride, pad, dil, gslot=None, stats_parts=0, in_link=None):
         ctx.gslot = gslot
+        ctx.in_link = in_link
         x, ldx = pm_vec4(x)
         w_param = w
         w = w_cl(w)
@@ -378,8 +394,22 @@ class _Conv2d(torch.autograd.Function):
                 arena, wt = getattr(ctx.wparam, '_dsrl_arena', None), getattr(ctx.wparam, '_dsrl_wt', None)
                 if wt is not None and arena is not None and arena.wt_valid:
                     wt_ptr = wt.data_ptr()
-            call('dsrl_conv2d_dgrad_accumulate' if acc else 'dsrl_conv2d_dgrad', dy.data_ptr(), lddy, w.data_ptr(), wt_ptr, dx.data_ptr(), Cc, *shp,
-                 ws.data_ptr(), ws.numel(), st)
+            link = ctx.in_link
+            parts = 0
+            if (link is not None and link.valid and not acc and link.y is not None and link.y.data_ptr() == x.data_ptr()
+                    and tuple(link.y.shape) == (N, Cc, H, W) and Cc % 32 == 0):
+                parts = int(query('dsrl_conv2d_dgrad_stats_parts', *shp))
+            if parts > 0:
+                # x is y = relu(bn(.)) of a BatchNorm that feeds only this conv: leave its backward partial sums with the data gradient
+                bstats = torch.empty(2 * parts * Cc, device=x.device, dtype=torch.float32)
+                _, bld = pm(link.x)
+                call('dsrl_conv2d_dgrad_bnstats', dy.data_ptr(), lddy, w.data_ptr(), wt_ptr, dx.data_ptr(), Cc, *shp, ws.data_ptr(), ws.numel(),
+                     link.x.data_ptr(), bld, link.y.data_ptr(), ldx, link.mean.data_ptr(), link.invstd.data_ptr(), int(link.relu),
+                     bstats.data_ptr(), parts, st)
+                link.stats, link.parts, link.dx_ptr = bstats, parts, dx.data_ptr()
+            else:
+                call('dsrl_conv2d_dgrad_accumulate' if acc else 'dsrl_conv2d_dgrad', dy.data_ptr(), lddy, w.data_ptr(), wt_ptr, dx.data_ptr(), Cc, *shp,
+                     ws.data_ptr(), ws.numel(), st)
             if acc:
                 dx = None                   # the contribution went into the buffer autograd already holds for this input
             elif slot is not None:
@@ -392,7 +422,7 @@ class _Conv2d(torch.autograd.Function):
             db = torch.empty(K, device=x.device, dtype=torch.float32)
             ws = _ws(cquery('dsrl_colsum_workspace_bytes', P, K), x)
             call('dsrl_colsum', dy.data_ptr(), lddy, P, K, db.data_ptr(), ws.data_ptr(), ws.numel(), st)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class _StemConv(torch.autograd.Function):
@@ -458,8 +488,9 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, grad_slot=None
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, drop_p, seed, rng_stream, residual, rslot=None,
-                stats=None, stats_parts=0):
+                stats=None, stats_parts=0, out_link=None):
         ctx.rslot = rslot
+        ctx.out_link = out_link
         x, ldx = pm(x)
         _need_gpu(gamma, beta, running_mean, running_var)
         N, Cc, H, W = x.shape
@@ -493,6 +524,8 @@ class _BNAct(torch.autograd.Function):
             call('dsrl_bn_apply', x.data_ptr(), ldx, y.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                  res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream), st)
         ctx.save_for_backward(x, y, mean, invstd, gamma)
+        if out_link is not None and drop_p == 0.0 and Cc % 32 == 0 and ldx == Cc:
+            out_link.x, out_link.y, out_link.mean, out_link.invstd, out_link.relu, out_link.valid = x, y, mean, invstd, bool(relu), True
         ctx.cfg = (bool(training), bool(relu), float(drop_p), residual is not None)
         ctx.gb = (gamma, beta) if isinstance(gamma, torch.nn.Parameter) and isinstance(beta, torch.nn.Parameter) else None
         return y
@@ -513,10 +546,17 @@ class _BNAct(torch.autograd.Function):
             sb = _sink(ctx.gb[1]) if sg is not None else None
         dgamma = sg if sg is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
         dbeta = sb if sb is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
-        ws = _ws(cquery('dsrl_bn_workspace_bytes', P, Cc), x)
-        call('dsrl_bn_bwd', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,
-             None if dres is None else dres.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-             dgamma.data_ptr(), dbeta.data_ptr(), int(relu), drop_p, int(training), ws.data_ptr(), ws.numel(), _stream())
+        link = ctx.out_link
+        if link is not None and link.stats is not None and link.dx_ptr == dy.data_ptr() and lddy == Cc and drop_p == 0.0:
+            # the gradient we received is the buffer the consuming conv's dgrad wrote, and it left our two per-channel sums with it
+            call('dsrl_bn_bwd_from_stats', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,
+                 None if dres is None else dres.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                 dgamma.data_ptr(), dbeta.data_ptr(), int(relu), int(training), link.stats.data_ptr(), int(link.parts), _stream())
+        else:
+            ws = _ws(cquery('dsrl_bn_workspace_bytes', P, Cc), x)
+            call('dsrl_bn_bwd', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,
+                 None if dres is None else dres.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                 dgamma.data_ptr(), dbeta.data_ptr(), int(relu), drop_p, int(training), ws.data_ptr(), ws.numel(), _stream())
         if sg is not None:
             ctx.gb[0]._dsrl_arena.written(ctx.gb[0]); dgamma = None
         if sb is not None:
@@ -526,10 +566,10 @@ class _BNAct(torch.autograd.Function):
                 ctx.rslot.buf = dres            # published: a later dgrad of the same input accumulates into it (GradSlot)
             else:
                 ctx.rslot.closed = True
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, dres, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, dres, None, None, None, None
 
 
-def batch_norm_act(x, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual=None, residual_grad_slot=None, stats=None):
+def batch_norm_act(x, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual=None, residual_grad_slot=None, stats=None, out_link=None):
     """BatchNorm2d `bn` (an nn.BatchNorm2d holding the parameters/buffers) + optional residual add, ReLU, Dropout."""
     training = bn.training or bn.running_mean is None
     if training and bn.running_mean is not None:
@@ -537,7 +577,8 @@ def batch_norm_act(x, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, relu,
                         drop_p if training or drop_p == 0.0 else 0.0, seed, rng_stream, residual, residual_grad_slot if residual is not None else None,
-                        stats[0] if (stats is not None and training) else None, stats[1] if (stats is not None and training) else 0)
+                        stats[0] if (stats is not None and training) else None, stats[1] if (stats is not None and training) else 0,
+                        out_link if bn_bwd_stats_enabled else None)
 
 
 # BatchNorm statistics from the conv epilogue: the conv that feeds a training-mode BN leaves (n, mean, M2) partials of its output, and
@@ -546,7 +587,7 @@ conv_bn_stats_enabled = os.environ.get('DSRL_CONV_BN_STATS', '1') != '0'
 
 
 def conv2d_bn_act(x, weight, bias, stride, padding, dilation, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual=None,
-                  grad_slot=None, residual_grad_slot=None):
+                  grad_slot=None, residual_grad_slot=None, in_link=None, out_link=None):
     """batch_norm_act(conv2d(x, ...), bn, ...) with the BN batch statistics taken from the conv epilogue when the launch can provide
     them (split-precision kernels, no split-K, <= 256 row blocks, out channels a multiple of 32)."""
     training = bn.training or bn.running_mean is None
@@ -555,11 +596,13 @@ def conv2d_bn_act(x, weight, bias, stride, padding, dilation, bn, relu=False, dr
         N, _, H, W = x.shape
         parts = int(query('dsrl_conv2d_fwd_stats_parts', N, H, W, C, K, weight.shape[2], weight.shape[3], int(stride), int(padding), int(dilation)))
         if parts > 0:
-            y, stats = _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation), grad_slot, parts)
+            y, stats = _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation), grad_slot, parts, in_link)
             return batch_norm_act(y, bn, relu=relu, drop_p=drop_p, seed=seed, rng_stream=rng_stream, residual=residual,
-                                  residual_grad_slot=residual_grad_slot, stats=(stats, parts))
-    return batch_norm_act(conv2d(x, weight, bias, stride, padding, dilation, grad_slot=grad_slot), bn, relu=relu, drop_p=drop_p, seed=seed,
-                          rng_stream=rng_stream, residual=residual, residual_grad_slot=residual_grad_slot)
+                                  residual_grad_slot=residual_grad_slot, stats=(stats, parts), out_link=out_link)
+    y = (_Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation), grad_slot, 0, in_link)
+         if (in_link is not None and x.is_cuda and C % 4 == 0) else conv2d(x, weight, bias, stride, padding, dilation, grad_slot=grad_slot))
+    return batch_norm_act(y, bn, relu=relu, drop_p=drop_p, seed=seed, rng_stream=rng_stream, residual=residual,
+                          residual_grad_slot=residual_grad_slot, out_link=out_link)
 
 
 class _Dropout(torch.autograd.Function):

@@ -46,10 +46,14 @@ class Bottleneck(t.nn.Module):
                 slot.closed = True
             identity = self.downsample(x)
         c1, c2, c3 = self.conv1, self.conv2, self.conv3
-        out = HF.conv2d_bn_act(x, c1.weight, None, c1.stride[0], c1.padding[0], c1.dilation[0], self.bn1, relu=True, grad_slot=slot)
-        out = HF.conv2d_bn_act(out, c2.weight, None, c2.stride[0], c2.padding[0], c2.dilation[0], self.bn2, relu=True)
+        # bn1's output feeds only conv2 and bn2's only conv3: their data-gradient kernels leave the BN-backward sums behind (HF.BNLink)
+        l1 = l2 = None
+        if HF.bn_bwd_stats_enabled and t.is_grad_enabled():
+            l1, l2 = HF.BNLink(), HF.BNLink()
+        out = HF.conv2d_bn_act(x, c1.weight, None, c1.stride[0], c1.padding[0], c1.dilation[0], self.bn1, relu=True, grad_slot=slot, out_link=l1)
+        out = HF.conv2d_bn_act(out, c2.weight, None, c2.stride[0], c2.padding[0], c2.dilation[0], self.bn2, relu=True, in_link=l1, out_link=l2)
         return HF.conv2d_bn_act(out, c3.weight, None, c3.stride[0], c3.padding[0], c3.dilation[0], self.bn3, relu=True, residual=identity,   # bn3 + identity, ReLU
-                                residual_grad_slot=slot if self.downsample is None else None)
+                                residual_grad_slot=slot if self.downsample is None else None, in_link=l2)
 
 
 class ResNet101(t.nn.Module):

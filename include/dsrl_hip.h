@@ -74,6 +74,15 @@ size_t dsrl_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int 
 int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, const float* wt /*nullable*/, float* dx, int lddx,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                       void* ws, size_t ws_bytes, dsrl_stream_t stream);
+/* dgrad of a conv whose input was y = relu(bn(x)) (or bn(x)): besides dx = the gradient w.r.t. y, the launch leaves the BatchNorm-backward
+ * partial sums of g = dx * [y > 0] and g * xhat per (block of rows, channel) in bstats [2][parts][C], parts =
+ * dsrl_conv2d_dgrad_stats_parts(shape) (0: this launch cannot - exact-fp32 kernels, split-K slabs, more than 256 row blocks). The
+ * BatchNorm backward then needs no reduction of its own: dsrl_bn_bwd_from_stats. bn_y may be null when bn_relu = 0. */
+int dsrl_conv2d_dgrad_stats_parts(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
+int dsrl_conv2d_dgrad_bnstats(const float* dy, int lddy, const float* w, const float* wt /*nullable*/, float* dx, int lddx,
+                              int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                              void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y /*nullable*/, int bn_ldy,
+                              const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats, int stats_parts, dsrl_stream_t stream);
 /* dx += dgrad(dy, w): the same computation accumulated onto the existing contents of dx (a tensor that feeds two branches receives
  * both gradient contributions in one buffer, e.g. the input of a ResNet bottleneck: ResNet101.py residual add + conv1). */
 int dsrl_conv2d_dgrad_accumulate(const float* dy, int lddy, const float* w, const float* wt /*nullable*/, float* dx, int lddx,
@@ -164,6 +173,12 @@ int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, const float* d
                 const float* mean, const float* invstd, const float* gamma,
                 float* dgamma, float* dbeta, int relu, float drop_p, int training,
                 void* ws, size_t ws_bytes, dsrl_stream_t stream);
+/* dsrl_bn_bwd (without dropout) with the two per-channel sums taken from the partials of dsrl_conv2d_dgrad_bnstats: one streaming kernel,
+ * no reduction pass, no device-wide barrier (C a multiple of 32). */
+int dsrl_bn_bwd_from_stats(const float* x, int ldx, const float* y /*nullable*/, int ldy, const float* dy, int lddy, float* dx, int lddx,
+                           float* dresidual /*nullable*/, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
+                           float* dgamma /*nullable*/, float* dbeta /*nullable*/, int relu, int training, const float* stats, int stats_parts,
+                           dsrl_stream_t stream);
 
 /* standalone Dropout (DSRL.py:54): Philox4x32-10 keyed by (seed, rng_stream), element index = p*C + c */
 int dsrl_dropout_fwd(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float p, uint64_t seed, uint32_t rng_stream, dsrl_stream_t stream);

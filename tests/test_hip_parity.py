@@ -649,6 +649,44 @@ def test_grad_slots_match_autograd_accumulation():
         assert np.array_equal(grads[0][k], grads[1][k]), k          # downstream of every shared buffer: untouched
 
 
+def test_bn_backward_statistics_from_dgrad_epilogue():
+    """functional.BNLink: bn1 / bn2 of every bottleneck take their two backward sums from the partials the consuming conv's dgrad left
+    (dsrl_conv2d_dgrad_bnstats -> dsrl_bn_bwd_from_stats). Same gradients as with the BN kernels' own reductions, up to summation order."""
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    rs = np.random.RandomState(6)
+    x = rs.standard_normal((2, 3, 96, 160)).astype(np.float32)
+    tg = rs.randint(0, 19, (2, 192, 320)).astype(np.uint8)
+    org = rs.standard_normal((2, 3, 192, 320)).astype(np.float32)
+    grads, counts = [], []
+    old, orig_call = HF.bn_bwd_stats_enabled, HF.call
+
+    def counting(name, *a):
+        counts[-1][name] = counts[-1].get(name, 0) + 1
+        return orig_call(name, *a)
+
+    try:
+        HF.call = counting
+        for enabled in (False, True):
+            HF.bn_bwd_stats_enabled = enabled
+            counts.append({})
+            torch.manual_seed(3)
+            model = D.DSRL(3, cs).to(DEV).to(memory_format=torch.channels_last).train()
+            for m in model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.eval()
+            outs = model(dev(x, cl=False))
+            L = hip_losses(outs, dev(tg), dev(org), 3)
+            (L[0] + L[1]).backward()
+            torch.cuda.synchronize()
+            grads.append({k: host(p.grad) for k, p in model.named_parameters() if p.grad is not None})
+    finally:
+        HF.bn_bwd_stats_enabled, HF.call = old, orig_call
+    assert counts[0].get('dsrl_bn_bwd_from_stats', 0) == 0 and counts[0].get('dsrl_conv2d_dgrad_bnstats', 0) == 0
+    assert counts[1].get('dsrl_bn_bwd_from_stats', 0) == 66 and counts[1].get('dsrl_conv2d_dgrad_bnstats', 0) == 66      # bn1, bn2 of 33 bottlenecks
+    bad = {k: rel_err(grads[1][k], grads[0][k]) for k in grads[0] if rel_err(grads[1][k], grads[0][k]) > 5e-4}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize('mode', ['mixed', 'bf16x6'])
 def test_full_model_vs_oracle(mode):
     """Whole DSRL (ResNet-101 OS16 backbone + head) at 32x64, B=2, train-mode BN, dropout off: every kernel family in one graph
