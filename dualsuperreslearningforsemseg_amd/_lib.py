@@ -36,7 +36,7 @@ PROTOTYPES = {
     'dsrl_conv2d_transpose_filters_batched': (i32, [fp, i32, i64, stream_t]),
     'dsrl_conv2d_dgrad': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv2d_dgrad_stats_parts': (i32, _conv_shape),
-    'dsrl_conv2d_dgrad_bnstats': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, fp, i32, fp, fp, i32, fp, i32, stream_t]),
+    'dsrl_conv2d_dgrad_bnstats': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, fp, i32, fp, fp, i32, fp, i32, i32, stream_t]),
     'dsrl_conv2d_dgrad_accumulate': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv2d_wgrad_workspace_bytes': (sz, _conv_shape),
     'dsrl_conv2d_wgrad': (i32, [fp, i32, fp, i32, fp] + _conv_shape + [fp, sz, stream_t]),

@@ -1579,13 +1579,14 @@ extern "C" int dsrl_conv2d_dgrad_stats_parts(int N, int H, int W, int C, int K, 
 extern "C" int dsrl_conv2d_dgrad_bnstats(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
                                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                                          void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y, int bn_ldy,
-                                         const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats, int stats_parts, dsrl_stream_t stream) {
+                                         const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats, int stats_parts, int accumulate,
+                                         dsrl_stream_t stream) {
     DSRL_REQUIRE(bn_x && bn_mean && bn_invstd && bstats && (bn_y || !bn_relu) && bn_ldx >= C && (!bn_relu || bn_ldy >= C), DSRL_E_BADARG, "conv2d_dgrad_bnstats: bad BatchNorm arguments");
     DSRL_REQUIRE(dsrl_conv2d_dgrad_stats_parts(N, H, W, C, K, R, S, stride, pad, dil) == stats_parts && stats_parts > 0, DSRL_E_BADARG,
                  "conv2d_dgrad_bnstats: this launch writes %d row blocks of partials, the caller expects %d",
                  dsrl_conv2d_dgrad_stats_parts(N, H, W, C, K, R, S, stride, pad, dil), stats_parts);
     DgradBn bn{bn_x, bn_y, bn_mean, bn_invstd, bstats, bn_ldx, bn_ldy, bn_relu};
-    return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, 0, &bn);
+    return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, accumulate ? 1 : 0, &bn);
 }
 extern "C" int dsrl_conv2d_dgrad_accumulate(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
                                             int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

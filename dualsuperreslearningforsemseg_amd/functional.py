@@ -279,14 +279,18 @@ class GradSlot:
 # then runs as one streaming kernel (dsrl_bn_bwd_from_stats).  A BNLink carries what the conv needs from the BN's forward and the
 # partials back; the BN only trusts them if the gradient it receives is the very buffer that conv wrote.
 bn_bwd_stats_enabled = os.environ.get('DSRL_BN_BWD_STATS', '1') != '0'
+# the same for bn3 via the next block's accumulating dgrad: correct, but measured slower (wide 4x-channel epilogues): off by default
+bn_bwd_stats_shared = os.environ.get('DSRL_BN_BWD_STATS_SHARED', '0') != '0'
 
 
 class BNLink:
-    __slots__ = ('x', 'y', 'mean', 'invstd', 'relu', 'valid', 'stats', 'parts', 'dx_ptr')
+    __slots__ = ('x', 'y_ptr', 'y_shape', 'mean', 'invstd', 'relu', 'valid', 'stats', 'parts', 'dx_ptr', 'shared')
 
-    def __init__(self):
-        self.x = self.y = self.mean = self.invstd = self.stats = None
+    def __init__(self, shared=False):
+        self.x = self.mean = self.invstd = self.stats = None      # the BN output itself is NOT kept (it may carry this link: no cycles)
+        self.y_ptr, self.y_shape = 0, None
         self.relu, self.valid, self.parts, self.dx_ptr = False, False, 0, 0
+        self.shared = shared        # y feeds the two consumers of a GradSlot: the accumulating (= last) dgrad completes its gradient
 
 
 class _Fork(torch.autograd.Function):
@@ -396,16 +400,18 @@ class _Conv2d(torch.autograd.Function):
                     wt_ptr = wt.data_ptr()
             link = ctx.in_link
             parts = 0
-            if (link is not None and link.valid and not acc and link.y is not None and link.y.data_ptr() == x.data_ptr()
-                    and tuple(link.y.shape) == (N, Cc, H, W) and Cc % 32 == 0):
+            # only the launch that completes the gradient may produce the sums: a plain dgrad when x has this single consumer, or the
+            # accumulating dgrad that adds the last contribution to a shared buffer (GradSlot with two consumers)
+            final = (not acc and ctx.gslot is None) or (acc and getattr(link, 'shared', False))
+            if (link is not None and link.valid and final and link.y_ptr == x.data_ptr() and link.y_shape == (N, Cc, H, W) and Cc % 32 == 0):
                 parts = int(query('dsrl_conv2d_dgrad_stats_parts', *shp))
             if parts > 0:
                 # x is y = relu(bn(.)) of a BatchNorm that feeds only this conv: leave its backward partial sums with the data gradient
                 bstats = torch.empty(2 * parts * Cc, device=x.device, dtype=torch.float32)
                 _, bld = pm(link.x)
                 call('dsrl_conv2d_dgrad_bnstats', dy.data_ptr(), lddy, w.data_ptr(), wt_ptr, dx.data_ptr(), Cc, *shp, ws.data_ptr(), ws.numel(),
-                     link.x.data_ptr(), bld, link.y.data_ptr(), ldx, link.mean.data_ptr(), link.invstd.data_ptr(), int(link.relu),
-                     bstats.data_ptr(), parts, st)
+                     link.x.data_ptr(), bld, x.data_ptr(), ldx, link.mean.data_ptr(), link.invstd.data_ptr(), int(link.relu),
+                     bstats.data_ptr(), parts, int(acc), st)
                 link.stats, link.parts, link.dx_ptr = bstats, parts, dx.data_ptr()
             else:
                 call('dsrl_conv2d_dgrad_accumulate' if acc else 'dsrl_conv2d_dgrad', dy.data_ptr(), lddy, w.data_ptr(), wt_ptr, dx.data_ptr(), Cc, *shp,
@@ -525,7 +531,8 @@ class _BNAct(torch.autograd.Function):
                  res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream), st)
         ctx.save_for_backward(x, y, mean, invstd, gamma)
         if out_link is not None and drop_p == 0.0 and Cc % 32 == 0 and ldx == Cc:
-            out_link.x, out_link.y, out_link.mean, out_link.invstd, out_link.relu, out_link.valid = x, y, mean, invstd, bool(relu), True
+            out_link.x, out_link.mean, out_link.invstd, out_link.relu, out_link.valid = x, mean, invstd, bool(relu), True
+            out_link.y_ptr, out_link.y_shape = y.data_ptr(), tuple(y.shape)
         ctx.cfg = (bool(training), bool(relu), float(drop_p), residual is not None)
         ctx.gb = (gamma, beta) if isinstance(gamma, torch.nn.Parameter) and isinstance(beta, torch.nn.Parameter) else None
         return y

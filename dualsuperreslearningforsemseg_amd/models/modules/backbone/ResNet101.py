@@ -34,26 +34,33 @@ class Bottleneck(t.nn.Module):
         # the block input feeds conv1 and the residual branch: both gradient contributions land in one buffer (HF.GradSlot) instead of
         # being summed by a separate elementwise kernel; fork() isolates the pair from any other user of x
         slot = None
+        # bn3 of the previous block left a link on its output: the data gradient that completes our input's shared buffer carries its sums
+        lin = getattr(x, '_dsrl_bnlink', None) if HF.bn_bwd_stats_enabled else None
         if HF.grad_slots_enabled and x.requires_grad and t.is_grad_enabled():
             x, slot = HF.fork(x), HF.GradSlot()
+        if slot is None:
+            lin = None
         if self.downsample is None:
             identity = x
         elif len(self.downsample) == 2 and isinstance(self.downsample[0], HipConv2d) and self.downsample[0].bias is None:
             ds = self.downsample[0]
-            identity = HF.conv2d_bn_act(x, ds.weight, None, ds.stride[0], ds.padding[0], ds.dilation[0], self.downsample[1], grad_slot=slot)
+            identity = HF.conv2d_bn_act(x, ds.weight, None, ds.stride[0], ds.padding[0], ds.dilation[0], self.downsample[1], grad_slot=slot, in_link=lin)
         else:
             if slot is not None:
                 slot.closed = True
             identity = self.downsample(x)
         c1, c2, c3 = self.conv1, self.conv2, self.conv3
         # bn1's output feeds only conv2 and bn2's only conv3: their data-gradient kernels leave the BN-backward sums behind (HF.BNLink)
-        l1 = l2 = None
+        l1 = l2 = l3 = None
         if HF.bn_bwd_stats_enabled and t.is_grad_enabled():
-            l1, l2 = HF.BNLink(), HF.BNLink()
-        out = HF.conv2d_bn_act(x, c1.weight, None, c1.stride[0], c1.padding[0], c1.dilation[0], self.bn1, relu=True, grad_slot=slot, out_link=l1)
+            l1, l2, l3 = HF.BNLink(), HF.BNLink(), HF.BNLink(shared=True)
+        out = HF.conv2d_bn_act(x, c1.weight, None, c1.stride[0], c1.padding[0], c1.dilation[0], self.bn1, relu=True, grad_slot=slot, out_link=l1, in_link=lin)
         out = HF.conv2d_bn_act(out, c2.weight, None, c2.stride[0], c2.padding[0], c2.dilation[0], self.bn2, relu=True, in_link=l1, out_link=l2)
-        return HF.conv2d_bn_act(out, c3.weight, None, c3.stride[0], c3.padding[0], c3.dilation[0], self.bn3, relu=True, residual=identity,   # bn3 + identity, ReLU
-                                residual_grad_slot=slot if self.downsample is None else None, in_link=l2)
+        out = HF.conv2d_bn_act(out, c3.weight, None, c3.stride[0], c3.padding[0], c3.dilation[0], self.bn3, relu=True, residual=identity,   # bn3 + identity, ReLU
+                               residual_grad_slot=slot if self.downsample is None else None, in_link=l2, out_link=l3)
+        if l3 is not None and l3.valid and HF.bn_bwd_stats_shared:
+            out._dsrl_bnlink = l3       # picked up by the next block, whose conv1 / downsample conv complete this tensor's gradient
+        return out
 
 
 class ResNet101(t.nn.Module):

@@ -82,7 +82,8 @@ int dsrl_conv2d_dgrad_stats_parts(int N, int H, int W, int C, int K, int R, int 
 int dsrl_conv2d_dgrad_bnstats(const float* dy, int lddy, const float* w, const float* wt /*nullable*/, float* dx, int lddx,
                               int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                               void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y /*nullable*/, int bn_ldy,
-                              const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats, int stats_parts, dsrl_stream_t stream);
+                              const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats, int stats_parts,
+                              int accumulate /* dx += ..., the sums are taken of the accumulated values */, dsrl_stream_t stream);
 /* dx += dgrad(dy, w): the same computation accumulated onto the existing contents of dx (a tensor that feeds two branches receives
  * both gradient contributions in one buffer, e.g. the input of a ResNet bottleneck: ResNet101.py residual add + conv1). */
 int dsrl_conv2d_dgrad_accumulate(const float* dy, int lddy, const float* w, const float* wt /*nullable*/, float* dx, int lddx,
