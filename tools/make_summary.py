@@ -22,9 +22,10 @@ tot = sum(float(r['TotalDurationNs']) for r in rows) / 1e6 / steps
 groups = [('conv_igemm_split_kernel<bf16x6> (forward)', lambda n: 'conv_igemm_split' in n and 'false, 3' in n),
           ('conv_wgrad_split_kernel<bf16x3>', lambda n: 'conv_wgrad_split' in n),
           ('conv_igemm_split_kernel<bf16x3> (dgrad)', lambda n: 'conv_igemm_split' in n and 'true, 2' in n),
-          ('bn_stats_apply_kernel (forward, statistics from the conv epilogue: 83 layers)', lambda n: 'bn_stats_apply' in n),
-          ('bn_fused_fwd_kernel (22 layers) / bn_fused_bwd_kernel (105 layers)', lambda n: 'bn_fused' in n),
-          ('bn_* three-kernel path (8 large / odd-width layers)', lambda n: 'bn_' in n and 'bn_fused' not in n and 'bn_stats_apply' not in n),
+          ('bn_stats_apply_kernel (forward, statistics from the conv epilogue: 83 layers)', lambda n: 'bn_stats_apply' in n and 'bwd' not in n),
+          ('bn_bwd_stats_apply_kernel (backward, sums from the dgrad epilogue; split-K dgrads fall back)', lambda n: 'bn_bwd_stats_apply' in n),
+          ('bn_fused_fwd_kernel / bn_fused_bwd_kernel (device-wide barrier)', lambda n: 'bn_fused' in n),
+          ('bn_* three-kernel path (8 large / odd-width layers)', lambda n: 'bn_' in n and 'bn_fused' not in n and 'stats_apply' not in n),
           ('wgrad_reduce_kernel', lambda n: 'wgrad_reduce' in n),
           ('torch elementwise add (remaining gradient accumulation)', lambda n: 'CUDAFunctor_add' in n),
           ('weight_transpose_batched_kernel (1 launch/step)', lambda n: 'weight_transpose' in n),
