@@ -1236,7 +1236,7 @@ static TileCfg pick_cfg_wgrad(int K, int C) {
 static int pick_psplits(long long tiles, long long chunks) {
     const int forced = env_int("DSRL_FORCE_PSPLITS", 0);
     if (forced > 0) return (int)std::max<long long>(1, std::min<long long>(forced, chunks));
-    long long sp = ceil_div(1152, std::max<long long>(tiles, 1));
+    long long sp = ceil_div(env_int("DSRL_WGRAD_TARGET_BLOCKS", 1152), std::max<long long>(tiles, 1));
     sp = std::min(sp, std::max<long long>(1, chunks / 4));
     return (int)std::max<long long>(1, std::min<long long>(sp, 128));
 }
