@@ -667,6 +667,7 @@ def test_bn_backward_statistics_from_dgrad_epilogue(shared):
 
     try:
         HF.call = counting
+        HF.set_conv_precision('mixed')       # the epilogue statistics exist in the split-precision kernels only
         HF.bn_bwd_stats_shared = shared      # also bn3, through the next block's accumulating dgrad (off by default: measured slower)
         for enabled in (False, True):
             HF.bn_bwd_stats_enabled = enabled
