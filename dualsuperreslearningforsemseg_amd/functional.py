@@ -311,6 +311,7 @@ def fork(x):
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, dil, gslot=None, stats_parts=0, in_link=None):
+        ctx.set_materialize_grads(False)       # no zero tensor for the (non-differentiable) statistics output's gradient
         ctx.gslot = gslot
         ctx.in_link = in_link
         x, ldx = pm_vec4(x)
@@ -357,6 +358,8 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, *_unused):
+        if dy is None:
+            return (None,) * 9
         x, w = ctx.saved_tensors
         shp = ctx.shp
         N, H, W, Cc, K, R, S, stride, pad, dil = shp
