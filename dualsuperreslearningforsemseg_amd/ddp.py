@@ -127,9 +127,18 @@ class FlatParams:
         self._pending[ci] -= 1
         if self._pending[ci] == 0:
             a, b, _ = self.chunks[ci]
-            if self.device.type == 'cuda':
-                HF.join_side_streams()      # the chunk may hold weight gradients produced on the side stream
-            self._works.append(dist.all_reduce(self.g_flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            if self.device.type == 'cuda' and HF.overlap_wgrad:
+                # The chunk holds gradients written on the compute stream AND weight gradients written on the side stream.  Launch the
+                # collective with the side stream current, after making that stream wait for the compute stream: the collective's own
+                # stream then starts behind every producer of the chunk on both streams, and the compute stream itself never waits
+                # (it used to join the side stream here, draining the weight-gradient backlog at every chunk boundary).
+                cur = torch.cuda.current_stream(self.device)
+                side = HF.side_stream(self.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    self._works.append(dist.all_reduce(self.g_flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            else:
+                self._works.append(dist.all_reduce(self.g_flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     # ------------------------------------------------------------------ transposed conv filters for the data-gradient kernels
     def _build_transposed_filters(self):

@@ -18,7 +18,7 @@ dev = torch.device('cuda:0')
 torch.cuda.set_device(dev)
 
 
-def run(distributed, steps=12):
+def run(distributed, steps=int(os.environ.get('REH_STEPS', '44'))):
     torch.manual_seed(54321)
     model = DSRL(3, cs).to(dev).to(memory_format=torch.channels_last).train()
     for m in model.modules():
@@ -28,7 +28,7 @@ def run(distributed, steps=12):
         real = dist.get_world_size
         ddp.dist.get_world_size = lambda group=None: 2          # claim two ranks: the collectives still run on the 1-rank group
         try:
-            flat = ddp.FlatParams(model)
+            flat = ddp.FlatParams(model, broadcast_buffers=os.environ.get('REH_NO_BCAST') is None)
         finally:
             ddp.dist.get_world_size = real
         assert flat.world == 2 and len(flat._hooks) > 0
@@ -54,7 +54,7 @@ def run(distributed, steps=12):
 plain, ms_plain = run(False)
 dist.init_process_group('nccl', rank=0, world_size=1)
 rccl, ms_rccl = run(True)
-for i in (0, 3, 7, 11):
+for i in (0, 3, 7, 11, len(plain) - 1):
     print(f'step {i}: plain total {plain[i][3]:.5f} | with RCCL reduction {rccl[i][3]:.5f}')
 rel = max(abs(a[3] - b[3]) / abs(a[3]) for a, b in zip(plain, rccl))
 print(f'max relative difference {rel:.2e}; ms/step plain {ms_plain:.1f}, with RCCL {ms_rccl:.1f}; fused-BN barrier timeouts {HF.bn_fused_barrier_timeouts()}')
