@@ -4,35 +4,95 @@ Cityscapes-shaped batches, per-rank batch 8 (train_stage3_cmdline.json), one pro
 RCCL.  A "step" = forward (ResNet-101 + ASPP + SSSR/SISR decoders + feature transformers) + CE/MSE/FA losses + backward +
 gradient reduction + SGD update + the per-iteration loss/NaN readback, exactly what train_or_resume() runs per batch.
 
-    python bench.py [--gpus N --steps K --warmup W]           (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W]
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     - the dominant kernel (the MFMA implicit-GEMM conv that takes the most device time): achieved in-bounds (algorithmic)
-                 TFLOP/s from HIP events recorded by the library around every launch, against the dense MFMA peak of the
-                 arithmetic that kernel runs in: 157.3 TFLOP/s for fp32 MFMA, 2516.6/3 for bf16x3 and 2516.6/6 for bf16x6
-                 (three / six bf16 MFMAs per algorithmic product - DESIGN.md section 4); every conv kernel family is listed;
-  cpu_baseline - the numpy oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample.
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks (python -m torch.distributed.run, one
+per GPU, rendezvous on 127.0.0.1) BEFORE anything touches the GPU and exits with their return code; launched by
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  `value` is measured with the DEFAULT conv arithmetic, the
+fp32-equivalent "bf16x6" split (fp32 storage, fp32 accumulation, error vs fp64 equal to exact-product fp32 MFMA); the same step
+under the reduced-precision-gradient "mixed" mode and under exact-product fp32 MFMA is timed over the same step counts and listed
+in `images_per_s_by_conv_arithmetic`.  Extra objects:
+  roofline       - the dominant kernel (the MFMA implicit-GEMM conv family that takes the most device time): achieved in-bounds
+                   (algorithmic) TFLOP/s from HIP events recorded by the library around every launch, against the dense MFMA peak
+                   of the arithmetic that kernel runs in: 157.3 TFLOP/s for fp32 MFMA, 2516.6/3 for bf16x3 and 2516.6/6 for bf16x6
+                   (three / six bf16 MFMAs per algorithmic product - DESIGN.md section 3b); every conv kernel family is listed;
+                   `decoder_stack`: the decoder-head conv stack (north_star's 30 % target) per pass, each conv timed on its own;
+  roofline_hbm   - the memory-bound kernels of the step (CE, ConvTranspose, MSE, large BatchNorm, SGD): algorithmic bytes / time
+                   against the 8 TB/s HBM peak;
+  cpu_baseline   - the same training step on this box's host cores from stock torch.nn CPU modules (what the reference's
+                   `--device cpu` path executes, oracle/torch_cpu_model.py), plus the numpy oracle as `cpu_baseline_numpy_port`.
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak 157.3 TFLOP/s, dense bf16 2516.6 TFLOP/s.  A split-precision conv
-# issues 3 (bf16x3) or 6 (bf16x6) bf16 MFMAs per algorithmic product, so its MFMA roof for ALGORITHMIC flops is the bf16 peak / 3 or / 6.
+# /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak 157.3 TFLOP/s, dense bf16 2516.6 TFLOP/s, HBM 8 TB/s.  A split-precision
+# conv issues 3 (bf16x3) or 6 (bf16x6) bf16 MFMAs per algorithmic product, so its MFMA roof for ALGORITHMIC flops is the bf16 peak / 3 or / 6.
 BF16_MFMA_PEAK_TFLOPS = 2516.6
 MFMA_PEAK_TFLOPS = {0: 157.3, 1: BF16_MFMA_PEAK_TFLOPS / 3, 2: BF16_MFMA_PEAK_TFLOPS / 6}      # by arithmetic: fp32, bf16x3, bf16x6
 ARITH_NAME = {0: 'fp32', 1: 'bf16x3', 2: 'bf16x6'}
+HBM_PEAK_GBS = 8000.0
+ARITH_TEXT = {'fp32': 'exact-product fp32 MFMA', 'bf16x3': 'bf16x3 split, fp32 accumulate', 'bf16x6': 'bf16x6 split (fp32-equivalent), fp32 accumulate',
+              'mixed': 'forward bf16x6 (fp32-equivalent), dgrad/wgrad bf16x3 (reduced-precision gradients); fp32 storage and accumulation'}
 
 
-def cpu_baseline(state_dict, batch=2, height=256, width=512):
-    """The same workload on the host cores: numpy oracle (oracle/, a port of the reference arithmetic), whole stage-3 step =
-    ResNet-101 + head forward, CE/MSE/FA losses and the full backward pass, fp32, B=2 at 256x512 (a bounded sample: ~20 s)."""
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=8, help='per-rank batch (train_stage3_cmdline.json: 8)')
+    ap.add_argument('--height', type=int, default=256, help='input height (BASELINE config 5: --height 512 --width 1024)')
+    ap.add_argument('--width', type=int, default=512)
+    ap.add_argument('--stage', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='skip the per-kernel roofline passes and the per-arithmetic runs')
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` as the driver invokes it: become the launcher of N ranks.  Nothing here imports torch.cuda or
+    touches the GPU, and nothing is exec'ed: the ranks are children of a plain subprocess."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ----------------------------------------------------------------------------------------------------------------- CPU baselines
+def host_cores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+
+
+def cpu_baseline_torch(state_dict, stage, batch=2, height=256, width=512):
+    """The same training step from stock torch.nn CPU modules (ATen / oneDNN): the arithmetic the reference's `--device cpu` path
+    runs (utils.py:259-260).  One warm-up + one timed step of B=2 at 256x512 (bounded: ~10 s on 8 cores, less on a GPU box's host)."""
+    from oracle.torch_cpu_model import time_train_step
+    cores = host_cores()
+    ips, threads, dt, n = time_train_step(state_dict, batch, height, width, stage, threads=cores, repeats=1, budget_s=12.0)
+    return {'value': round(ips, 4), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'impl': 'torch-cpu',
+            'sample': f'stock torch.nn CPU modules (same layer graph and weights; ATen/oneDNN kernels, {threads} threads), whole stage-{stage} step: '
+                      f'forward, CE/MSE/FA, backward, torch.optim.SGD; B={batch} at {height}x{width}->{2 * height}x{2 * width}; best of {n} timed step(s) '
+                      f'after one warm-up = {dt:.2f} s'}
+
+
+def cpu_baseline_numpy(state_dict, batch=1, height=256, width=512):
+    """The numpy oracle (oracle/, the checker of the parity tests) on the host cores: whole model forward + losses + backward, B=1."""
     import numpy as np
     import oracle as O
     rs = np.random.RandomState(1234)
@@ -41,33 +101,132 @@ def cpu_baseline(state_dict, batch=2, height=256, width=512):
     org = rs.standard_normal((batch, 3, 2 * height, 2 * width)).astype(np.float32)
     tg = rs.randint(0, 19, (batch, 2 * height, 2 * width)).astype(np.uint8); tg[rs.uniform(size=tg.shape) < 0.1] = 255
     t0 = time.time()
-    out = O.model_forward(sd, x, 3, True)
+    out = O.model_forward(sd, x, 3, batch > 1)          # B=1: BatchNorm in eval mode (the global-pool BN needs B >= 2 to train, ASPP.py:39-40)
     O.total_loss(out, tg, org, 3)
     dt = time.time() - t0
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    cores = host_cores()
     try:                                        # threads the BLAS behind numpy actually uses
         from threadpoolctl import threadpool_info
         blas = [i.get('num_threads') for i in threadpool_info() if i.get('user_api') == 'blas']
         cores = max(blas) if blas else cores
     except Exception:
         pass
-    return {'value': round(batch / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'numpy oracle (fp32, multi-threaded BLAS), whole stage-3 step without the optimizer update: ResNet-101 + head forward, '
-                      f'CE/MSE/FA, full backward; B={batch} at {height}x{width}->{2 * height}x{2 * width}; one pass = {dt:.1f} s'}
+    return {'value': round(batch / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port', 'impl': 'numpy oracle',
+            'sample': f'numpy oracle (fp32, multi-threaded BLAS), ResNet-101 + head forward, CE/MSE/FA, full backward, no optimizer update; '
+                      f'B={batch} at {height}x{width}; one pass = {dt:.1f} s'}
 
 
+# ----------------------------------------------------------------------------------------------------------------- kernel timers
+def _time_ms(fn, reps, torch):
+    fn(); fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def decoder_stack_roofline(torch, HF, B, H, W, reps=10):
+    """north_star: '>= 30 % of CDNA4 MFMA peak on the decoder conv stack'.  Every conv of the decoder head (ASPP, shortcut, cat_conv x2,
+    cls_conv, SISR; DSRL.py:13-84) at the step's shapes, each pass launched on its own through the C ABI and timed with events on the
+    launch stream; algorithmic (in-bounds) FLOP / time against the MFMA peak of the arithmetic the pass runs in."""
+    from dualsuperreslearningforsemseg_amd import _lib
+    h16, w16, h4, w4 = H // 16, W // 16, H // 4, W // 4
+    shapes = [('aspp.0 1x1 2048->256', 2048, h16, w16, 256, 1, 0, 1), ('aspp.1 3x3 d6', 2048, h16, w16, 256, 3, 6, 6), ('aspp.2 3x3 d12', 2048, h16, w16, 256, 3, 12, 12),
+              ('aspp.3 3x3 d18', 2048, h16, w16, 256, 3, 18, 18), ('aspp.5 1x1 1280->256', 1280, h16, w16, 256, 1, 0, 1), ('shortcut 1x1 256->48', 256, h4, w4, 48, 1, 0, 1),
+              ('cat_conv.0 3x3 304->256', 304, h4, w4, 256, 3, 1, 1), ('cat_conv.4 3x3 256->256', 256, h4, w4, 256, 3, 1, 1), ('cls_conv 1x1 256->19', 256, h4, w4, 19, 1, 0, 1),
+              ('SISR 3x3 304->192', 304, h4, w4, 192, 3, 1, 1)]
+    mode = HF.get_conv_precision()
+    arith = {'fp32': (0, 0, 0), 'bf16x3': (1, 1, 1), 'bf16x6': (2, 2, 2), 'mixed': (2, 1, 1)}[mode]       # forward, dgrad, wgrad
+    tot = {'forward': [0.0, 0.0], 'dgrad': [0.0, 0.0], 'wgrad': [0.0, 0.0]}
+    layers = {}
+    dev = torch.device('cuda', torch.cuda.current_device())
+    for name, C, h, w, K, R, pad, dil in shapes:
+        x = torch.randn((B, C, h, w), device=dev).contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn((K, C, R, R), device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+        Kp = (K + 3) & ~3
+        dyb = torch.zeros((B, Kp, h, w), device=dev).contiguous(memory_format=torch.channels_last)
+        dyb[:, :K].normal_()
+        dy = dyb[:, :K]
+        y = torch.empty((B, K, h, w), device=dev).contiguous(memory_format=torch.channels_last)
+        dx, dw = torch.empty_like(x), torch.empty_like(wt)
+        shp = (B, h, w, C, K, R, R, 1, pad, dil)
+        st = HF._stream()
+        wsf = HF._ws(HF.cquery('dsrl_conv2d_fwd_workspace_bytes', *shp), x)
+        wsd = HF._ws(HF.cquery('dsrl_conv2d_dgrad_workspace_bytes', *shp), x)
+        wsw = HF._ws(HF.cquery('dsrl_conv2d_wgrad_workspace_bytes', *shp), x)
+        gf = 2.0 * HF.conv2d_inbounds_macs(*shp) / 1e9
+        t_f = _time_ms(lambda: _lib.call('dsrl_conv2d_fwd', x.data_ptr(), C, wt.data_ptr(), None, y.data_ptr(), K, *shp, wsf.data_ptr(), wsf.numel(), st), reps, torch)
+        t_d = _time_ms(lambda: _lib.call('dsrl_conv2d_dgrad', dy.data_ptr(), Kp, wt.data_ptr(), None, dx.data_ptr(), C, *shp, wsd.data_ptr(), wsd.numel(), st), reps, torch)
+        t_w = _time_ms(lambda: _lib.call('dsrl_conv2d_wgrad', x.data_ptr(), C, dy.data_ptr(), Kp, dw.data_ptr(), *shp, wsw.data_ptr(), wsw.numel(), st), reps, torch)
+        layers[name] = {'gflop': round(gf, 2), 'forward_tflops': round(gf / t_f, 1), 'dgrad_tflops': round(gf / t_d, 1), 'wgrad_tflops': round(gf / t_w, 1)}
+        for k, t in (('forward', t_f), ('dgrad', t_d), ('wgrad', t_w)):
+            tot[k][0] += gf; tot[k][1] += t
+    out = {'conv_arithmetic': mode, 'layers': layers,
+           'note': 'each conv launched alone through the C ABI (dgrad includes its own filter transpose), events on the launch stream, '
+                   f'{reps} launches each; achieved = in-bounds FLOP / time; peak = dense bf16 MFMA 2516.6 TF / (3 | 6 MFMAs per product) or 157.3 TF fp32'}
+    all_f = all_t = 0.0
+    for i, k in enumerate(('forward', 'dgrad', 'wgrad')):
+        peak = MFMA_PEAK_TFLOPS[arith[i]]
+        ach = tot[k][0] / tot[k][1]
+        out[k] = {'achieved': round(ach, 1), 'peak': round(peak, 1), 'frac': round(ach / peak, 4), 'arithmetic': ARITH_NAME[arith[i]], 'ms': round(tot[k][1], 3)}
+        all_f += tot[k][0]; all_t += tot[k][1]
+    out['all_passes'] = {'achieved': round(all_f / all_t, 1), 'ms': round(all_t, 3),
+                         'frac_of_time_weighted_peak': round(sum(tot[k][1] * (tot[k][0] / tot[k][1]) / MFMA_PEAK_TFLOPS[arith[i]]
+                                                                 for i, k in enumerate(('forward', 'dgrad', 'wgrad'))) / all_t, 4)}
+    return out
+
+
+def hbm_roofline(torch, HF, flat, B, H, W, reps=10):
+    """The memory-bound kernels of the step, each launched on its own through the product wrappers: ALGORITHMIC bytes (every operand
+    read / written once) / time against 8 TB/s."""
+    dev = flat.device
+    Ho, Wo, P = 2 * H, 2 * W, B * 4 * H * W
+    rows = []
+
+    def add(name, nbytes, ms, calls=1):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        rows.append({'kernel': name, 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                     'algorithmic_bytes': int(nbytes), 'avg_launch_ms': round(ms, 4), 'launches_per_step': calls})
+
+    logits = torch.randn((B, 19, Ho, Wo), device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    tgt = torch.randint(0, 19, (B, Ho, Wo), device=dev, dtype=torch.uint8)
+    loss = HF.cross_entropy(logits, tgt, 255)
+    add('ce_fwd (CrossEntropy forward, 19 logits/pixel)', P * 19 * 4 + P, _time_ms(lambda: HF.cross_entropy(logits.detach(), tgt, 255), reps, torch))
+    add('ce_bwd (CrossEntropy backward)', 2 * P * 19 * 4 + P, _time_ms(lambda: torch.autograd.grad(loss, logits, retain_graph=True), reps, torch))
+    a = torch.randn((B, 3, Ho, Wo), device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = torch.randn((B, 3, Ho, Wo), device=dev).contiguous(memory_format=torch.channels_last)
+    ml = HF.mse_loss(a, b)
+    add('mse_fwd', 2 * P * 3 * 4, _time_ms(lambda: HF.mse_loss(a.detach(), b), reps, torch))
+    add('mse_bwd', 3 * P * 3 * 4, _time_ms(lambda: torch.autograd.grad(ml, a, retain_graph=True), reps, torch))
+    x = torch.randn((B, 19, H, W), device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wt = torch.randn((19, 19, 2, 2), device=dev).requires_grad_(True)
+    bias = torch.zeros(19, device=dev, requires_grad=True)
+    y = HF.conv_transpose2d_k2s2(x, wt, bias)
+    dy = torch.randn_like(y)
+    add('convt2x2_fwd (final ConvTranspose2d 19->19, logits write)', (P // 4 + P) * 19 * 4, _time_ms(lambda: HF.conv_transpose2d_k2s2(x.detach(), wt.detach(), bias.detach()), reps, torch))
+    add('convt2x2_bwd (dx + dw + db)', (P + 2 * P // 4) * 19 * 4, _time_ms(lambda: torch.autograd.grad(y, (x, wt, bias), dy, retain_graph=True), reps, torch))
+    bn = torch.nn.BatchNorm2d(256).to(dev).train()
+    xb = torch.randn((B, 256, H // 4, W // 4), device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    nb = xb.numel() * 4
+    yb = HF.batch_norm_act(xb, bn, relu=True)
+    dyb = torch.randn_like(yb)
+    add('bn large tensor forward (layer1 bn3 shape, statistics + apply + ReLU)', 2 * nb, _time_ms(lambda: HF.batch_norm_act(xb.detach(), bn, relu=True), reps, torch), 8)
+    add('bn large tensor backward', 4 * nb, _time_ms(lambda: torch.autograd.grad(yb, xb, dyb, retain_graph=True), reps, torch), 8)
+    g0, p0, m0 = flat.g_flat.clone(), flat.p_flat.clone(), flat.m_flat.clone()
+    add('sgd_kernel (p, g, momentum arenas)', 5 * flat.numel * 4, _time_ms(lambda: HF.sgd_step_(flat.p_flat, flat.g_flat, flat.m_flat, 0.0, 0.9, 0.0, 1.0), reps, torch))
+    flat.g_flat.copy_(g0); flat.p_flat.copy_(p0); flat.m_flat.copy_(m0)
+    return rows
+
+
+# ----------------------------------------------------------------------------------------------------------------- main
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=8, help='per-rank batch (train_stage3_cmdline.json: 8)')
-    ap.add_argument('--height', type=int, default=256)
-    ap.add_argument('--width', type=int, default=512)
-    ap.add_argument('--stage', type=int, default=3)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events')
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -78,8 +237,7 @@ def main():
         local = 0
         os.environ['DSRL_BN_FUSED'] = '0'     # several processes on one GPU: the fused BN kernels' device-wide barrier needs the GPU to itself
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f'--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without torch.distributed.run)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
@@ -92,6 +250,7 @@ def main():
 
     import dualsuperreslearningforsemseg_amd as D
     from dualsuperreslearningforsemseg_amd import _lib, settings
+    from dualsuperreslearningforsemseg_amd import functional as HF
     from dualsuperreslearningforsemseg_amd.command_handlers.train_or_resume import SyntheticCityscapes, TrainStep
     from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
     from dualsuperreslearningforsemseg_amd.ddp import FlatParams
@@ -109,6 +268,7 @@ def main():
     data = SyntheticCityscapes(args.batch, (args.height, args.width), dev, rank=rank, length=1)
     (img, org), (tgt, _) = next(iter(data))
     hp = dict(lr=0.006, momentum=0.9, weight_decay=5e-4)        # train_stage3_cmdline.json
+    weights0 = None if (args.no_cpu_baseline or world > 1) else {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
     host_ms = []
 
@@ -124,30 +284,49 @@ def main():
             last = step.collect()
         return last
 
-    run(args.warmup)
-    torch.cuda.synchronize()
+    def timed(nwarm, nsteps):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+        run(nwarm)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        del host_ms[:]
+        t0 = time.perf_counter()
+        last = run(nsteps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt)
+        return el, last
+
+    elapsed, losses = timed(args.warmup, args.steps)
+    host_enqueue = sorted(host_ms)[len(host_ms) // 2] if host_ms else 0.0
+    replays = step.graph_replays
     if world > 1:
-        dist.barrier()
-    PROF_STRIDE = 7         # the timed region brackets every 7th conv launch with HIP events (an event pair costs ~3 us of device time;
-                            # 7 is co-prime with the conv launches per step, so all layers are sampled evenly over the steps)
-    if not args.no_prof:
-        lib.dsrl_prof_enable(PROF_STRIDE)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    losses = run(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
         # data-parallel invariant: after K identical-seed steps every rank must hold bit-identical parameters
         chk = torch.stack([flat.p_flat.double().sum(), flat.p_flat.double().abs().sum()])
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), f'ranks diverged: {lo.tolist()} vs {hi.tolist()}'
+
+    # the same step under the other conv arithmetics, timed over the SAME warm-up / step counts (every rank takes part)
+    by_arith = None
+    default_mode = HF.get_conv_precision()
+    if not args.no_prof:
+        gb = args.batch * world
+        by_arith = {default_mode: round(gb * args.steps / elapsed, 1)}
+        for mode in ('bf16x6', 'mixed', 'fp32'):
+            if mode == default_mode:
+                continue
+            HF.set_conv_precision(mode)
+            el, _ = timed(args.warmup, args.steps)
+            by_arith[mode] = round(gb * args.steps / el, 1)
+        HF.set_conv_precision(None)
 
     def read_prof(nsteps, stride=1):
         fams = []
@@ -171,70 +350,66 @@ def main():
                                             'frac': round(f[3] / (f[2] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[f[4]], 4) if f[2] > 0 else 0.0}
                                      for f in fams}}
 
-    from dualsuperreslearningforsemseg_amd import functional as HF
-    conv_arith = {'fp32': 'fp32 MFMA', 'bf16x3': 'bf16x3 split, fp32 accumulate', 'bf16x6': 'bf16x6 split (fp32-equivalent), fp32 accumulate',
-                  'mixed': 'forward bf16x6 (fp32-equivalent), dgrad/wgrad bf16x3; fp32 storage and accumulation'}[HF.get_conv_precision()]
     roof = None
     if not args.no_prof:
-        timed = read_prof(args.steps, PROF_STRIDE)
-        roof = {'bound': 'mfma', 'peak': None, 'unit': 'TFLOP/s', 'traffic': None}
-        if HF.overlap_wgrad:
-            # In the timed region weight-gradient kernels run on a side stream concurrently with data-gradient / BN kernels, so a
-            # kernel's event-to-event time includes the share of the GPU it gave away. The per-kernel roofline is therefore taken
-            # from a few extra steps with that overlap disabled (kernels run one at a time); both figures are reported.
-            HF.overlap_wgrad = False
-            run(1); torch.cuda.synchronize()
-            lib.dsrl_prof_enable(1)
-            excl_steps = 5
-            run(excl_steps); torch.cuda.synchronize()
-            excl = read_prof(excl_steps)
-            HF.overlap_wgrad = True
-            roof.update(excl)
-            roof['measured'] = f'{excl_steps} extra steps right after the timed region, weight-gradient side stream disabled (exclusive kernel execution)'
-            roof['timed_region_with_stream_overlap'] = {k: timed[k] for k in ('kernel', 'achieved', 'peak', 'frac', 'avg_launch_ms', 'launches_timed', 'kernel_ms_per_step', 'all_mfma_kernels')}
-            roof['timed_region_with_stream_overlap']['sampling'] = f'every {PROF_STRIDE}th conv launch of the timed region'
-        else:
-            roof.update(timed)
-            roof['measured'] = 'timed region'
-
-    if roof is not None:
+        # Per-kernel durations: the timed region replays a hipGraph (no place for per-launch events) and overlaps weight-gradient kernels
+        # with the rest of backward, so the roofline comes from a few extra EAGER steps right behind it, every conv launch bracketed by
+        # HIP events on its launch stream and the weight-gradient side stream off (a kernel's bracket is then its own execution).
+        graph_was, overlap_was = step.use_graph, HF.overlap_wgrad
+        step.use_graph, HF.overlap_wgrad = False, False
+        run(2); torch.cuda.synchronize()
+        lib.dsrl_prof_enable(1)
+        excl_steps = 5
+        run(excl_steps); torch.cuda.synchronize()
+        roof = {'bound': 'mfma', 'unit': 'TFLOP/s', 'traffic': None}
+        roof.update(read_prof(excl_steps))
+        roof['measured'] = (f'{excl_steps} eager steps right after the timed region (same process, same tensors), HIP events around every conv launch on its '
+                            'launch stream, weight-gradient side stream disabled (exclusive kernel execution)')
+        step.use_graph, HF.overlap_wgrad = graph_was, overlap_was
         try:        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (not collectable in-process)
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'round1_pmc_traffic.json')))
-            if (args.stage, args.height, args.width, args.batch) == (3, 256, 512, 8) and roof.get('kernel') in pmc:
-                roof['traffic'] = pmc[roof['kernel']]['hbm_bytes_per_launch']
-                roof['traffic_source'] = 'profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950)'
+            for fn in ('round2_pmc_traffic.json', 'round1_pmc_traffic.json'):
+                path = os.path.join(ROOT, 'profiles', fn)
+                if not os.path.isfile(path):
+                    continue
+                pmc = json.load(open(path))
+                if (args.stage, args.height, args.width, args.batch) == (3, 256, 512, 8) and roof.get('kernel') in pmc:
+                    roof['traffic'] = pmc[roof['kernel']]['hbm_bytes_per_launch']
+                    roof['traffic_source'] = f'profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950)'
+                    break
         except Exception:
             pass
+        if world == 1:
+            roof['decoder_stack'] = decoder_stack_roofline(torch, HF, args.batch, args.height, args.width)
 
-    # the same step under the stricter conv arithmetics, a few steps each (single GPU only): fp32-equivalent bf16x6 everywhere and
-    # exact-product fp32 MFMA.  The headline `value` is the default 'mixed' mode (bf16x6 forward, bf16x3 backward), see DESIGN.md 3b.
-    by_arith = None
-    if world == 1 and not args.no_prof and HF.get_conv_precision() == 'mixed':
-        by_arith = {}
-        for mode in ('bf16x6', 'fp32'):
-            HF.set_conv_precision(mode)
-            run(3); torch.cuda.synchronize()
-            t1 = time.perf_counter(); run(10); torch.cuda.synchronize()
-            by_arith[mode] = round(args.batch * 10 / (time.perf_counter() - t1), 1)
-        HF.set_conv_precision(None)
+    hbm = None
+    if not args.no_prof and world == 1:
+        hbm = hbm_roofline(torch, HF, flat, args.batch, args.height, args.width)
 
     if rank == 0:
         gb = args.batch * world
+        is_headline = (args.stage, args.height, args.width) == (3, 256, 512)
         line = {
-            'metric': 'stage-3 train images/sec at 256x512->512x1024' if (args.stage, args.height, args.width) == (3, 256, 512)
-                      else f'stage-{args.stage} train images/sec at {args.height}x{args.width}',
+            'metric': 'stage-3 train images/sec at 256x512->512x1024' if is_headline
+                      else f'stage-{args.stage} train images/sec at {args.height}x{args.width}->{2 * args.height}x{2 * args.width}',
             'value': round(gb * args.steps / elapsed, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'host_enqueue_ms_per_step': round(sorted(host_ms[args.warmup:args.warmup + args.steps])[args.steps // 2], 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'conv_arithmetic': conv_arith, 'images_per_s_by_conv_arithmetic': by_arith, 'data': 'synthetic',
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'host_enqueue_ms_per_step': round(host_enqueue, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'conv_arithmetic': ARITH_TEXT[default_mode], 'images_per_s_by_conv_arithmetic': by_arith, 'data': 'synthetic',
             'config': {'workload': f'DSRL stage {args.stage} (ResNet-101 OS16 + ASPP + SSSR/SISR decoders + FA loss), full train step, '
-                                   f'random-init weights, {args.height}x{args.width} input -> {2 * args.height}x{2 * args.width} logits',
+                                   f'random-init weights, {args.height}x{args.width} input -> {2 * args.height}x{2 * args.width} logits'
+                                   + ('' if is_headline else ' (not the headline configuration; BASELINE config 5 is --height 512 --width 1024)'),
                        'global_batch': gb, 'per_gpu_batch': args.batch, 'parallelism': f'dp{world}', 'optimizer': 'SGD m0.9 wd5e-4 lr0.006',
+                       'step_execution': (f'hipGraph replay ({replays} of the {args.steps + args.warmup} headline iterations; collectives and SGD follow the replay when dp > 1)'
+                                          if replays else 'eager launches'),
                        'losses_last_step': [round(v, 5) for v in losses]},
-            'roofline': roof,
+            'roofline': roof, 'roofline_hbm': hbm,
         }
-        if not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline(model.state_dict())
+        if weights0 is not None:
+            line['cpu_baseline'] = cpu_baseline_torch(weights0, args.stage)
+            if args.stage == 3:
+                line['cpu_baseline_numpy_port'] = cpu_baseline_numpy(weights0)
         print(json.dumps(line), flush=True)
+    step.release()
     if world > 1:
         dist.destroy_process_group()
 

@@ -91,7 +91,10 @@ PROTOTYPES = {
     'dsrl_seg_metrics': (i32, [fp, i32, fp, i64, i32, i32, fp, stream_t]),
     'dsrl_prepare_batch': (i32, [fp, fp, fp, C.POINTER(f32), C.POINTER(f32), fp, fp, fp, i32, i32, i32, i32, i32, stream_t]),
     'dsrl_sgd_step': (i32, [fp, fp, fp, i64, f32, f32, f32, f32, stream_t]),
+    'dsrl_sgd_step_dev': (i32, [fp, fp, fp, i64, fp, stream_t]),
     'dsrl_nan_check': (i32, [fp, i64, fp, stream_t]),
+    'dsrl_rng_bind_device_key': (i32, [fp]),
+    'dsrl_rng_advance_key': (i32, [fp, stream_t]),
     'dsrl_prof_enable': (i32, [i32]),
     'dsrl_prof_read': (i32, [i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'dsrl_prof_read_bytes': (i32, [i32, C.POINTER(C.c_double)]),

@@ -60,16 +60,39 @@ class SyntheticCityscapes:
             yield self.batches[i % len(self.batches)]
 
 
-class TrainStep:
-    """One iteration of train_or_resume.py:404-460 for a fixed model/arena."""
+class _CapturedStep:
+    __slots__ = ('graph', 'img', 'org', 'tgt', 'outs', 'vals', 'bns')
 
-    def __init__(self, model, flat, stage, w1, w2, ignore_index):
+
+class TrainStep:
+    """One iteration of train_or_resume.py:404-460 for a fixed model/arena.
+
+    With `graph` (default: on, DSRL_GRAPH=0 turns it off) a training iteration is captured once per batch shape into a hipGraph -
+    key advance, gradient zeroing, filter transposes, forward, losses, backward, SGD update - and replayed: ~1000 kernel launches
+    become one hipGraphLaunch, so the host no longer paces the device.  What makes the capture replayable: the dropout key and the
+    optimiser hyper-parameters are read from device memory (functional.DeviceRng, dsrl_sgd_step_dev), the fused BatchNorm barrier
+    is self-resetting, and the batch is copied into static input buffers.  With more than one rank the collectives stay outside the
+    graph: BN-buffer broadcast before the replay, chunked gradient all-reduce and the SGD kernel after it."""
+
+    GRAPH_WARMUP = 2          # eager iterations per batch shape before the capture (lazy initialisation, allocator warm-up)
+
+    def __init__(self, model, flat, stage, w1, w2, ignore_index, graph=None):
         self.model, self.flat, self.stage, self.w1, self.w2, self.ignore = model, flat, stage, w1, w2, ignore_index
         self.fa = FALoss()
         dev = flat.device
         self.flag = t.zeros(1, dtype=t.int32, device=dev)
         self.zero = t.zeros((), device=dev)
         self._pending, self._free = [], []           # (pinned host buffer, event) of iterations in flight / reusable
+        self.use_graph = (os.environ.get('DSRL_GRAPH', '1') != '0') if graph is None else bool(graph)
+        self._graphs, self._warm = {}, {}
+        self.rng = self.hyper = self._hyper_host = self._hyper_vals = None
+        self.host_enqueue_s = 0.0
+        self.graph_replays = 0
+        if self.use_graph and flat.world > 1:
+            # the collectives of a replayed step run behind the graph, never beside its kernels: no hook-launched all-reduce, and the
+            # fused BatchNorm kernels can have every CU (ddp.FlatParams caps them at 128 blocks for the overlapped eager path)
+            flat.defer_collectives = True
+            HF.set_bn_fused_max_blocks(None)
 
     def losses(self, outs, input_org, target):
         SSSR, SISR, SSSR_ft, SISR_ft = outs
@@ -78,18 +101,16 @@ class TrainStep:
         fa = self.w2 * self.fa(SSSR_ft, SISR_ft) if self.stage > 2 else self.zero          # :437
         return ce, ms, fa, ce + ms + fa                                                    # :438
 
-    def enqueue(self, input_image, input_org, target, lr, momentum, weight_decay, do_train=True):
-        """Enqueue one whole iteration on the device and start the asynchronous device->host copy of its five scalars (CE, MSE,
-        FA, total, NaN flag) into pinned memory.  Nothing is waited for: collect() returns the values of the OLDEST iteration
-        still outstanding.  Calling enqueue(k+1) before collect(k) keeps the launch queue fed across the iteration boundary
-        (the reference reads its losses synchronously every iteration, train_or_resume.py:457-460; here the read of
-        iteration k overlaps the enqueue of k+1 and the NaN assert fires one iteration late).  Returns the network outputs."""
-        import time
-        t_host0 = time.perf_counter()
+    # ------------------------------------------------------------------ the iteration itself (eager, or under capture)
+    def _body(self, input_image, input_org, target, hp, do_train, in_graph=False):
         flat = self.flat
+        dev_mode = self.rng is not None
         if do_train:
+            if dev_mode:
+                self.rng.advance()                # this step's dropout key, derived on the device
             flat.zero_grad()                                                               # optimizer.zero_grad(), :418
-            flat.sync_buffers()
+            if not in_graph:
+                flat.sync_buffers()
             flat.refresh_transposed_filters()     # one launch: the [C][R][S][K] filter copies every dgrad of this step reads
         self.flag.zero_()
         with t.set_grad_enabled(do_train):
@@ -97,9 +118,100 @@ class TrainStep:
             HF.nan_check_(self.flag, *[o for o in outs if o.is_cuda])                      # the four NaN asserts, :426-433
             ce, ms, fa, total = self.losses(outs, input_org, target)
             if do_train:
-                total.backward()                                                           # :444 (chunked RCCL all-reduce overlaps)
-                flat.sgd_step(lr, momentum, weight_decay)                                  # :445
+                total.backward()                                                           # :444 (eager: chunked RCCL all-reduce overlaps)
+                if in_graph and flat.world > 1:
+                    HF.join_side_streams()        # the collectives and the update follow the replay (_replay)
+                elif flat.defer_collectives and flat.world > 1:
+                    HF.join_side_streams()        # graph mode, iterations before the capture: the same order of events, eagerly
+                    flat.reduce_all()
+                    flat.sgd_step(hp[0], hp[1], hp[2], hyper=self.hyper if dev_mode else None, reduce=False)
+                else:
+                    flat.sgd_step(hp[0], hp[1], hp[2], hyper=self.hyper if dev_mode else None)     # :445
         vals = t.cat([t.stack([ce, ms, fa, total]).detach().float(), self.flag.float()])
+        return outs, vals
+
+    def _set_hyper(self, hp):
+        vals = (float(hp[0]), float(hp[1]), float(hp[2]), 1.0 / self.flat.world)
+        if vals != self._hyper_vals:
+            self._hyper_host.copy_(t.tensor(vals, dtype=t.float32))
+            self.hyper.copy_(self._hyper_host, non_blocking=True)
+            self._hyper_vals = vals
+
+    def _graph_key(self, input_image, input_org, target):
+        return (tuple(input_image.shape), tuple(input_org.shape), tuple(target.shape), HF.get_conv_precision(), HF.overlap_wgrad)
+
+    def _capture(self, key, input_image, input_org, target, hp):
+        c = _CapturedStep()
+        c.img, c.org, c.tgt = input_image.clone(), input_org.clone(), target.clone()
+        bns = [m for m in self.model.modules() if isinstance(m, t.nn.modules.batchnorm._BatchNorm)]
+        before = [getattr(m, '_dsrl_batches', 0) for m in bns]
+        step_before = HF._rng_state['step']
+        c.graph = t.cuda.CUDAGraph()
+        # A forked capture (weight gradients on a side stream) replays slower than a linear one on this runtime: the graph executor
+        # pays more for its cross-queue dependencies than the overlap wins (measured 24.2 vs 23.8 ms per step), so the capture is
+        # linear unless DSRL_GRAPH_OVERLAP=1
+        overlap_was = HF.overlap_wgrad
+        if os.environ.get('DSRL_GRAPH_OVERLAP', '0') == '0':
+            HF.overlap_wgrad = False
+        try:
+            with t.cuda.graph(c.graph, capture_error_mode=os.environ.get('DSRL_GRAPH_CAPTURE_MODE', 'thread_local')):
+                c.outs, c.vals = self._body(c.img, c.org, c.tgt, hp, True, in_graph=True)
+        finally:
+            HF.overlap_wgrad = overlap_was
+        # nothing ran during the capture: take back the host-side bookkeeping of that phantom iteration
+        HF._rng_state['step'] = step_before
+        c.bns = [m for m, n in zip(bns, before) if getattr(m, '_dsrl_batches', 0) != n]
+        for m, n in zip(bns, before):
+            if hasattr(m, '_dsrl_batches'):
+                m._dsrl_batches = n
+        self._graphs[key] = c
+        return c
+
+    def _replay(self, c, input_image, input_org, target):
+        flat = self.flat
+        for dst, src in ((c.img, input_image), (c.org, input_org), (c.tgt, target)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        if flat.world > 1:
+            flat.sync_buffers()
+        c.graph.replay()
+        HF._rng_state['step'] += 1              # host mirror of the key the device just derived
+        HF._rng_state['current'] = HF._derive(HF._rng_state['step'])
+        for m in c.bns:
+            m._dsrl_batches += 1
+        if flat.world > 1:
+            flat.reduce_all()
+            flat.sgd_step(0.0, 0.0, 0.0, hyper=self.hyper, reduce=False)
+        self.graph_replays += 1
+        return c.outs, c.vals
+
+    def enqueue(self, input_image, input_org, target, lr, momentum, weight_decay, do_train=True):
+        """Enqueue one whole iteration on the device and start the asynchronous device->host copy of its five scalars (CE, MSE,
+        FA, total, NaN flag) into pinned memory.  Nothing is waited for: collect() returns the values of the OLDEST iteration
+        still outstanding.  Calling enqueue(k+1) before collect(k) keeps the launch queue fed across the iteration boundary
+        (the reference reads its losses synchronously every iteration, train_or_resume.py:457-460; here the read of
+        iteration k overlaps the enqueue of k+1 and the NaN assert fires one iteration late).  Returns the network outputs
+        (in graph mode: the capture's static output tensors, overwritten by the next replay)."""
+        import time
+        t_host0 = time.perf_counter()
+        hp = (lr, momentum, weight_decay)
+        if do_train and self.use_graph:
+            if self.rng is None:
+                self.rng = HF.DeviceRng(self.flat.device)
+                self.hyper = t.zeros(4, device=self.flat.device)
+                self._hyper_host = t.empty(4, dtype=t.float32, pin_memory=True)
+            self._set_hyper(hp)
+            key = self._graph_key(input_image, input_org, target)
+            c = self._graphs.get(key)
+            if c is None and self._warm.get(key, 0) >= self.GRAPH_WARMUP:
+                c = self._capture(key, input_image, input_org, target, hp)
+            if c is None:
+                self._warm[key] = self._warm.get(key, 0) + 1
+                outs, vals = self._body(input_image, input_org, target, hp, True)
+            else:
+                outs, vals = self._replay(c, input_image, input_org, target)
+        else:
+            outs, vals = self._body(input_image, input_org, target, hp, do_train)
         if len(self._free) == 0:
             self._free.append((t.empty(5, dtype=t.float32, pin_memory=True), t.cuda.Event()))
         host, ev = self._free.pop()
@@ -125,6 +237,13 @@ class TrainStep:
                                    'is another process using this GPU? (functional.set_bn_fused_max_blocks(0) selects the three-kernel path)')
             raise AssertionError("network output contains 'NaN' values and so cannot continue.")
         return vals[:4]
+
+    def release(self):
+        """Drops the captured graphs and unbinds the device-resident dropout key (launches take their `seed` argument again)."""
+        self._graphs.clear()
+        if self.rng is not None:
+            self.rng.release()
+            self.rng = None
 
     def __call__(self, input_image, input_org, target, lr, momentum, weight_decay, do_train=True):
         """Synchronous form: enqueue + collect of the same iteration."""

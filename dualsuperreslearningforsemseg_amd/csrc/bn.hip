@@ -9,6 +9,8 @@
 #include <mutex>
 #include <stdlib.h>
 
+struct SeedArg { unsigned long long value; const unsigned long long* dev; };
+
 namespace dsrl {
 
 constexpr int kMaxRowBlocks = 256;
@@ -112,7 +114,8 @@ __global__ void invstd_from_var_kernel(const float* __restrict__ var, int C, flo
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long P, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const float* __restrict__ res, int ldr, int relu, float drop_p, unsigned long long seed, unsigned rng_stream) {
+                                                        const float* __restrict__ res, int ldr, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream) {
+    const unsigned long long seed = seed_arg.dev ? *seed_arg.dev : seed_arg.value;     // device-resident key: replayable from a graph
     const ChanMap m = chan_map(C, blockIdx.y);
     if (m.c < 0) return;
     const float sc = gamma[m.c] * invstd[m.c];
@@ -240,7 +243,8 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 
 // ---------------------------------------------------------------------------------------------- dropout
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long P, int C,
-                                                       float p_drop, unsigned long long seed, unsigned rng_stream) {
+                                                       float p_drop, SeedArg seed_arg, unsigned rng_stream) {
+    const unsigned long long seed = seed_arg.dev ? *seed_arg.dev : seed_arg.value;     // device-resident key: replayable from a graph
     const long long total = P * C;
     const float ks = 1.f / (1.f - p_drop);
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -317,7 +321,8 @@ __global__ __launch_bounds__(256) void bn_partial4_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long P, int C,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const float* __restrict__ res, int ldr, int relu, float drop_p, unsigned long long seed, unsigned rng_stream) {
+                                                         const float* __restrict__ res, int ldr, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream) {
+    const unsigned long long seed = seed_arg.dev ? *seed_arg.dev : seed_arg.value;     // device-resident key: replayable from a graph
     const ChanMap4 m = chan_map4(C, blockIdx.y);
     if (m.q < 0) return;
     float sc[4], sh[4];
@@ -421,35 +426,49 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
 // bound there.  One kernel instead: 256 blocks = (channel group of 32 channels = one 128-byte line per pixel) x (row slab); a
 // block keeps its whole slab in registers (<= 16 float4 per thread and tensor), writes one partial per channel, crosses ONE
 // device-wide barrier, merges the <= 256 slab partials of its own 32 channels (every block of a group computes bit-identical
-// statistics: same partials, same order) and applies from registers - the tensor is read once.  The barrier is a monotonic
-// arrival counter: a launch is handed the count all earlier launches leave behind (host side, under a mutex, stream-ordered).
+// statistics: same partials, same order) and applies from registers - the tensor is read once.  The barrier is a self-resetting
+// arrival counter + generation word (grid_barrier below): nothing is handed over by the host, so a launch can be replayed from a graph.
 // 256 blocks of <= 128 registers are always co-resident on 256 CUs; the spin is bounded so that a bug cannot hang the GPU.
-__device__ unsigned long long g_grid_arrivals = 0ull;
+__device__ unsigned int g_grid_count = 0u;               // arrivals of the barrier in progress (back to 0 when it completes)
+__device__ unsigned int g_grid_gen = 0u;                 // generation: bumped by the last arriver, which is what the others wait for
 __device__ unsigned int g_grid_timeouts = 0u;           // blocks that gave up waiting (dsrl_bn_fused_barrier_timeouts)
 constexpr int kFusedBlocks = 128, kFusedBlocksBig = 256, kFusedThreads = 512, kFusedMaxPasses = 16;   // measured: the barrier costs ~20 ns per arriving block,
                                                                                                    // so 128 blocks unless the tensor needs the registers of 256
 constexpr int kFusedRL = kFusedThreads / 8, kFusedNW = kFusedThreads / 64, kFusedNS = kFusedThreads / 32;   // row lanes, waves, merge slices
 
-// Hand-off protocol (MI355X_MICROARCH.md, "Correctness boundaries", second valid form): the per-XCD L2s are not coherent with each
+// Hand-off protocol (MI355X_MICROARCH.md, "Valid forms", sc1 stores + sc1 loads): the per-XCD L2s are not coherent with each
 // other, so every handed-off value (the slab partials) is written with an agent-scope store (sc1: written through to the
-// coherence point) that is drained (vmcnt(0), which __syncthreads() implies for the storing wave) before the arrival counter is
-// bumped, and read back with agent-scope loads (st_agent / ld_agent).  No L2-wide write-back / invalidate is needed, which is what
-// an agent-scope release/acquire fence pair would cost in every one of the 256 blocks.
-__device__ inline bool grid_barrier(unsigned long long target) {
+// coherence point); EVERY storing wave drains its stores (s_waitcnt vmcnt(0), explicit inline asm - __syncthreads() alone only
+// waits for LDS traffic) before the workgroup barrier behind which lane 0 bumps the arrival counter, and the partials are read
+// back with agent-scope loads (st_agent / ld_agent).  No L2-wide write-back / invalidate is needed, which is what an agent-scope
+// release/acquire fence pair would cost in every one of the 256 blocks.
+// The barrier itself is self-resetting (sense reversal): lane 0 reads the generation, arrives, and either - as the last of the
+// `nblocks` arrivers - zeroes the count and bumps the generation, or spins until the generation moves.  No state is handed over by
+// the host, so a launch may be replayed from a hipGraph; the fused launches of one device must not overlap each other (the host
+// side keeps them on one stream, see dsrl_bn_train_fwd).
+__device__ inline bool grid_barrier(unsigned nblocks) {
     __shared__ int ok_sh;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's sc1 partial stores have reached the coherence point
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(&g_grid_arrivals, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
+        const unsigned gen = __hip_atomic_load(&g_grid_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the generation is read BEFORE this block counts as arrived
+        const unsigned prev = __hip_atomic_fetch_add(&g_grid_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool ok = true;
-        while (__hip_atomic_load(&g_grid_arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins >= (1u << 25)) {                                 // seconds: the other blocks never became resident
-                ok = false;
-                __hip_atomic_fetch_add(&g_grid_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
+        if (prev + 1u == nblocks) {
+            __hip_atomic_store(&g_grid_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the reset lands before anybody is released
+            __hip_atomic_fetch_add(&g_grid_gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&g_grid_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                if (++spins >= (1u << 25)) {                                 // seconds: the other blocks never became resident
+                    ok = false;
+                    __hip_atomic_fetch_add(&g_grid_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
             }
-            __builtin_amdgcn_s_sleep(1);
         }
         ok_sh = ok ? 1 : 0;
     }
@@ -473,8 +492,9 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_fwd_kernel(const float
                                                             int groups, int slabs, int rows_per_slab, float eps, float momentum,
                                                             float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ rm, float* __restrict__ rv,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            const float* __restrict__ res, int ldr, int relu, float drop_p, unsigned long long seed, unsigned rng_stream,
-                                                            float* part, unsigned long long target) {
+                                                            const float* __restrict__ res, int ldr, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream,
+                                                            float* part) {
+    const unsigned long long seed = seed_arg.dev ? *seed_arg.dev : seed_arg.value;     // device-resident key: replayable from a graph
     __shared__ float shw[kFusedNW][3][4][8];          // per wave: (n, mean, M2) x 4 channels x 8 float4 columns
     __shared__ double shm[kFusedNS][3][32];           // cross-slab merge: 8 slices x 3 sums x 32 channels
     __shared__ float fin[2][32];               // mean, invstd of the group's channels
@@ -531,7 +551,7 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_fwd_kernel(const float
         const long long o = (long long)slab * C + grp * 32 + tid;
         st_agent(part + o, na); st_agent(part + (long long)slabs * C + o, ma); st_agent(part + 2ll * slabs * C + o, qa);
     }
-    const bool arrived = grid_barrier(target);
+    const bool arrived = grid_barrier(gridDim.x);
     // ---- statistics of the group's 32 channels from all slabs in one pass, fp64, shifted by slab 0's mean (no cancellation):
     //      N = sum n, S = sum n d, T = sum (M2 + n d^2), d = m - m_ref;  mean = m_ref + S / N, M2 = T - S^2 / N.
     //      8 slices of the slabs per channel, 4 slabs (12 independent loads) in flight per thread; slice results added in fixed order
@@ -607,7 +627,7 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_bwd_kernel(const float
                                                             float* __restrict__ dres, int lddr, int P, int C, int groups, int slabs, int rows_per_slab,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int relu, float drop_p, int training,
-                                                            float* part, unsigned long long target) {
+                                                            float* part) {
     __shared__ float shw[kFusedNW][2][4][8];
     __shared__ double shm[kFusedNS][2][32];
     __shared__ float fin[2][32];               // sum g / n, sum g*xhat / n
@@ -657,7 +677,7 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_bwd_kernel(const float
         const long long o = (long long)slab * C + grp * 32 + tid;
         st_agent(part + o, a); st_agent(part + (long long)slabs * C + o, b);
     }
-    const bool arrived = grid_barrier(target);
+    const bool arrived = grid_barrier(gridDim.x);
     {
         const int ch = tid & 31, k = tid >> 5;
         const float* pa = part + grp * 32 + ch;
@@ -713,8 +733,9 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(const float* __rest
                                                               int groups, int rows_per_slab, float eps, float momentum,
                                                               float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ rm, float* __restrict__ rv,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              const float* __restrict__ res, int ldr, int relu, float drop_p, unsigned long long seed, unsigned rng_stream,
+                                                              const float* __restrict__ res, int ldr, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream,
                                                               const float* __restrict__ part, int nparts) {
+    const unsigned long long seed = seed_arg.dev ? *seed_arg.dev : seed_arg.value;     // device-resident key: replayable from a graph
     __shared__ double shm[8][3][32];
     __shared__ float fin[2][32];
     const int grp = blockIdx.x % groups, slab = blockIdx.x / groups;
@@ -880,6 +901,14 @@ using namespace dsrl;
 extern "C" size_t dsrl_bn_workspace_bytes(int64_t P, int C) { return (size_t)(3 * (size_t)std::max(row_blocks(P), 256) + 2) * C * sizeof(float); }
 
 namespace dsrl {
+// Dropout key of a launch: the `seed` argument of the call, or - once dsrl_rng_bind_device_key() has bound one for the device - the
+// 64-bit word at that device address, read by the kernel when it runs (so that a captured launch sees a fresh key on every replay).
+static std::atomic<const unsigned long long*> g_rng_dev_key[64];
+static SeedArg seed_arg(uint64_t seed) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    return SeedArg{(unsigned long long)seed, g_rng_dev_key[dev].load()};
+}
 static int env_int_bn(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static std::atomic<int> g_fused_max_blocks{-1};      // dsrl_bn_fused_max_blocks(); -1 = DSRL_BN_FUSED / DSRL_BN_FUSED_BIG from the environment
 struct FusedPlan { bool ok; int blocks, groups, slabs, rows_per_slab; };
@@ -900,17 +929,21 @@ static FusedPlan fused_plan(int64_t P, int C) {
     }
     return f;
 }
-// arrival count every earlier fused launch on this device leaves behind; launches are handed their barrier target in stream order
+// The fused kernels share one per-device barrier word pair, so two of them must never be in flight together: they are serialised by
+// running on ONE stream per device.  The first fused launch of a device pins its stream; a launch that arrives on another stream
+// (outside graph capture, where the capture's own stream stands in for it) takes the three-kernel path instead.
 static std::mutex g_fused_mu;
-static unsigned long long g_fused_base[64] = {0};
-struct FusedTicket {
-    std::unique_lock<std::mutex> lock; unsigned long long target; int dev;
-    explicit FusedTicket(int blocks) : lock(g_fused_mu), target(0), dev(0) {
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-        target = g_fused_base[dev] + (unsigned long long)blocks;
-    }
-    void launched() { g_fused_base[dev] = target; }
-};
+static hipStream_t g_fused_stream[64];
+static bool g_fused_stream_set[64] = {false};
+static bool fused_stream_ok(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) return true;   // a graph orders its own nodes
+    std::lock_guard<std::mutex> lock(g_fused_mu);
+    if (!g_fused_stream_set[dev]) { g_fused_stream[dev] = st; g_fused_stream_set[dev] = true; }
+    return g_fused_stream[dev] == st;
+}
 }  // namespace dsrl
 
 extern "C" size_t dsrl_colsum_workspace_bytes(int64_t P, int C) { return (size_t)row_blocks(P) * C * sizeof(float); }
@@ -949,10 +982,10 @@ extern "C" int dsrl_bn_apply(const float* x, int ldx, float* y, int ldy, int64_t
     if (int e = bind_stream_device(st)) return e;
     if (vec4_ok(C, {ldx, ldy, residual ? ldr : 0}, {x, y, residual}))
         hipLaunchKernelGGL(bn_apply4_kernel, apply_grid4(P, C), dim3(256), 0, st, x, ldx, y, ldy, (long long)P, C, mean, invstd, gamma, beta, residual, ldr,
-                           relu, drop_p, (unsigned long long)seed, (unsigned)rng_stream);
+                           relu, drop_p, seed_arg(seed), (unsigned)rng_stream);
     else
         hipLaunchKernelGGL(bn_apply_kernel, apply_grid(P, C), dim3(256), 0, st, x, ldx, y, ldy, (long long)P, C, mean, invstd, gamma, beta, residual, ldr,
-                           relu, drop_p, (unsigned long long)seed, (unsigned)rng_stream);
+                           relu, drop_p, seed_arg(seed), (unsigned)rng_stream);
     return launch_status("bn_apply_kernel");
 }
 
@@ -966,7 +999,15 @@ extern "C" int dsrl_bn_fused_barrier_timeouts(int64_t* count) {
     DSRL_REQUIRE(count, DSRL_E_BADARG, "bn_fused_barrier_timeouts: null pointer");
     unsigned int v = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_grid_timeouts), sizeof(v)) != hipSuccess) return launch_status("hipMemcpyFromSymbol(g_grid_timeouts)");
-    *count = (int64_t)v;
+    *count = (int64_t)v;        // cumulative since the library was loaded
+    static unsigned int seen[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (v != seen[dev]) {       // new timeouts since the last query: a block that gave up left the arrival count behind - start the next barrier clean
+        const unsigned int zero = 0u;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_grid_count), &zero, sizeof(zero)) != hipSuccess) return launch_status("hipMemcpyToSymbol(g_grid_count)");
+        seen[dev] = v;
+    }
     return DSRL_OK;
 }
 
@@ -977,16 +1018,13 @@ extern "C" int dsrl_bn_train_fwd(const float* x, int ldx, float* y, int ldy, int
     DSRL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, DSRL_E_BADARG, "bn_train_fwd: dropout p=%f outside [0,1)", drop_p);
     DSRL_REQUIRE(ws_bytes >= dsrl_bn_workspace_bytes(P, C), DSRL_E_WORKSPACE, "bn_train_fwd: workspace too small");
     const FusedPlan f = fused_plan(P, C);
-    if (f.ok && vec4_ok(C, {ldx, ldy, residual ? ldr : 0}, {x, y, residual})) {
+    if (f.ok && vec4_ok(C, {ldx, ldy, residual ? ldr : 0}, {x, y, residual}) && bind_stream_device((hipStream_t)stream) == DSRL_OK &&
+        fused_stream_ok((hipStream_t)stream)) {
         hipStream_t st = (hipStream_t)stream;
-        if (int e = bind_stream_device(st)) return e;
-        FusedTicket t(f.blocks);
         hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3(f.blocks), dim3(kFusedThreads), 0, st, x, ldx, y, ldy, (int)P, C, f.groups, f.slabs, f.rows_per_slab, eps, momentum,
-                           mean, invstd, running_mean, running_var, gamma, beta, residual, ldr, relu, drop_p, (unsigned long long)seed, (unsigned)rng_stream,
-                           (float*)ws, t.target);
-        if (int e = launch_status("bn_fused_fwd_kernel")) return e;
-        t.launched();
-        return DSRL_OK;
+                           mean, invstd, running_mean, running_var, gamma, beta, residual, ldr, relu, drop_p, seed_arg(seed), (unsigned)rng_stream,
+                           (float*)ws);
+        return launch_status("bn_fused_fwd_kernel");
     }
     if (int e = dsrl_bn_stats(x, ldx, P, C, eps, momentum, mean, invstd, running_mean, running_var, ws, ws_bytes, stream)) return e;
     return dsrl_bn_apply(x, ldx, y, ldy, P, C, mean, invstd, gamma, beta, residual, ldr, relu, drop_p, seed, rng_stream, stream);
@@ -1007,7 +1045,7 @@ extern "C" int dsrl_bn_train_fwd_from_stats(const float* x, int ldx, float* y, i
     const int rows_per_slab = (int)ceil_div(P, (int64_t)slabs);
     slabs = (int)ceil_div(P, (int64_t)rows_per_slab);
     hipLaunchKernelGGL(bn_stats_apply_kernel, dim3((unsigned)(groups * slabs)), dim3(256), 0, st, x, ldx, y, ldy, (int)P, C, groups, rows_per_slab, eps, momentum,
-                       mean, invstd, running_mean, running_var, gamma, beta, residual, ldr, relu, drop_p, (unsigned long long)seed, (unsigned)rng_stream, stats, stats_parts);
+                       mean, invstd, running_mean, running_var, gamma, beta, residual, ldr, relu, drop_p, seed_arg(seed), (unsigned)rng_stream, stats, stats_parts);
     return launch_status("bn_stats_apply_kernel");
 }
 
@@ -1021,13 +1059,10 @@ extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, con
     if (int e = bind_stream_device(st)) return e;
     const bool v4 = vec4_ok(C, {ldx, y ? ldy : 0, lddy, lddx, dresidual ? lddr : 0}, {x, y, dy, dx, dresidual});
     const FusedPlan f = fused_plan(P, C);
-    if (f.ok && v4) {
-        FusedTicket t(f.blocks);
+    if (f.ok && v4 && fused_stream_ok(st)) {
         hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3(f.blocks), dim3(kFusedThreads), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (int)P, C,
-                           f.groups, f.slabs, f.rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, drop_p, training, (float*)ws, t.target);
-        if (int e = launch_status("bn_fused_bwd_kernel")) return e;
-        t.launched();
-        return DSRL_OK;
+                           f.groups, f.slabs, f.rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, drop_p, training, (float*)ws);
+        return launch_status("bn_fused_bwd_kernel");
     }
     const int nbx = row_blocks(P);
     const long long rpb = ceil_div(P, nbx);
@@ -1082,13 +1117,30 @@ extern "C" int dsrl_colsum(const float* x, int ld, int64_t P, int C, float* out,
     return launch_status("colsum_finalize_kernel");
 }
 
+__global__ void rng_advance_kernel(unsigned long long* state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { state[1] += 1ull; state[0] = state[2] * 1000003ull + state[1]; }
+}
+extern "C" int dsrl_rng_bind_device_key(const uint64_t* dev_key) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("rng_bind_device_key: no current HIP device"); (void)hipGetLastError(); return DSRL_E_LAUNCH; }
+    g_rng_dev_key[dev].store((const unsigned long long*)dev_key);
+    return DSRL_OK;
+}
+extern "C" int dsrl_rng_advance_key(uint64_t* state, dsrl_stream_t stream) {
+    DSRL_REQUIRE(state && ((uintptr_t)state % 8) == 0, DSRL_E_BADARG, "rng_advance_key: state must be three 8-byte aligned 64-bit words on the device");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, st, (unsigned long long*)state);
+    return launch_status("rng_advance_kernel");
+}
+
 static int dropout_common(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float p, uint64_t seed, uint32_t rng_stream, dsrl_stream_t stream) {
     DSRL_REQUIRE(x && y && P > 0 && C > 0 && p >= 0.f && p < 1.f, DSRL_E_BADARG, "dropout: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
     const long long total = (long long)P * C;
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 8192)), dim3(256), 0, st, x, ldx, y, ldy, (long long)P, C, p,
-                       (unsigned long long)seed, (unsigned)rng_stream);
+                       seed_arg(seed), (unsigned)rng_stream);
     return launch_status("dropout_kernel");
 }
 extern "C" int dsrl_dropout_fwd(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float p, uint64_t seed, uint32_t rng_stream, dsrl_stream_t stream) {

@@ -1248,7 +1248,7 @@ static int pick_splits(long long tiles, int nq) {
     return (int)std::max<long long>(1, std::min<long long>(nq / 24, cap));
 }
 
-// Conv arithmetic, per pass.  Mode (dsrl_conv_precision(), else DSRL_CONV_PRECISION, else the default 3):
+// Conv arithmetic, per pass.  Mode (dsrl_conv_precision(), else DSRL_CONV_PRECISION, else the default 2 = fp32-equivalent):
 //   0  fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32, exact products)
 //   1  bf16x3 everywhere   (16 mantissa bits per operand, ~5e-6 relative error per conv)
 //   2  bf16x6 everywhere   (24 mantissa bits per operand: fp32-equivalent, measured error vs fp64 equal to mode 0)
@@ -1257,7 +1257,7 @@ static int pick_splits(long long tiles, int nq) {
 enum ConvPass { PASS_FWD, PASS_DGRAD, PASS_WGRAD };
 static int conv_precision_mode() {
     int prec = g_conv_precision.load();
-    if (prec < 0) prec = env_int("DSRL_CONV_PRECISION", 3);
+    if (prec < 0) prec = env_int("DSRL_CONV_PRECISION", 2);
     return prec < 0 ? 0 : (prec > 3 ? 3 : prec);
 }
 static int conv_planes(ConvPass pass) {

@@ -299,6 +299,26 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
         buf[e] = bv; p[e] -= lr * bv;
     }
 }
+// the same update with the four hyper-parameters read from device memory (a captured launch follows the LR schedule without re-capture)
+__global__ __launch_bounds__(256) void sgd_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long long n,
+                                                       const float* __restrict__ hyper) {
+    const float lr = hyper[0], mom = hyper[1], wd = hyper[2], gscale = hyper[3];
+    const long long n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p); const float4* g4 = reinterpret_cast<const float4*>(g); float4* b4 = reinterpret_cast<float4*>(buf);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
+        float4 pv = p4[e]; const float4 gv = g4[e]; float4 bv = b4[e];
+        bv.x = mom * bv.x + fmaf(wd, pv.x, gv.x * gscale); pv.x -= lr * bv.x;
+        bv.y = mom * bv.y + fmaf(wd, pv.y, gv.y * gscale); pv.y -= lr * bv.y;
+        bv.z = mom * bv.z + fmaf(wd, pv.z, gv.z * gscale); pv.z -= lr * bv.z;
+        bv.w = mom * bv.w + fmaf(wd, pv.w, gv.w * gscale); pv.w -= lr * bv.w;
+        p4[e] = pv; b4[e] = bv;
+    }
+    for (long long e = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const float d = fmaf(wd, p[e], g[e] * gscale);
+        const float bv = mom * buf[e] + d;
+        buf[e] = bv; p[e] -= lr * bv;
+    }
+}
 __global__ __launch_bounds__(256) void nan_check_kernel(const float* __restrict__ x, long long n, int* __restrict__ flag) {
     bool bad = false;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) bad |= (x[e] != x[e]);
@@ -468,6 +488,14 @@ extern "C" int dsrl_sgd_step(float* p, const float* g, float* buf, int64_t n, fl
     if (int e = bind_stream_device(st)) return e;
     hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 1024), 4096)), dim3(256), 0, st, p, g, buf, (long long)n, lr, momentum, weight_decay, grad_scale);
     return launch_status("sgd_kernel");
+}
+extern "C" int dsrl_sgd_step_dev(float* p, const float* g, float* buf, int64_t n, const float* hyper, dsrl_stream_t stream) {
+    DSRL_REQUIRE(p && g && buf && hyper && n > 0, DSRL_E_BADARG, "sgd_step_dev: bad arguments");
+    DSRL_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)buf % 16) == 0, DSRL_E_BADARG, "sgd_step_dev: arenas must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(sgd_dev_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 1024), 4096)), dim3(256), 0, st, p, g, buf, (long long)n, hyper);
+    return launch_status("sgd_dev_kernel");
 }
 extern "C" int dsrl_nan_check(const float* x, int64_t n, int* flag, dsrl_stream_t stream) {
     DSRL_REQUIRE(x && flag && n > 0, DSRL_E_BADARG, "nan_check: bad arguments");

@@ -85,6 +85,7 @@ class FlatParams:
         self._pending = [c[2] for c in self.chunks]
         self._works = []
         self._hooks = []
+        self.defer_collectives = False      # set while a step is captured into a hipGraph: reduce_all() runs the collectives after the replay
         # gradient sink: kernels may write a parameter's gradient straight into its arena slot (functional._sink)
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._claimed = set()
@@ -125,7 +126,7 @@ class FlatParams:
     def _on_grad_ready(self, i):
         ci = self._chunk_of[i]
         self._pending[ci] -= 1
-        if self._pending[ci] == 0:
+        if self._pending[ci] == 0 and not self.defer_collectives:
             a, b, _ = self.chunks[ci]
             if self.device.type == 'cuda' and HF.overlap_wgrad:
                 # The chunk holds gradients written on the compute stream AND weight gradients written on the side stream.  Launch the
@@ -200,15 +201,30 @@ class FlatParams:
             w.wait()
         self._works = []
 
+    def reduce_all(self):
+        """All chunk all-reduces of the gradient arena at once, behind whatever the current stream holds (the replay of a captured
+        forward + backward); the caller's stream waits for them.  Used when backward ran from a hipGraph, where no hook fires."""
+        if self.world == 1:
+            return
+        works = [dist.all_reduce(self.g_flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for a, b, _ in self.chunks]
+        for w in works:
+            w.wait()
+
     def sync_buffers(self):
         if self.world > 1 and self.broadcast_buffers_enabled:
             dist.broadcast(self.b_flat, 0, group=self.pg)
 
     # ------------------------------------------------------------------ optimiser
-    def sgd_step(self, lr, momentum, weight_decay):
-        """torch.optim.SGD(momentum, weight_decay).step() on the whole arena; gradients are averaged over ranks here."""
-        self.finish_reduction()
-        HF.sgd_step_(self.p_flat, self.g_flat, self.m_flat, lr, momentum, weight_decay, 1.0 / self.world)
+    def sgd_step(self, lr, momentum, weight_decay, hyper=None, reduce=True):
+        """torch.optim.SGD(momentum, weight_decay).step() on the whole arena; gradients are averaged over ranks here.  `hyper`: a
+        4-float device tensor (lr, momentum, weight_decay, 1/world) the kernel reads when it runs (graph-replayable) instead of the
+        three host values."""
+        if reduce:
+            self.finish_reduction()
+        if hyper is not None:
+            HF.sgd_step_dev_(self.p_flat, self.g_flat, self.m_flat, hyper)
+        else:
+            HF.sgd_step_(self.p_flat, self.g_flat, self.m_flat, lr, momentum, weight_decay, 1.0 / self.world)
         self.wt_valid = False               # the filters changed: the transposed copies are stale until the next refresh
 
     def state_dict(self):

@@ -43,7 +43,7 @@ CONV_PRECISION_MODES = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'mixed': 3}
 
 def set_conv_precision(mode):
     """Arithmetic of the conv kernels (include/dsrl_hip.h: dsrl_conv_precision): 'fp32' (exact fp32 MFMA products), 'bf16x3',
-    'bf16x6' (fp32-equivalent) or 'mixed' (forward bf16x6, backward bf16x3; the default); None follows DSRL_CONV_PRECISION.
+    'bf16x6' (fp32-equivalent; the default) or 'mixed' (forward bf16x6, backward bf16x3); None follows DSRL_CONV_PRECISION.
     Returns the previous setting as the library reported it (an int, -1 = environment)."""
     code = -1 if mode is None else (CONV_PRECISION_MODES[mode] if isinstance(mode, str) else int(mode))
     if not -1 <= code <= 3:
@@ -55,7 +55,7 @@ def get_conv_precision():
     """Name of the mode the conv kernels currently run in."""
     lib = _lib.load()
     prev = int(lib.dsrl_conv_precision(-2))          # out-of-range argument: query only
-    code = prev if prev >= 0 else int(os.environ.get('DSRL_CONV_PRECISION', '3'))
+    code = prev if prev >= 0 else int(os.environ.get('DSRL_CONV_PRECISION', '2'))
     code = min(max(code, 0), 3)
     return [k for k, v in CONV_PRECISION_MODES.items() if v == code][0]
 
@@ -951,6 +951,37 @@ def sgd_step_(p, g, buf, lr, momentum, weight_decay, grad_scale=1.0):
     _need_gpu(p, g, buf)
     call('dsrl_sgd_step', p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), float(lr), float(momentum), float(weight_decay),
          float(grad_scale), _stream())
+
+
+def sgd_step_dev_(p, g, buf, hyper):
+    """The same update with (lr, momentum, weight_decay, grad_scale) read from the 4-float device tensor `hyper` at run time."""
+    _need_gpu(p, g, buf, hyper)
+    call('dsrl_sgd_step_dev', p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), hyper.data_ptr(), _stream())
+
+
+class DeviceRng:
+    """Device-resident twin of the host dropout key (begin_forward): three 64-bit words {key, step, base}.  While bound, every
+    dropout-bearing kernel of the device reads `key` when it runs and advance() enqueues the per-step derivation, so that a step
+    captured in a hipGraph draws fresh masks on every replay (include/dsrl_hip.h: dsrl_rng_bind_device_key)."""
+
+    def __init__(self, device):
+        self.state = torch.zeros(3, dtype=torch.int64, device=device)
+        self.sync_from_host()
+        with torch.cuda.device(device):
+            call('dsrl_rng_bind_device_key', self.state.data_ptr())
+
+    def sync_from_host(self):
+        def s64(v):
+            v &= 0xFFFFFFFFFFFFFFFF
+            return v - (1 << 64) if v >= (1 << 63) else v
+        self.state.copy_(torch.tensor([s64(_derive(_rng_state['step'])), s64(_rng_state['step']), s64(_rng_state['seed'])], dtype=torch.int64))
+
+    def advance(self):
+        call('dsrl_rng_advance_key', self.state.data_ptr(), _stream())
+
+    def release(self):
+        with torch.cuda.device(self.state.device):
+            call('dsrl_rng_bind_device_key', None)
 
 
 def nan_check_(flag, *tensors):

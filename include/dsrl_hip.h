@@ -14,8 +14,10 @@
  *     plain torch layout (Cin,Cout,2,2).
  *   - Every function enqueues on `stream` (a hipStream_t) and returns immediately; no allocation, no host
  *     synchronisation (the two read-out functions dsrl_prof_read and dsrl_bn_fused_barrier_timeouts excepted); re-entrant from
- *     the autograd worker thread. Process-wide state is limited to three settings (dsrl_conv_precision, dsrl_bn_fused_max_blocks,
- *     dsrl_prof_enable) and the arrival counter of the fused BatchNorm kernels' device-wide barrier.
+ *     the autograd worker thread. Process-wide state is limited to four settings (dsrl_conv_precision, dsrl_bn_fused_max_blocks,
+ *     dsrl_prof_enable, dsrl_rng_bind_device_key) and the self-resetting arrival counter of the fused BatchNorm kernels'
+ *     device-wide barrier. The fused BatchNorm launches of one device share that counter, so they must not overlap each other: the
+ *     first one pins its stream, launches on any other stream (outside graph capture) take the three-kernel path.
  *   - The caller owns all buffers including `ws` (workspace, >= the matching *_workspace_bytes()).
  *   - Return 0 on success, a negative DSRL_E_* otherwise; dsrl_last_error() has the message (thread-local).
  */
@@ -46,7 +48,7 @@ int dsrl_device_check(int* cu_count);
 
 /* ------------------------------------------------------------------------------------------------
  * conv2d: implicit GEMM on the matrix cores; fp32 in / out / accumulate, products formed as dsrl_conv_precision selects
- * (default: split-precision bf16 MFMAs, bf16x6 forward = fp32-equivalent, bf16x3 backward; mode 0: v_mfma_f32_32x32x2_f32).
+ * (default: "bf16x6" split-precision bf16 MFMAs = fp32-equivalent in every pass; mode 0: v_mfma_f32_32x32x2_f32).
  * replaces nn.Conv2d forward/backward at ASPP.py:10-15,19; DSRL.py:19-23,34-38,42-46,50,78-83 and the
  * ResNet101.py convolutions; x (N,H,W,C) -> y (N,Ho,Wo,K).
  * ---------------------------------------------------------------------------------------------- */
@@ -98,9 +100,9 @@ int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
  * accumulation in every mode; the modes differ in how the products are formed on the matrix cores:
  *   0  v_mfma_f32_32x32x2_f32 (exact fp32 products)
  *   1  "bf16x3": operand = 2 bf16 terms (16 mantissa bits), 3 bf16 MFMAs per product; ~5e-6 relative error per conv
- *   2  "bf16x6": operand = 3 bf16 terms (24 mantissa bits), 6 bf16 MFMAs per product; error vs fp64 equal to mode 0
- *   3  forward bf16x6, dgrad / wgrad bf16x3 (default)
- *  -1  follow the environment variable DSRL_CONV_PRECISION (unset = 3)
+ *   2  "bf16x6": operand = 3 bf16 terms (24 mantissa bits), 6 bf16 MFMAs per product; error vs fp64 equal to mode 0 (default)
+ *   3  "mixed": forward bf16x6, dgrad / wgrad bf16x3 (reduced-precision gradients, ~5e-6)
+ *  -1  follow the environment variable DSRL_CONV_PRECISION (unset = 2)
  * Any other value changes nothing (query). Returns the previous setting. */
 int dsrl_conv_precision(int mode);
 /* in-bounds multiply-accumulates of one forward conv (zero-padding taps excluded): the roofline numerator */
@@ -180,6 +182,14 @@ int dsrl_bn_bwd_from_stats(const float* x, int ldx, const float* y /*nullable*/,
                            float* dresidual /*nullable*/, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
                            float* dgamma /*nullable*/, float* dbeta /*nullable*/, int relu, int training, const float* stats, int stats_parts,
                            dsrl_stream_t stream);
+
+/* Device-resident dropout key. By default every dropout-bearing launch (dsrl_bn_apply, dsrl_bn_train_fwd*, dsrl_dropout_*) bakes its
+ * `seed` argument into the launch. After dsrl_rng_bind_device_key(ptr) the kernels of the CURRENT device ignore that argument and read
+ * the 64-bit key at `ptr` when they run, so launches captured in a hipGraph draw fresh masks on every replay; NULL restores the
+ * default. dsrl_rng_advance_key(state) enqueues the per-step key derivation on three device words {key, step, base}:
+ * step += 1; key = base * 1000003 + step (mod 2^64) - the derivation functional.begin_forward() performs on the host. */
+int dsrl_rng_bind_device_key(const uint64_t* dev_key /*nullable*/);
+int dsrl_rng_advance_key(uint64_t* state /*device: key, step, base*/, dsrl_stream_t stream);
 
 /* standalone Dropout (DSRL.py:54): Philox4x32-10 keyed by (seed, rng_stream), element index = p*C + c */
 int dsrl_dropout_fwd(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float p, uint64_t seed, uint32_t rng_stream, dsrl_stream_t stream);
@@ -274,6 +284,9 @@ int dsrl_prepare_batch(const uint8_t* rgb, const uint8_t* labels, const uint8_t*
 /* torch.optim.SGD(momentum, weight_decay): d = g*grad_scale + wd*p; buf = mom*buf + d; p -= lr*buf */
 int dsrl_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float weight_decay,
                   float grad_scale, dsrl_stream_t stream);
+/* the same update with {lr, momentum, weight_decay, grad_scale} read from four floats in device memory when the kernel runs: a launch
+ * captured in a hipGraph follows the per-epoch LR schedule (train_or_resume.py:109-113, 349) without being re-captured */
+int dsrl_sgd_step_dev(float* p, const float* g, float* buf, int64_t n, const float* hyper /*device, 4 floats*/, dsrl_stream_t stream);
 /* flag[0] |= 1 if any element is NaN (the reference's per-output NaN asserts folded into one readback) */
 int dsrl_nan_check(const float* x, int64_t n, int* flag, dsrl_stream_t stream);
 

@@ -41,3 +41,13 @@ def golden():
             cache[name] = np.load(os.path.join(GOLDEN, name + '.npz'))
         return cache[name]
     return load
+
+
+@pytest.fixture(autouse=True)
+def _unbind_device_rng():
+    """A graph-mode TrainStep binds the device-resident dropout key (dsrl_rng_bind_device_key); parity tests pass explicit seeds, so
+    every test starts and ends with the key unbound."""
+    yield
+    if _has_gpu():
+        from dualsuperreslearningforsemseg_amd import _lib
+        _lib.call('dsrl_rng_bind_device_key', None)

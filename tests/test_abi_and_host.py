@@ -132,7 +132,7 @@ def test_conv_precision_api_roundtrip():
     from dualsuperreslearningforsemseg_amd import functional as HF
     HF.set_conv_precision(None)
     default = HF.get_conv_precision()
-    assert default == {'0': 'fp32', '1': 'bf16x3', '2': 'bf16x6', '3': 'mixed'}[os.environ.get('DSRL_CONV_PRECISION', '3')]
+    assert default == {'0': 'fp32', '1': 'bf16x3', '2': 'bf16x6', '3': 'mixed'}[os.environ.get('DSRL_CONV_PRECISION', '2')]
     for mode in ('fp32', 'bf16x3', 'bf16x6', 'mixed'):
         HF.set_conv_precision(mode)
         assert HF.get_conv_precision() == mode

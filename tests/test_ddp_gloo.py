@@ -45,6 +45,15 @@ def _worker(rank, world, port, q):
             o = flat.offsets[[id(q_) for q_ in flat.params].index(id(p))]
             got = mean_grad.as_strided(p.shape, p.stride(), o)
             assert torch.allclose(got, r.grad, rtol=1e-4, atol=1e-6), n
+        # deferred form (a step replayed from a hipGraph): no collective from the hooks, reduce_all() afterwards gives the same sum
+        hooked = flat.g_flat.clone()
+        flat.defer_collectives = True
+        flat.zero_grad()
+        model(xs[rank]).square().mean().backward()
+        assert len(flat._works) == 0, 'a hook launched a collective although they are deferred'
+        flat.reduce_all()
+        flat.defer_collectives = False
+        assert torch.allclose(flat.g_flat, hooked, rtol=1e-6, atol=1e-7)
         # buffers travel from rank 0
         model[1].running_mean.fill_(float(rank + 1))
         flat.sync_buffers()

@@ -253,3 +253,27 @@ def test_prepare_batch_vs_reference(golden):
     img_in, img_org, target = O.prepare_batch(g['prep.rgb'], g['prep.labels'], cs.LABEL_MAPPING_DICT, cs.MEAN, cs.STD, (16, 32))
     close(img_in, g['prep.img_in'], 1e-5); close(img_org, g['prep.img_org'], 1e-5)
     np.testing.assert_array_equal(target, g['prep.target'])
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_torch_cpu_baseline_graph_vs_reference(golden, mode):
+    """bench.py's stock-torch CPU baseline (oracle/torch_cpu_model.py) computes what the reference's head computes: full-width
+    head on the reference-generated vectors (Dropout modules in eval, as in make_golden.py)."""
+    import torch
+    from oracle.torch_cpu_model import TorchCpuDSRL, total_loss
+    g = golden('head_fullwidth')
+    model = TorchCpuDSRL(3)
+    sd = {k: torch.from_numpy(v) for k, v in gen.make_head_params(303, gen.FULL, 3).items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith('feature_extractor.backbone.') or 'num_batches' in k for k in missing)
+    model.train(mode == 'train')
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    x16, x4, target, org = gen.make_head_inputs(404, 2, 4, 8, gen.FULL)
+    outs = model.forward_head(torch.from_numpy(x16), torch.from_numpy(x4))
+    L = total_loss(outs, torch.from_numpy(target), torch.from_numpy(org), 3)
+    close(gen.strided_sample(outs[0].detach().numpy(), 65536), g[f'{mode}.SSSR_sample'], 1e-4)
+    assert (outs[0].detach().numpy().argmax(axis=1) == g[f'{mode}.SSSR_argmax']).mean() > 0.9999
+    close(outs[2].detach().numpy(), g[f'{mode}.SSSR_ft'], 1e-4)
+    close(np.array([float(v) for v in L]), g[f'{mode}.losses'], 1e-4)
