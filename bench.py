@@ -76,7 +76,18 @@ def spawn_ranks(args):
 
 # ----------------------------------------------------------------------------------------------------------------- CPU baselines
 def host_cores():
-    return len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    """Cores this process may really use: the affinity mask, cut down to the cgroup CPU quota when there is one (a GPU box exposes all
+    of the host's logical CPUs in the mask but grants a share of them: threads beyond the share only fight each other)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    if n > 32 and not os.environ.get('DSRL_CPU_BASELINE_THREADS'):
+        n = 16          # no quota visible on a many-core host: the documented CPU share of a one-GPU box
+    return int(os.environ.get('DSRL_CPU_BASELINE_THREADS', n))
 
 
 def cpu_baseline_torch(state_dict, stage, batch=2, height=256, width=512):

@@ -22,6 +22,12 @@ stream_t = C.c_void_p
 
 _conv_shape = [i32] * 10                      # N,H,W,C,K,R,S,stride,pad,dil
 
+
+class WgradProblem(C.Structure):              # include/dsrl_hip.h: dsrl_wgrad_problem
+    _fields_ = [('x', C.c_void_p), ('dy', C.c_void_p), ('dw', C.c_void_p)] + [(n, C.c_int32) for n in
+                ('ldx', 'lddy', 'N', 'H', 'W', 'C', 'K', 'R', 'S', 'stride', 'pad', 'dil')]
+
+
 PROTOTYPES = {
     'dsrl_version': (i32, []),
     'dsrl_last_error': (C.c_char_p, []),
@@ -40,6 +46,10 @@ PROTOTYPES = {
     'dsrl_conv2d_dgrad_accumulate': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv2d_wgrad_workspace_bytes': (sz, _conv_shape),
     'dsrl_conv2d_wgrad': (i32, [fp, i32, fp, i32, fp] + _conv_shape + [fp, sz, stream_t]),
+    'dsrl_conv2d_wgrad_group_table_bytes': (sz, [i32]),
+    'dsrl_conv2d_wgrad_group_workspace_bytes': (sz, [fp, i32]),
+    'dsrl_conv2d_wgrad_group_plan': (i32, [fp, i32, fp, sz, fp, fp, sz]),
+    'dsrl_conv2d_wgrad_group_launch': (i32, [fp, fp, stream_t]),
     'dsrl_conv_precision': (i32, [i32]),
     'dsrl_conv2d_inbounds_macs': (i64, _conv_shape),
     'dsrl_conv2d_rowfold_fwd_workspace_bytes': (sz, [i32] * 9),

@@ -61,7 +61,7 @@ class SyntheticCityscapes:
 
 
 class _CapturedStep:
-    __slots__ = ('graph', 'img', 'org', 'tgt', 'outs', 'vals', 'bns')
+    __slots__ = ('graph', 'img', 'org', 'tgt', 'outs', 'vals', 'bns', 'keep')
 
 
 class TrainStep:
@@ -120,8 +120,10 @@ class TrainStep:
             if do_train:
                 total.backward()                                                           # :444 (eager: chunked RCCL all-reduce overlaps)
                 if in_graph and flat.world > 1:
+                    HF.flush_wgrad_queue()
                     HF.join_side_streams()        # the collectives and the update follow the replay (_replay)
                 elif flat.defer_collectives and flat.world > 1:
+                    HF.flush_wgrad_queue()
                     HF.join_side_streams()        # graph mode, iterations before the capture: the same order of events, eagerly
                     flat.reduce_all()
                     flat.sgd_step(hp[0], hp[1], hp[2], hyper=self.hyper if dev_mode else None, reduce=False)
@@ -153,11 +155,13 @@ class TrainStep:
         overlap_was = HF.overlap_wgrad
         if os.environ.get('DSRL_GRAPH_OVERLAP', '0') == '0':
             HF.overlap_wgrad = False
+        c.keep = HF.graph_keepalive = []          # pinned host tables the captured copies read on every replay
         try:
             with t.cuda.graph(c.graph, capture_error_mode=os.environ.get('DSRL_GRAPH_CAPTURE_MODE', 'thread_local')):
                 c.outs, c.vals = self._body(c.img, c.org, c.tgt, hp, True, in_graph=True)
         finally:
             HF.overlap_wgrad = overlap_was
+            HF.graph_keepalive = None
         # nothing ran during the capture: take back the host-side bookkeeping of that phantom iteration
         HF._rng_state['step'] = step_before
         c.bns = [m for m, n in zip(bns, before) if getattr(m, '_dsrl_batches', 0) != n]

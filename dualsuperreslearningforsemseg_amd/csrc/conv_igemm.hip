@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <stdlib.h>
+#include <string.h>
 #include <mutex>
 #include <vector>
 
@@ -727,6 +728,11 @@ struct WgradArgs {
     int kctiles;                // ktiles * ctiles
     unsigned mHW, sHW, mW, sW;  // magic multipliers / shifts: p / (Ho*Wo) and rem / Wo for p < 2^31 (fast_div)
     int kg;                     // split kernel: pixel groups per block (1, 2 or 4)
+    // grouped launches (dsrl_conv2d_wgrad_group_*): blocks of this problem (the rest up to the next start are padding), where the
+    // slab reduce writes, and that reduce's block count
+    int nblocks;
+    float* dw_final;
+    int rblocks;
 };
 
 template <int MR, int NR, int WGM, int WGN>
@@ -867,8 +873,8 @@ __device__ __forceinline__ int fast_div(int n, unsigned m, unsigned s) { return 
 // The pixel -> (n, ho, wo) decomposition of every staged x row uses magic-number division (two mul-hi instead of two divides).
 // KG > 1 (pixel groups): KG groups of 4 waves per block, group g takes the 32-pixel chunks g, g+KG, ... of the block's pixel range with
 // its own two LDS stages; the KG accumulator sets are summed through LDS in a fixed order - KG times fewer slabs to write and reduce.
-template <int MR, int NR, int WGM, int WGN, int NPL, int KG = 1>
-__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_wgrad_split_kernel(const WgradArgs a) {
+template <int MR, int NR, int WGM, int WGN, int NPL, int KG>
+__device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int bid) {
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
     constexpr int A_V = BM / 4, B_V = BN / 4;                 // float4 per pixel row
     constexpr int A_RP = 256 / A_V, B_RP = 256 / B_V;          // pixel rows per staging pass
@@ -887,7 +893,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_wgrad_split_ke
     const int wm = wave / WGN, wn = wave % WGN;
     const int per_z = a.ntaps * a.kctiles;
     const int nb = per_z * a.psplits;
-    const int id = a.xcd_remap ? xcd_contiguous(blockIdx.x, nb) : blockIdx.x;
+    const int id = a.xcd_remap ? xcd_contiguous(bid, nb) : bid;
     const int zsplit = id / per_z, rem_id = id - zsplit * per_z;
     const int tapi = rem_id / a.kctiles, kc = rem_id - tapi * a.kctiles;
     const int kt = kc / a.ctiles, ct = kc - kt * a.ctiles;
@@ -1131,6 +1137,29 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_wgrad_split_ke
     }
 }
 
+template <int MR, int NR, int WGM, int WGN, int NPL, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_wgrad_split_kernel(const WgradArgs a) {
+    wgrad_split_body<MR, NR, WGM, WGN, NPL, KG>(a, (int)blockIdx.x);
+}
+
+// Grouped launch: ONE grid covers the weight gradients of many convolutions that share a tile configuration.  `table` holds one
+// WgradArgs per problem, `starts` the first block of each (ascending, multiples of 8 so that a problem's local block ids keep their
+// XCD round-robin phase); a block finds its problem by bisection (wave-uniform scalar loads) and runs the ordinary kernel body on it.
+template <int MR, int NR, int WGM, int WGN, int NPL>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_group_kernel(const WgradArgs* __restrict__ table, const int* __restrict__ starts, int nprob) {
+    const int b = (int)blockIdx.x;
+    int lo = 0, hi = nprob - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (starts[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const WgradArgs& a = table[lo];
+    const int local = b - starts[lo];
+    if (local >= a.nblocks) return;             // padding block
+    wgrad_split_body<MR, NR, WGM, WGN, NPL, 1>(a, local);
+}
+
 struct TapList { int taps[64]; int n; };
 // dw[k][tap][c] = sum_z slab[z][k][tap][c] over the active taps; C % 4 == 0, one float4 per thread, slabs unrolled by 4
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int psplits, long long slab, float* __restrict__ dw,
@@ -1152,6 +1181,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         for (; zz < psplits; ++zz) {
             const float4 a = *reinterpret_cast<const float4*>(slabs + zz * slab + idx);
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        *reinterpret_cast<float4*>(dw + idx) = s;
+    }
+}
+
+// the same reduce for a table of problems: block b of problem j sums 1024 float4 positions (4 per thread) of its slabs
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(const WgradArgs* __restrict__ table, const int* __restrict__ starts, int nprob) {
+    const int b = (int)blockIdx.x;
+    int lo = 0, hi = nprob - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (starts[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const WgradArgs& a = table[lo];
+    const int local = b - starts[lo];
+    if (local >= a.rblocks) return;
+    const int C4 = a.C >> 2, RS = a.R * a.S;
+    const long long total = (long long)a.K * a.ntaps * C4;
+    const float* __restrict__ slabs = a.dw;
+    float* __restrict__ dw = a.dw_final;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long long e = (long long)local * 1024 + u * 256 + threadIdx.x;
+        if (e >= total) break;
+        const int c4 = (int)(e % C4);
+        const long long t = e / C4;
+        const int ti = (int)(t % a.ntaps), k = (int)(t / a.ntaps);
+        const long long idx = ((long long)k * RS + a.taps[ti]) * a.C + 4 * c4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int zz = 0;
+        for (; zz + 4 <= a.psplits; zz += 4) {
+            const float4 p = *reinterpret_cast<const float4*>(slabs + (zz + 0) * a.slab + idx), q = *reinterpret_cast<const float4*>(slabs + (zz + 1) * a.slab + idx);
+            const float4 r = *reinterpret_cast<const float4*>(slabs + (zz + 2) * a.slab + idx), d = *reinterpret_cast<const float4*>(slabs + (zz + 3) * a.slab + idx);
+            s.x += (p.x + q.x) + (r.x + d.x); s.y += (p.y + q.y) + (r.y + d.y); s.z += (p.z + q.z) + (r.z + d.z); s.w += (p.w + q.w) + (r.w + d.w);
+        }
+        for (; zz < a.psplits; ++zz) {
+            const float4 p = *reinterpret_cast<const float4*>(slabs + zz * a.slab + idx);
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
         }
         *reinterpret_cast<float4*>(dw + idx) = s;
     }
@@ -1718,6 +1786,171 @@ extern "C" int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int l
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st,
                            (const float*)ws, psplits, a.slab, dw, K, RS, C, p.tl);
         return launch_status("wgrad_reduce_kernel");
+    }
+    return DSRL_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ grouped wgrad
+// The weight gradients of a backward pass are independent of everything else in it (only the optimiser reads them), and most
+// layers are too small to fill 256 CUs on their own.  dsrl_conv2d_wgrad_group_* therefore runs ALL of them as a few grids: one
+// per tile configuration, blocks ordered longest first, a problem's pixel range split only where a block would otherwise exceed
+// ~4096 pixels (small-weight / many-pixel layers: their slabs are tiny).  Compared with one launch per layer: no launch ramp / tail
+// per layer, no pixel splits (slab write + reduce launch) just to fill the chip, one slab reduce for the whole pass.
+namespace dsrl {
+constexpr unsigned kGroupMagic = 0x44535247u;       // "DSRG"
+constexpr int kGroupMaxProblems = 512, kGroupMaxLaunches = kNumCfg;
+struct GroupLaunch { int cfg, first, count, grid; double flops, bytes; };
+struct GroupHeader {
+    unsigned magic; int n, nlaunch, npl;
+    GroupLaunch launch[kGroupMaxLaunches];
+    int rgrid;                      // blocks of the slab reduce (0: no problem is split)
+    long long args_off, starts_off, rstarts_off, used_bytes;      // byte offsets inside the table
+};
+static size_t group_table_bytes(int n) {
+    return align_up(sizeof(GroupHeader), 256) + align_up((size_t)n * sizeof(WgradArgs), 256) + 2 * align_up((size_t)(n + 1) * sizeof(int), 256);
+}
+static int group_target_px() { return std::max(256, env_int("DSRL_WGRAD_GROUP_PX", 4096)); }
+struct GroupItem { WgradArgs a; TileCfg cfg; int bm, bn; double cost, flops, bytes; size_t slab_bytes; };
+static int group_item(const dsrl_wgrad_problem& q, int npl, GroupItem& it) {
+    const int N = q.N, H = q.H, W = q.W, C = q.C, K = q.K, R = q.R, S = q.S, stride = q.stride, pad = q.pad, dil = q.dil;
+    if (int e = check_conv(q.x, q.dy, q.dw, N, H, W, C, K, R, S, stride, pad, dil)) return e;
+    DSRL_REQUIRE(C % 4 == 0 && q.ldx % 4 == 0 && q.lddy % 4 == 0 && q.lddy >= pad4(K) && ((uintptr_t)q.x % 16) == 0 && ((uintptr_t)q.dy % 16) == 0 && ((uintptr_t)q.dw % 16) == 0,
+                 DSRL_E_UNSUPPORTED, "conv2d_wgrad_group: C (%d), ldx (%d), lddy (%d) must be multiples of 4 (lddy >= K rounded up to 4), pointers 16-byte aligned", C, q.ldx, q.lddy);
+    const WgPlan p = plan_wgrad(N, H, W, C, K, R, S, stride, pad, dil);
+    DSRL_REQUIRE(p.P < (1ll << 31), DSRL_E_UNSUPPORTED, "conv2d_wgrad_group: more than 2^31 output pixels");
+    WgradArgs a{};
+    a.x = q.x; a.dy = q.dy; a.ldx = q.ldx; a.lddy = q.lddy; a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = p.Ho; a.Wo = p.Wo;
+    a.stride = stride; a.pad = pad; a.dil = dil; a.P = p.P; a.ctiles = p.ctiles; a.slab = (long long)K * R * S * C;
+    const long long xb = span_bytes((long long)N * H * W, q.ldx, C), db = span_bytes(p.P, q.lddy, pad4(K));
+    DSRL_REQUIRE_31(xb, "conv2d_wgrad_group(x)"); DSRL_REQUIRE_31(db, "conv2d_wgrad_group(dy)");
+    a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db;
+    a.ntaps = p.tl.n;
+    for (int i = 0; i < p.tl.n; ++i) a.taps[i] = p.tl.taps[i];
+    const long long chunks = ceil_div(p.P, 32);
+    const int forced = env_int("DSRL_FORCE_PSPLITS", 0);
+    long long sp = forced > 0 ? forced : (p.P + group_target_px() / 2) / group_target_px();
+    sp = std::max<long long>(1, std::min<long long>(sp, std::max<long long>(1, chunks / 4)));
+    a.psplits = (int)std::min<long long>(sp, 256);
+    a.kg = 1; a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
+    a.nblocks = a.kctiles * a.ntaps * a.psplits;
+    a.dw_final = q.dw; a.dw = q.dw;
+    a.rblocks = a.psplits > 1 ? (int)ceil_div((long long)K * a.ntaps * (C / 4), 1024) : 0;
+    make_magic(a.Ho * a.Wo, a.mHW, a.sHW);
+    make_magic(a.Wo, a.mW, a.sW);
+    it.a = a; it.cfg = p.cfg; it.bm = p.bm; it.bn = p.bn;
+    it.cost = (double)p.P / a.psplits * p.bm * p.bn;
+    it.flops = 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil);
+    it.bytes = 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)p.P * K);
+    it.slab_bytes = a.psplits > 1 ? align_up((size_t)a.psplits * a.slab * sizeof(float), 256) : 0;
+    (void)npl;
+    return DSRL_OK;
+}
+}  // namespace dsrl
+
+extern "C" size_t dsrl_conv2d_wgrad_group_table_bytes(int n) { return n > 0 ? group_table_bytes(n) : 0; }
+
+extern "C" size_t dsrl_conv2d_wgrad_group_workspace_bytes(const dsrl_wgrad_problem* problems, int n) {
+    if (!problems || n <= 0) return 0;
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        const dsrl_wgrad_problem& q = problems[i];
+        if (q.N <= 0 || q.H <= 0 || q.W <= 0 || q.C <= 0 || q.K <= 0 || q.R <= 0 || q.S <= 0 || q.stride <= 0 || q.dil <= 0 || q.pad < 0) continue;
+        if (out_size(q.H, q.R, q.stride, q.pad, q.dil) <= 0 || out_size(q.W, q.S, q.stride, q.pad, q.dil) <= 0) continue;
+        const long long P = (long long)q.N * out_size(q.H, q.R, q.stride, q.pad, q.dil) * out_size(q.W, q.S, q.stride, q.pad, q.dil);
+        const long long chunks = ceil_div(P, 32);
+        const int forced = env_int("DSRL_FORCE_PSPLITS", 0);
+        long long sp = forced > 0 ? forced : (P + group_target_px() / 2) / group_target_px();
+        sp = std::min<long long>(std::max<long long>(1, std::min<long long>(sp, std::max<long long>(1, chunks / 4))), 256);
+        if (sp > 1) total += align_up((size_t)sp * q.K * q.R * q.S * q.C * sizeof(float), 256);
+    }
+    return total;
+}
+
+extern "C" int dsrl_conv2d_wgrad_group_plan(const dsrl_wgrad_problem* problems, int n, void* host_table, size_t table_bytes, const void* dev_table,
+                                            void* ws, size_t ws_bytes) {
+    DSRL_REQUIRE(problems && host_table && dev_table && n > 0 && n <= kGroupMaxProblems, DSRL_E_BADARG, "conv2d_wgrad_group_plan: bad arguments (n=%d, at most %d problems)", n, kGroupMaxProblems);
+    DSRL_REQUIRE(table_bytes >= group_table_bytes(n), DSRL_E_WORKSPACE, "conv2d_wgrad_group_plan: table %zu < %zu bytes", table_bytes, group_table_bytes(n));
+    DSRL_REQUIRE(((uintptr_t)dev_table % 16) == 0 && ((uintptr_t)host_table % 16) == 0, DSRL_E_BADARG, "conv2d_wgrad_group_plan: tables must be 16-byte aligned");
+    const int npl = conv_planes(PASS_WGRAD);
+    DSRL_REQUIRE(npl == 2 || npl == 3, DSRL_E_UNSUPPORTED, "conv2d_wgrad_group_plan: the grouped launch exists for the split-precision arithmetics only (dsrl_conv_precision 1..3)");
+    std::vector<GroupItem> items((size_t)n);
+    size_t need_ws = 0;
+    for (int i = 0; i < n; ++i) {
+        if (int e = group_item(problems[i], npl, items[(size_t)i])) return e;
+        need_ws += items[(size_t)i].slab_bytes;
+    }
+    DSRL_REQUIRE(ws_bytes >= need_ws && (need_ws == 0 || ws), DSRL_E_WORKSPACE, "conv2d_wgrad_group_plan: workspace %zu < %zu", ws_bytes, need_ws);
+    DSRL_REQUIRE(need_ws == 0 || ((uintptr_t)ws % 16) == 0, DSRL_E_BADARG, "conv2d_wgrad_group_plan: workspace must be 16-byte aligned");
+    // order: by tile configuration, inside one longest blocks first (the hardware deals blocks in id order: the short ones fill the tail)
+    std::stable_sort(items.begin(), items.end(), [](const GroupItem& l, const GroupItem& r) { return l.cfg != r.cfg ? l.cfg < r.cfg : l.cost > r.cost; });
+    char* base = (char*)host_table;
+    memset(base, 0, group_table_bytes(n));
+    GroupHeader* h = (GroupHeader*)base;
+    h->magic = kGroupMagic; h->n = n; h->npl = npl; h->nlaunch = 0;
+    h->args_off = (long long)align_up(sizeof(GroupHeader), 256);
+    h->starts_off = h->args_off + (long long)align_up((size_t)n * sizeof(WgradArgs), 256);
+    h->rstarts_off = h->starts_off + (long long)align_up((size_t)(n + 1) * sizeof(int), 256);
+    h->used_bytes = (long long)group_table_bytes(n);
+    WgradArgs* args = (WgradArgs*)(base + h->args_off);
+    int* starts = (int*)(base + h->starts_off);
+    int* rstarts = (int*)(base + h->rstarts_off);
+    size_t ws_off = 0;
+    int rtotal = 0;
+    for (int i = 0; i < n; ++i) {
+        GroupItem& it = items[(size_t)i];
+        if (it.a.psplits > 1) { it.a.dw = (float*)((char*)ws + ws_off); ws_off += it.slab_bytes; }
+        args[i] = it.a;
+        rstarts[i] = rtotal;
+        rtotal += it.a.rblocks;
+        if (h->nlaunch == 0 || h->launch[h->nlaunch - 1].cfg != (int)it.cfg) {
+            GroupLaunch& L = h->launch[h->nlaunch++];
+            L.cfg = (int)it.cfg; L.first = i; L.count = 0; L.grid = 0; L.flops = 0; L.bytes = 0;
+        }
+        GroupLaunch& L = h->launch[h->nlaunch - 1];
+        starts[i] = L.grid;                                       // local to the launch; multiples of 8
+        L.grid += (int)align_up((size_t)it.a.nblocks, 8);
+        L.count += 1; L.flops += it.flops; L.bytes += it.bytes;
+    }
+    rstarts[n] = rtotal;
+    h->rgrid = rtotal;
+    return DSRL_OK;
+}
+
+extern "C" int dsrl_conv2d_wgrad_group_launch(const void* host_table, const void* dev_table, dsrl_stream_t stream) {
+    DSRL_REQUIRE(host_table && dev_table, DSRL_E_BADARG, "conv2d_wgrad_group_launch: null table");
+    const GroupHeader* h = (const GroupHeader*)host_table;
+    DSRL_REQUIRE(h->magic == kGroupMagic && h->n > 0 && h->nlaunch > 0 && h->nlaunch <= kGroupMaxLaunches, DSRL_E_BADARG, "conv2d_wgrad_group_launch: the host table was not written by dsrl_conv2d_wgrad_group_plan");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const WgradArgs* hargs = (const WgradArgs*)((const char*)host_table + h->args_off);
+    const WgradArgs* dargs = (const WgradArgs*)((const char*)dev_table + h->args_off);
+    const int* dstarts = (const int*)((const char*)dev_table + h->starts_off);
+    const int* drstarts = (const int*)((const char*)dev_table + h->rstarts_off);
+    for (int i = 0; i < h->n; ++i) {        // taps that only ever see zero padding have a zero gradient
+        const WgradArgs& a = hargs[i];
+        if (a.ntaps < a.R * a.S)
+            if (hipMemsetAsync(a.dw_final, 0, (size_t)a.K * a.R * a.S * a.C * sizeof(float), st) != hipSuccess) return launch_status("hipMemsetAsync(dw)");
+    }
+    const int npl = h->npl;
+    for (int l = 0; l < h->nlaunch; ++l) {
+        const GroupLaunch& L = h->launch[l];
+        if (L.grid <= 0) continue;
+        int bm, bn; cfg_dims((TileCfg)L.cfg, bm, bn);
+        const size_t lds = (size_t)2 * npl * 16 * ((bm * 2 + 64) + (bn * 2 + 64));
+        const WgradArgs* t = dargs + L.first;
+        const int* s = dstarts + L.first;
+        ProfScope prof(3 * (npl - 1) + 1, L.flops, L.bytes, st);
+#define DSRL_LAUNCH_WGROUP(a_, b_, c_, d_)                                                                                         \
+        if (npl == 2) hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 2>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count); \
+        else hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 3>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count);
+        DSRL_CFG_SWITCH((TileCfg)L.cfg, DSRL_LAUNCH_WGROUP)
+#undef DSRL_LAUNCH_WGROUP
+        if (int e = launch_status("conv_wgrad_group_kernel")) return e;
+    }
+    if (h->rgrid > 0) {
+        hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)h->rgrid), dim3(256), 0, st, dargs, drstarts, h->n);
+        return launch_status("wgrad_reduce_group_kernel");
     }
     return DSRL_OK;
 }

@@ -184,11 +184,14 @@ class FlatParams:
         self._claimed.clear()
         self._pending = [c[2] for c in self.chunks]
         self._works = []
+        if self.device.type == 'cuda':
+            HF.open_wgrad_queue()           # the convs of this step defer their weight gradients (functional.WgradQueue)
 
     def finish_reduction(self):
         """Waits (stream-wise) for the chunk all-reduces launched during backward; chunks whose hooks did not all fire
         (parameters unused in this step) are reduced here so that every rank issues the same collectives."""
         if self.device.type == 'cuda':
+            HF.flush_wgrad_queue()          # the deferred weight gradients of this backward pass, as grouped grids
             HF.join_side_streams()          # weight gradients written on the side stream (functional.overlap_wgrad)
         if self.world == 1:
             return

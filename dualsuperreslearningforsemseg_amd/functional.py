@@ -88,6 +88,65 @@ def join_side_streams():
             cur.wait_stream(st)
 
 
+# Deferred weight gradients: while a WgradQueue is open (ddp.FlatParams opens one per training step), a conv's backward only records
+# its weight-gradient problem (x, dy, arena slot); flush() launches all of them as a few grouped grids (dsrl_conv2d_wgrad_group_*).
+# Nothing but the optimiser reads a weight gradient, the small layers do not fill the chip on their own, and a pass-wide grid needs
+# neither the side stream nor per-layer pixel splits.  Off: DSRL_WGRAD_GROUP=0 (per-layer launches, overlapped on the side stream).
+group_wgrad = os.environ.get('DSRL_WGRAD_GROUP', '1') != '0'
+graph_keepalive = None          # a list while a hipGraph capture is in progress: host buffers the captured copies read on every replay
+
+
+class WgradQueue:
+    def __init__(self):
+        self.items = []           # (x, ldx, dy, lddy, dw tensor, shp, on_written)
+
+    def add(self, x, ldx, dy, lddy, dw, shp, on_written=None):
+        self.items.append((x, ldx, dy, lddy, dw, shp, on_written))
+
+    def flush(self):
+        items, self.items = self.items, []
+        if not items:
+            return
+        n = len(items)
+        probs = (_lib.WgradProblem * n)()
+        for q, (x, ldx, dy, lddy, dw, shp, _) in zip(probs, items):
+            N, H, W, Cc, K, R, S, stride, pad, dil = shp
+            q.x, q.dy, q.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+            q.ldx, q.lddy, q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.dil = ldx, lddy, N, H, W, Cc, K, R, S, stride, pad, dil
+        import ctypes
+        lib = _lib.load()
+        like = items[0][0]
+        tbytes = int(lib.dsrl_conv2d_wgrad_group_table_bytes(n))
+        ws = _ws(int(lib.dsrl_conv2d_wgrad_group_workspace_bytes(ctypes.addressof(probs), n)), like)
+        host = torch.empty(tbytes, dtype=torch.uint8, pin_memory=True)
+        dev = torch.empty(tbytes, dtype=torch.uint8, device=like.device)
+        call('dsrl_conv2d_wgrad_group_plan', ctypes.addressof(probs), n, host.data_ptr(), tbytes, dev.data_ptr(), ws.data_ptr(), ws.numel())
+        dev.copy_(host, non_blocking=True)
+        if graph_keepalive is not None:
+            graph_keepalive.append(host)          # a captured copy re-reads this pinned buffer on every replay
+        call('dsrl_conv2d_wgrad_group_launch', host.data_ptr(), dev.data_ptr(), _stream())
+        for it in items:
+            if it[6] is not None:
+                it[6]()
+
+
+wgrad_queue = None              # the open queue, if any
+
+
+def open_wgrad_queue():
+    global wgrad_queue
+    wgrad_queue = WgradQueue() if (group_wgrad and get_conv_precision() != 'fp32') else None
+    return wgrad_queue
+
+
+def flush_wgrad_queue():
+    """Launches what the open queue holds and closes it: only a step that opened a queue (FlatParams.zero_grad) defers."""
+    global wgrad_queue
+    q, wgrad_queue = wgrad_queue, None
+    if q is not None:
+        q.flush()
+
+
 def _need_gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -369,7 +428,11 @@ class _Conv2d(torch.autograd.Function):
         st = _stream()
         if ctx.needs_input_grad[1]:
             sink = _sink(ctx.wparam) if ctx.wparam is not None and _is_krsc(ctx.wparam) else None
-            if sink is not None and overlap_wgrad and ctx.needs_input_grad[0]:
+            if sink is not None and wgrad_queue is not None:
+                # deferred: all weight gradients of this backward pass run as a few grouped grids when the pass is over
+                wp = ctx.wparam
+                wgrad_queue.add(x, ldx, dy, lddy, sink, shp, lambda wp=wp: wp._dsrl_arena.written(wp))
+            elif sink is not None and overlap_wgrad and ctx.needs_input_grad[0]:
                 cur, side = torch.cuda.current_stream(), side_stream(x.device)
                 side.wait_stream(cur)                                   # dy (and x) are ready on the compute stream
                 with torch.cuda.stream(side):

@@ -96,6 +96,25 @@ size_t dsrl_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int 
 int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                       void* ws, size_t ws_bytes, dsrl_stream_t stream);
+/* Grouped weight gradients: every dsrl_conv2d_wgrad of a backward pass as a few grids (one per tile configuration, blocks ordered
+ * longest first) plus one slab reduce, instead of one launch + reduce per layer. The weight gradients of a pass depend on nothing
+ * but (x, dy) of their layer and are read by the optimiser only, so the caller may collect the problems while backward runs and
+ * launch them once at its end (ddp.FlatParams does). Split-precision arithmetics only (dsrl_conv_precision 1..3).
+ *   1. ws  = dsrl_conv2d_wgrad_group_workspace_bytes(problems, n); table = dsrl_conv2d_wgrad_group_table_bytes(n)
+ *   2. dsrl_conv2d_wgrad_group_plan(problems, n, host_table, table, dev_table, ws_ptr, ws)  - fills host_table (host memory) with
+ *      device-side descriptors that hold absolute device pointers (x, dy, dw, slabs inside ws_ptr) and offsets valid for dev_table
+ *   3. the caller copies host_table -> dev_table (table bytes, stream-ordered before step 4; from pinned memory if asynchronous)
+ *   4. dsrl_conv2d_wgrad_group_launch(host_table, dev_table, stream)
+ * Same results as n calls of dsrl_conv2d_wgrad up to the summation order over pixel ranges. */
+typedef struct dsrl_wgrad_problem {
+    const float* x; const float* dy; float* dw;
+    int32_t ldx, lddy, N, H, W, C, K, R, S, stride, pad, dil;
+} dsrl_wgrad_problem;
+size_t dsrl_conv2d_wgrad_group_table_bytes(int n);
+size_t dsrl_conv2d_wgrad_group_workspace_bytes(const dsrl_wgrad_problem* problems, int n);
+int dsrl_conv2d_wgrad_group_plan(const dsrl_wgrad_problem* problems, int n, void* host_table, size_t table_bytes, const void* dev_table,
+                                 void* ws, size_t ws_bytes);
+int dsrl_conv2d_wgrad_group_launch(const void* host_table, const void* dev_table, dsrl_stream_t stream);
 /* Arithmetic of the implicit-GEMM conv kernels (forward, dgrad, wgrad, row-folded stem), process-wide. fp32 in, fp32 out and fp32
  * accumulation in every mode; the modes differ in how the products are formed on the matrix cores:
  *   0  v_mfma_f32_32x32x2_f32 (exact fp32 products)

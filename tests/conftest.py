@@ -49,5 +49,6 @@ def _unbind_device_rng():
     every test starts and ends with the key unbound."""
     yield
     if _has_gpu():
-        from dualsuperreslearningforsemseg_amd import _lib
+        from dualsuperreslearningforsemseg_amd import _lib, functional as HF
         _lib.call('dsrl_rng_bind_device_key', None)
+        HF.wgrad_queue = None

@@ -115,6 +115,41 @@ def test_conv_vs_oracle_real_shapes(shape):
     check(host(xt.grad), dxo, 2e-5, 'dx'); check(host(wt.grad), dwo, 2e-5, 'dw'); check(host(bt.grad), dbo, 2e-5, 'db')
 
 
+@pytest.mark.parametrize('mode', ['bf16x6', 'mixed'])
+def test_wgrad_group_vs_oracle_and_per_layer(mode):
+    """dsrl_conv2d_wgrad_group_* (all weight gradients of a pass as a few grouped grids) against the fp64 oracle and against the
+    per-layer dsrl_conv2d_wgrad: three tile configurations, dilated taps that never leave the padding (memset path), a strided conv,
+    19 output channels with a padded gradient stride, a channel count that is no multiple of 32, and a layer long enough for several
+    pixel ranges (slabs + the grouped reduce)."""
+    HF.set_conv_precision(mode)
+    shapes = [(2, 512, 16, 32, 256, 3, 1, 18, 18), (2, 304, 64, 128, 192, 3, 1, 1, 1), (3, 64, 33, 47, 64, 3, 2, 1, 1), (1, 256, 64, 128, 19, 1, 1, 0, 1),
+              (4, 1024, 16, 32, 256, 1, 1, 0, 1), (2, 256, 32, 64, 48, 1, 1, 0, 1), (8, 64, 64, 128, 64, 1, 1, 0, 1), (2, 32, 40, 24, 128, 3, 1, 2, 2),
+              (2, 20, 16, 16, 36, 3, 1, 1, 1)]
+    q = HF.WgradQueue()
+    refs = []
+    for i, (N, C, H, W, K, R, stride, pad, dil) in enumerate(shapes):
+        rs = np.random.RandomState(1000 + i)
+        x = np.maximum(rs.standard_normal((N, C, H, W)), 0).astype(np.float32)
+        w = np.zeros((K, C, R, R), np.float32)
+        Ho, Wo = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1, (W + 2 * pad - dil * (R - 1) - 1) // stride + 1
+        dy = rs.standard_normal((N, K, Ho, Wo)).astype(np.float32)
+        dwo = O.conv2d_bwd(x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64), stride, pad, dil, False)[1]
+        xt, ldx = HF.pm_vec4(dev(x)); dyt, lddy = HF.pm_vec4(dev(dy))
+        shp = (N, H, W, C, K, R, R, stride, pad, dil)
+        dw_g = torch.full((K, C, R, R), float('nan'), device=DEV).contiguous(memory_format=torch.channels_last)
+        dw_l = torch.empty_like(dw_g)
+        ws = HF._ws(HF.cquery('dsrl_conv2d_wgrad_workspace_bytes', *shp), xt)
+        HF.call('dsrl_conv2d_wgrad', xt.data_ptr(), ldx, dyt.data_ptr(), lddy, dw_l.data_ptr(), *shp, ws.data_ptr(), ws.numel(), HF._stream())
+        q.add(xt, ldx, dyt, lddy, dw_g, shp)
+        refs.append((dwo, dw_g, dw_l, shp))
+    q.flush()
+    tol = 3e-5 if mode == 'mixed' else 3e-6
+    for dwo, dw_g, dw_l, shp in refs:
+        e1 = check(host(dw_g), dwo, tol, f'grouped dw {shp}')
+        e2 = check(host(dw_g), host(dw_l), tol, f'grouped vs per-layer {shp}')
+        print(shp, '%.1e %.1e' % (e1, e2))
+
+
 def test_conv_into_and_from_channel_slices():
     """ld > C: reading a channel slice of a wider buffer (the concat layout) gives the same result."""
     rs = np.random.RandomState(5)
@@ -581,8 +616,14 @@ def test_gradient_sink_matches_autograd_accumulation():
             flat.finish_reduction()              # joins the side stream the weight-gradient kernels ran on
             assert len(flat._claimed) >= 30
         grads.append({k: host(p.grad) for k, p in head.named_parameters()})
-    bad = {k: float(np.abs(grads[0][k] - grads[1][k]).max()) for k in grads[0] if not np.array_equal(grads[0][k], grads[1][k])}
-    assert not bad, bad
+    # BN gradients: the same kernels either way - bit-identical.  Conv weight gradients: the arena path defers them into the grouped launch
+    # (dsrl_conv2d_wgrad_group_*), whose pixel ranges are split differently from the per-layer launch - equal up to the summation order.
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        if a.ndim == 4 and 'upsample16_pred' not in k and 'feature_transformer' not in k:
+            assert np.abs(a - b).max() <= 2e-6 * max(np.abs(a).max(), 1e-30), (k, float(np.abs(a - b).max()), float(np.abs(a).max()))
+        else:
+            assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
 
 
 def test_batched_filter_transposes_match_per_layer_path():
