@@ -6,11 +6,15 @@ What differs by design:
   * gradients are reduced and the SGD update applied on flat arenas (ddp.FlatParams) over RCCL instead of torch DDP buckets;
   * the reference's 8 blocking device->host reads and 3 host-side NaN scans per iteration (train_or_resume.py:406-451) are
     folded into ONE readback of [CE, MSE, FA, Total, nan_flag] per iteration with the same abort-on-NaN behaviour;
-  * apex mixed precision (`mixed_precision`) is not available: the kernels are fp32 and a non-empty value is rejected;
+  * apex is not used. `mixed_precision` (apex opt levels 'O0'..'O3' in the reference, train_or_resume.py:68-72, 441-444) selects the
+    arithmetic of the MFMA conv kernels instead: 'O0' = fp32-equivalent bf16x6, 'O1' = bf16x6 forward / bf16x3 gradients, 'O2'/'O3' =
+    bf16x3 everywhere (BASELINE config 5's reduced-precision MFMA path).  Storage and accumulation stay fp32 in every mode, so there
+    is no loss scaling (nothing can underflow that fp32 training would keep) and `amp_state_dict` is None;
   * the input pipeline (torchvision Cityscapes + PIL transforms) is out of scope: `dataset` may carry a 'loader_factory'
     (callable(split, batch_size, device, rank, world) -> iterable of ((input_image, input_org), (target, _))) and
     `SyntheticCityscapes` below provides device-resident batches of the Cityscapes shapes.
 """
+import glob
 import os
 from datetime import datetime
 
@@ -266,8 +270,10 @@ def train_or_resume(is_resuming_training, device, distributed, mixed_precision, 
                     weights_decay, poly_power, stage, w1, w2, freeze_batch_norm, experiment_id, description, early_stopping, dry_run=False, **other_args):
     if not isCUDAdevice(device):
         raise RuntimeError("this build runs on the MI355X only: use device='gpu' (the reference's --device cpu path is its own)")
-    if mixed_precision:
-        raise RuntimeError('apex mixed precision is not available: the HIP kernels are fp32')
+    if mixed_precision not in settings.MIXED_PRECISION_TO_CONV_ARITHMETIC:
+        raise RuntimeError(f"mixed_precision={mixed_precision!r}: expected one of {sorted(k for k in settings.MIXED_PRECISION_TO_CONV_ARITHMETIC if k)} "
+                           '(apex itself is not used: the opt level selects the MFMA conv arithmetic)')
+    conv_arith = settings.MIXED_PRECISION_TO_CONV_ARITHMETIC[mixed_precision]
     input_size = other_args.get('model_input_size', settings.MODEL_INPUT_SIZE)
     if distributed:
         t.manual_seed(settings.RANDOM_SEED)                                                # identical init on all ranks, :31
@@ -319,30 +325,72 @@ def train_or_resume(is_resuming_training, device, distributed, mixed_precision, 
     val_loader = factory('val', batch_size, device_obj, rank, world) if is_master_rank else None
 
     history = []
-    for epoch in range(starting_epoch + 1, epochs + 1):
-        lr = polynomial_lr(learning_rate, end_learning_rate, epoch - 1, epochs, poly_power)       # scheduler.step() per epoch, :349
-        means = _do_train_val(True, epoch, model, step, train_loader, lr, momentum, weights_decay, freeze_batch_norm, is_master_rank)
-        rec = {'epoch': epoch, 'lr': lr, 'train': means}
-        if is_master_rank:
-            if epoch % checkpoint_interval == 0 and experiment_id:
-                ckpt_dir = os.path.join(experiment_id, settings.CHECKPOINTS_DIR.format(stage=stage))
-                os.makedirs(ckpt_dir, exist_ok=True)
-                t.save({'device': device, 'mixed_precision': mixed_precision, 'amp_state_dict': None, 'batch_size': batch_size, 'epochs': epochs,
-                        'learning_rate': learning_rate, 'end_learning_rate': end_learning_rate, 'momentum': momentum, 'weights_decay': weights_decay,
-                        'poly_power': poly_power, 'stage': stage, 'w1': w1, 'w2': w2, 'freeze_batch_norm': freeze_batch_norm,
-                        'experiment_id': experiment_id, 'description': description, 'early_stopping': early_stopping, 'epoch': epoch,
-                        'best_validation_dict': best_validation_dict, 'CE_train_avg_loss': means[0], 'MSE_train_avg_loss': means[1],
-                        'FA_train_avg_loss': means[2], 'Avg_train_loss': means[3], 'model_state_dict': _get_state_dict(model),
-                        'optimizer_state_dict': flat.state_dict()}, os.path.join(ckpt_dir, settings.CHECKPOINT_FILE.format(epoch=epoch)))
-            if val_loader is not None and epoch % val_interval == 0:
-                rec['val'] = _do_train_val(False, epoch, model, step, val_loader, lr, momentum, weights_decay, False, True)
-                if rec['val'][4] > best_validation_dict['best_miou_percent']:
-                    best_validation_dict = {'epoch': epoch, 'best_miou_percent': rec['val'][4], 'loss': rec['val'][3]}
-        history.append(rec)
+    CE_val_avg_loss = MSE_val_avg_loss = FA_val_avg_loss = Avg_val_loss = None
+    amp_state_dict = None
+
+    def save_checkpoint(filename, epoch, train_means):
+        """utils.py:273-275 with every key of settings.VARIABLES_IN_CHECKPOINT (train_or_resume.py:268-282, 318-332)."""
+        ckpt_dir = os.path.join(experiment_id, settings.CHECKPOINTS_DIR.format(stage=stage))
+        os.makedirs(ckpt_dir, exist_ok=True)
+        have = {'device': device, 'mixed_precision': mixed_precision, 'amp_state_dict': amp_state_dict, 'disable_cudnn_benchmark': disable_cudnn_benchmark,
+                'num_workers': num_workers, 'val_interval': val_interval, 'checkpoint_interval': checkpoint_interval, 'checkpoint_history': checkpoint_history,
+                'init_weights': init_weights, 'batch_size': batch_size, 'epochs': epochs, 'learning_rate': learning_rate,
+                'end_learning_rate': end_learning_rate, 'momentum': momentum, 'weights_decay': weights_decay, 'poly_power': poly_power, 'stage': stage,
+                'w1': w1, 'w2': w2, 'freeze_batch_norm': freeze_batch_norm, 'experiment_id': experiment_id, 'description': description,
+                'early_stopping': early_stopping, 'CE_train_avg_loss': train_means[0], 'MSE_train_avg_loss': train_means[1],
+                'FA_train_avg_loss': train_means[2], 'Avg_train_loss': train_means[3], 'CE_val_avg_loss': CE_val_avg_loss,
+                'MSE_val_avg_loss': MSE_val_avg_loss, 'FA_val_avg_loss': FA_val_avg_loss, 'Avg_val_loss': Avg_val_loss, 'epoch': epoch,
+                'best_validation_dict': best_validation_dict, 'model_state_dict': _get_state_dict(model),
+                'optimizer_state_dict': flat.state_dict(lr, momentum, weights_decay, initial_lr=learning_rate)}
+        t.save({k: have[k] for k in settings.VARIABLES_IN_CHECKPOINT}, os.path.join(ckpt_dir, filename))
+        return ckpt_dir
+
+    if conv_arith is not None:
+        HF.set_conv_precision(conv_arith)
+    try:
+        for epoch in range(starting_epoch + 1, epochs + 1):
+            lr = polynomial_lr(learning_rate, end_learning_rate, epoch - 1, epochs, poly_power)       # scheduler.step() per epoch, :349
+            means = _do_train_val(True, epoch, model, step, train_loader, lr, momentum, weights_decay, freeze_batch_norm, is_master_rank)
+            rec = {'epoch': epoch, 'lr': lr, 'train': means}
+            stop = False
+            if is_master_rank:
+                if checkpoint_history > 0 and epoch % checkpoint_interval == 0 and experiment_id:                 # :264
+                    CE_val_avg_loss = MSE_val_avg_loss = FA_val_avg_loss = Avg_val_loss = None                      # :270-273
+                    ckpt_dir = save_checkpoint(settings.CHECKPOINT_FILE.format(epoch=epoch), epoch, means)
+                    old = epoch - checkpoint_history * checkpoint_interval                                            # :285-291
+                    if old > 0:
+                        stale = os.path.join(ckpt_dir, settings.CHECKPOINT_FILE.format(epoch=old))
+                        if os.path.isfile(stale):
+                            os.remove(stale)
+                if val_loader is not None and epoch % val_interval == 0:                                            # :294
+                    rec['val'] = _do_train_val(False, epoch, model, step, val_loader, lr, momentum, weights_decay, False, True)
+                    CE_val_avg_loss, MSE_val_avg_loss, FA_val_avg_loss, Avg_val_loss, val_mIoU = rec['val'][:5]
+                    if val_mIoU > best_validation_dict['best_miou_percent']:                                        # :318-337
+                        best_validation_dict = {'epoch': epoch, 'best_miou_percent': val_mIoU, 'loss': Avg_val_loss}
+                        if experiment_id:
+                            ckpt_dir = os.path.join(experiment_id, settings.CHECKPOINTS_DIR.format(stage=stage))
+                            for x in glob.glob(os.path.join(ckpt_dir, '*_bestval.checkpoint')):
+                                if os.path.isfile(x):
+                                    os.remove(x)
+                            save_checkpoint(settings.CHECKPOINT_FILE.format(epoch='{:d}_bestval'.format(epoch)), epoch, means)
+                    if means[3] < Avg_val_loss and early_stopping:                                                  # :341-347
+                        rec['early_stopped'] = stop = True
+            history.append(rec)
+            if distributed:
+                # the reference breaks on the master rank only (its other ranks would hang in the next collective); here every rank learns it
+                flag = t.tensor([1 if stop else 0], device=device_obj)
+                dist.broadcast(flag, 0)
+                stop = bool(flag.item())
+            if stop:
+                break
+    finally:
+        step.release()
+        if conv_arith is not None:
+            HF.set_conv_precision(None)
     if is_master_rank and experiment_id:
         wdir = os.path.join(experiment_id, settings.WEIGHTS_DIR.format(stage=stage))
         os.makedirs(wdir, exist_ok=True)
-        t.save({'model_state_dict': _get_state_dict(model), 'mixed_precision': mixed_precision, 'amp_state_dict': None},
+        t.save({'model_state_dict': _get_state_dict(model), 'mixed_precision': mixed_precision, 'amp_state_dict': amp_state_dict},
                os.path.join(wdir, settings.FINAL_WEIGHTS_FILE))                               # utils.py:277-282
         history.append({'elapsed': str(datetime.now() - process_start_timestamp)})
     return history

@@ -230,10 +230,42 @@ class FlatParams:
             HF.sgd_step_(self.p_flat, self.g_flat, self.m_flat, lr, momentum, weight_decay, 1.0 / self.world)
         self.wt_valid = False               # the filters changed: the transposed copies are stale until the next refresh
 
-    def state_dict(self):
-        return {'momentum_arena': self.m_flat.clone(), 'numel': self.numel}
+    def _trainable_in_model_order(self):
+        return [p for p in self.model.parameters() if p.requires_grad]
+
+    def state_dict(self, lr=0.0, momentum=0.0, weight_decay=0.0, initial_lr=None):
+        """The optimiser state in torch.optim.SGD's state_dict layout (what the reference saves as `optimizer_state_dict`,
+        train_or_resume.py:276, and loads back at main.py:51-52): one param group over model.parameters() order, per-parameter
+        `momentum_buffer` tensors (copies of the arena views, channels-last parameters returned in their logical NCHW shape)."""
+        ps = self._trainable_in_model_order()
+        state = {}
+        for i, p in enumerate(ps):
+            o = self.offsets[self._index[id(p)]]
+            state[i] = {'momentum_buffer': self.m_flat.as_strided(p.shape, p.stride(), o).detach().clone().contiguous().cpu()}
+        group = {'lr': lr, 'momentum': momentum, 'dampening': 0, 'weight_decay': weight_decay, 'nesterov': False, 'params': list(range(len(ps)))}
+        if initial_lr is not None:
+            group['initial_lr'] = initial_lr            # what a torch LR scheduler leaves in the group (PolynomialLR in the reference)
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        if sd['numel'] != self.numel:
-            raise ValueError('optimizer arena size mismatch')
-        self.m_flat.copy_(sd['momentum_arena'])
+        """Accepts torch.optim.SGD's layout (a reference checkpoint or our own) and the round-1 arena dump."""
+        if 'momentum_arena' in sd:
+            if sd['numel'] != self.numel:
+                raise ValueError('optimizer arena size mismatch')
+            self.m_flat.copy_(sd['momentum_arena'])
+            return
+        ps = self._trainable_in_model_order()
+        ids = [i for g in sd['param_groups'] for i in g['params']]
+        if len(ids) != len(ps):
+            raise ValueError(f'optimizer state has {len(ids)} parameters, the model {len(ps)}')
+        self.m_flat.zero_()
+        with torch.no_grad():
+            for p, i in zip(ps, ids):
+                st = sd['state'].get(i)
+                buf = None if st is None else st.get('momentum_buffer')
+                if buf is None:
+                    continue                          # torch creates the buffer lazily: a parameter that never stepped has none
+                if tuple(buf.shape) != tuple(p.shape):
+                    raise ValueError(f'momentum buffer {tuple(buf.shape)} does not match parameter {tuple(p.shape)}')
+                o = self.offsets[self._index[id(p)]]
+                self.m_flat.as_strided(p.shape, p.stride(), o).copy_(buf.to(self.device))

@@ -19,6 +19,15 @@ WEIGHTS_DIR = os.path.join(WEIGHTS_ROOT_DIR, 'stage{stage}')
 FINAL_WEIGHTS_FILE = 'final.weights'
 CHECKPOINTS_DIR = os.path.join(WEIGHTS_DIR, 'checkpoints')
 CHECKPOINT_FILE = 'epoch{epoch}.checkpoint'
+# settings.py:76-80: every key main.py:51-52 / inspect_checkpoint read back from a .checkpoint file
+VARIABLES_IN_CHECKPOINT = \
+    ['device', 'mixed_precision', 'amp_state_dict', 'disable_cudnn_benchmark', 'num_workers', 'val_interval', 'checkpoint_interval', 'checkpoint_history',
+     'init_weights', 'batch_size', 'epochs', 'learning_rate', 'end_learning_rate', 'momentum', 'weights_decay', 'poly_power', 'stage', 'w1', 'w2',
+     'freeze_batch_norm', 'experiment_id', 'description', 'early_stopping', 'CE_train_avg_loss', 'MSE_train_avg_loss', 'FA_train_avg_loss',
+     'Avg_train_loss', 'CE_val_avg_loss', 'MSE_val_avg_loss', 'FA_val_avg_loss', 'Avg_val_loss', 'epoch', 'best_validation_dict', 'model_state_dict',
+     'optimizer_state_dict', 'amp_state_dict']
+# `mixed_precision` (apex opt levels in the reference, train_or_resume.py:68-72) selects the arithmetic of the MFMA conv kernels here
+MIXED_PRECISION_TO_CONV_ARITHMETIC = {None: None, '': None, 'O0': 'bf16x6', 'O1': 'mixed', 'O2': 'bf16x3', 'O3': 'bf16x3'}
 STAGES = [1, 2, 3]
 MODEL_INPUT_SIZE = (256, 512)                                   # settings.py:62 (a parameter here, not a constant)
 MODEL_OUTPUT_SIZE = tuple(x * 2 for x in MODEL_INPUT_SIZE)

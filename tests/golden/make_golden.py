@@ -315,6 +315,27 @@ def golden_head_256x512():
     print('head_256x512.npz', out['losses'], out['margin_q'])
 
 
+def golden_head_512x1024():
+    """BASELINE config 5 size (512x1024 input -> 1024x2048 logits), eval forward, B=1: argmax map, top-2 margins, strided logits
+    sample, checksums, feature-transformer maps (FA on 32x32 similarity matrices, n = 1024) and loss values."""
+    out = {}
+    head, outs, L, _ = run_head(gen.FULL, 3, 707, 808, 1, 32, 64, False, False)
+    sssr = np_(outs[0])
+    out['SSSR_argmax'] = sssr.argmax(axis=1).astype(np.uint8)
+    top2 = np.sort(sssr, axis=1)[:, -2:]
+    margin = (top2[:, 1] - top2[:, 0])
+    out['margin_q'] = np.quantile(margin, [0, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 0.5]).astype(np.float64)
+    out['margin_u8'] = np.minimum(margin / 1e-4, 255).astype(np.uint8)
+    out['SSSR_sample'] = gen.strided_sample(sssr, 1 << 17)
+    out['SSSR_sum'] = gen.checksum(sssr)
+    out['SISR_sample'] = gen.strided_sample(np_(outs[1]), 1 << 15)
+    out['SISR_sum'] = gen.checksum(np_(outs[1]))
+    out['SSSR_ft'] = np_(outs[2]); out['SISR_ft'] = np_(outs[3])
+    out['losses'] = np.array([float(x.detach()) for x in L], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, 'head_512x1024.npz'), **out)
+    print('head_512x1024.npz', out['losses'], out['margin_q'])
+
+
 def golden_train_steps():
     """Two SGD steps of the small head (train-mode BN, dropout off): losses per step, a few parameters after
     each step (train_or_resume.py:63-66, 435-445)."""
@@ -380,10 +401,13 @@ def golden_pipeline_and_metrics():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'pipeline':
         golden_pipeline_and_metrics(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'c5':
+        golden_head_512x1024(); sys.exit(0)
     golden_pipeline_and_metrics()
     golden_fa()
     golden_ops()
     golden_head_small()
     golden_head_fullwidth()
     golden_head_256x512()
+    golden_head_512x1024()
     golden_train_steps()

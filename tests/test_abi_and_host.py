@@ -107,7 +107,7 @@ def test_train_or_resume_rejects_cpu_and_amp():
     with pytest.raises(RuntimeError):
         train_or_resume(device='cpu', mixed_precision=None, **kw)
     with pytest.raises(RuntimeError):
-        train_or_resume(device='gpu', mixed_precision='O1', **kw)
+        train_or_resume(device='gpu', mixed_precision='fp8', **kw)          # apex opt levels O0..O3 select the conv arithmetic; anything else is refused
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

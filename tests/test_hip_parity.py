@@ -518,6 +518,73 @@ def test_head_256x512_golden(golden):
     assert abs(pix[0] - mean[0]) < 1e-3 and abs(pix[1] - mean[1]) < 1e-3      # "mIoU vs ref" on the argmax maps
 
 
+def test_head_512x1024_golden(golden):
+    """BASELINE.json config 5's size: 512x1024 input -> 1024x2048 logits, B=1, eval, against vectors from the imported reference:
+    identical argmax map (flips only at the reference's own near-ties), logits / SISR / transformer maps / CE, MSE, FA (32x32
+    similarity matrices: n = 1024 all-pairs terms) within 1e-3."""
+    g = golden('head_512x1024')
+    head, _ = make_head(gen.FULL, 3, 707, False)
+    x16, x4, target, org = gen.make_head_inputs(808, 1, 32, 64, gen.FULL)
+    with torch.no_grad():
+        outs = head(dev(x16), dev(x4))
+        L = hip_losses(outs, dev(target), dev(org), 3)
+    sssr = host(outs[0])
+    assert sssr.shape == (1, 19, 1024, 2048)
+    check(gen.strided_sample(sssr, 1 << 17), g['SSSR_sample'], TOL)
+    am = sssr.argmax(axis=1).astype(np.uint8)
+    diff = am != g['SSSR_argmax']
+    assert not np.any(diff & (g['margin_u8'] > 0)), f'{int(diff.sum())} argmax flips outside near-ties'
+    assert diff.mean() < 1e-5
+    check(gen.checksum(sssr)[:2], g['SSSR_sum'][:2], 1e-4)
+    check(gen.strided_sample(host(outs[1]), 1 << 15), g['SISR_sample'], TOL)
+    check(host(outs[2]), g['SSSR_ft'], TOL); check(host(outs[3]), g['SISR_ft'], TOL)
+    check(np.array([float(v) for v in L]), g['losses'], TOL)
+    pix, mean = O.miou_batch(am, target), O.miou_batch(g['SSSR_argmax'], target)
+    assert abs(pix[0] - mean[0]) < 1e-3 and abs(pix[1] - mean[1]) < 1e-3
+
+
+@pytest.mark.parametrize('mode', ['bf16x6', 'bf16x3'])
+def test_full_size_train_step_properties_512x1024(mode):
+    """Config-5 size end to end (whole model, 512x1024 -> 1024x2048, B=2, train mode with dropout), where no oracle finishes in seconds:
+    size-independent properties instead.  (1) Determinism: the same step from the same state and dropout key gives bit-identical
+    losses and gradients (no atomics, fixed reduction orders).  (2) The reduced-precision arithmetic of config 5 ('bf16x3': 16-bit
+    operands on the matrix cores, fp32 storage and accumulation - no loss scaling needed, the exponent range is fp32's) stays
+    within 2e-3 of the fp32-equivalent run on the losses, and its gradient arena keeps the direction (cosine > 0.99)."""
+    from dualsuperreslearningforsemseg_amd.command_handlers.train_or_resume import SyntheticCityscapes, TrainStep
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    from dualsuperreslearningforsemseg_amd.ddp import FlatParams
+    torch.manual_seed(54321)
+    model = D.DSRL(3, cs)
+    with torch.no_grad():
+        for m in model.modules():
+            if hasattr(m, 'bn3'):
+                m.bn3.weight.fill_(0.5)
+    model = model.to(DEV).to(memory_format=torch.channels_last).train()
+    flat = FlatParams(model)
+    (img, org), (tgt, _) = next(iter(SyntheticCityscapes(2, (512, 1024), torch.device(DEV), length=1)))
+    p0, b0 = flat.p_flat.clone(), flat.b_flat.clone()
+    runs = []
+    for m_ in (mode, mode, 'bf16x6'):
+        HF.set_conv_precision(m_)
+        flat.p_flat.copy_(p0); flat.b_flat.copy_(b0); flat.m_flat.zero_()
+        HF.set_dropout_seed(31337)
+        step = TrainStep(model, flat, 3, 0.1, 1.0, 255, graph=False)
+        losses, outs = step(img, org, tgt, 0.0, 0.9, 0.0, True)          # lr 0: the state stays put, the gradients are what we look at
+        assert outs[0].shape == (2, 19, 1024, 2048) and outs[2].shape == (2, 1, 128, 256)
+        runs.append((losses, flat.g_flat.clone()))
+    assert all(np.isfinite(v) for v in runs[0][0]), runs[0][0]
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]), 'the step is not deterministic'
+    ref = runs[2]
+    for a, b in zip(runs[0][0], ref[0]):
+        assert abs(a - b) <= 2e-3 * max(abs(b), 1e-3), (runs[0][0], ref[0])
+    rel = float((runs[0][1] - ref[1]).norm() / ref[1].norm())
+    cos = float(torch.dot(runs[0][1].double(), ref[1].double()) / (runs[0][1].double().norm() * ref[1].double().norm()))
+    # a random-init 101-layer net with batch-2 BatchNorm amplifies 1e-5 perturbations (ReLU flips): the whole-arena gradient is held to
+    # its direction, the per-op accuracy of the mode is pinned by test_conv_precision_modes (3e-5 per conv)
+    assert cos > 0.99, (cos, rel)
+    print(mode, 'losses', runs[0][0], 'gradient arena vs bf16x6: L2 difference %.2e, cosine %.5f' % (rel, cos))
+
+
 def test_head_train_with_dropout_vs_oracle():
     """Full train mode (batch-stat BN AND the four Dropout(0.2) modules live): HIP vs the fp64 oracle driven by the same
     Philox keys - the case the reference itself cannot be compared on (torch's RNG stream differs)."""
@@ -820,14 +887,40 @@ def test_train_or_resume_end_to_end(tmp_path):
     hist = train_or_resume(is_resuming_training=False, **kw)
     assert len(hist) == 3 and all(np.isfinite(v) for h in hist[:2] for v in h['train'][:4])
     assert abs(hist[1]['lr'] - ((0.006 - 0.0005) * (1 - 1 / 2) ** 0.9 + 0.0005)) < 1e-12 and 'val' in hist[0] and 0 <= hist[0]['val'][4] <= 100
-    ck = torch.load(os.path.join(str(tmp_path / 'exp'), settings.CHECKPOINTS_DIR.format(stage=3), settings.CHECKPOINT_FILE.format(epoch=2)), map_location='cpu', weights_only=False)
+    ckdir = os.path.join(str(tmp_path / 'exp'), settings.CHECKPOINTS_DIR.format(stage=3))
+    ck = torch.load(os.path.join(ckdir, settings.CHECKPOINT_FILE.format(epoch=2)), map_location='cpu', weights_only=False)
     assert ck['epoch'] == 2 and ck['stage'] == 3 and len(ck['model_state_dict']) == 702
+    # the reference reads back every key of settings.VARIABLES_IN_CHECKPOINT (main.py:51-52) and feeds optimizer_state_dict to torch.optim.SGD
+    assert set(ck) == set(settings.VARIABLES_IN_CHECKPOINT)
+    stock = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros_like(v)) for k, v in ck['model_state_dict'].items()
+                                    if not any(s_ in k for s_ in ('running_', 'num_batches'))])
+    opt = torch.optim.SGD(stock, lr=0.1, momentum=0.9)
+    opt.load_state_dict(ck['optimizer_state_dict'])                    # torch's own loader accepts the layout
+    assert len(opt.state_dict()['state']) == len(stock) and opt.param_groups[0]['momentum'] == 0.9 and opt.param_groups[0]['weight_decay'] == 5e-4
+    names = sorted(os.listdir(ckdir))
+    assert settings.CHECKPOINT_FILE.format(epoch=1) in names and any(n.endswith('_bestval.checkpoint') for n in names) == (ck['best_validation_dict']['epoch'] > 0), names
     fw = torch.load(os.path.join(str(tmp_path / 'exp'), settings.WEIGHTS_DIR.format(stage=3), settings.FINAL_WEIGHTS_FILE), map_location='cpu', weights_only=False)
     assert set(fw) == {'model_state_dict', 'mixed_precision', 'amp_state_dict'}
     kw['epochs'] = 3
     hist2 = train_or_resume(is_resuming_training=True, model_state_dict=ck['model_state_dict'], optimizer_state_dict=ck['optimizer_state_dict'],
                             epoch=ck['epoch'], best_validation_dict=ck['best_validation_dict'], **kw)
     assert hist2[0]['epoch'] == 3
+    # checkpoint_history = 2, interval 1: writing epoch 3 prunes epoch 1 (train_or_resume.py:285-291); only one *_bestval file at a time
+    names = sorted(os.listdir(ckdir))
+    assert settings.CHECKPOINT_FILE.format(epoch=1) not in names and settings.CHECKPOINT_FILE.format(epoch=3) in names, names
+    assert sum(n.endswith('_bestval.checkpoint') for n in names) <= 1
+    # the momentum buffers really travelled: a resume from the SGD-layout state equals the state the first run ended epoch 2 with
+    from dualsuperreslearningforsemseg_amd.ddp import FlatParams
+    m2 = D.DSRL(3, cs); m2.load_state_dict(ck['model_state_dict']); m2 = m2.to(DEV).to(memory_format=torch.channels_last)
+    f2 = FlatParams(m2); f2.load_state_dict(ck['optimizer_state_dict'])
+    assert float(f2.m_flat.abs().sum()) > 0
+    rt = f2.state_dict(0.1, 0.9, 5e-4)
+    for i, st in ck['optimizer_state_dict']['state'].items():
+        assert torch.equal(rt['state'][i]['momentum_buffer'], st['momentum_buffer']), i
+    # apex opt levels map onto the conv arithmetic (BASELINE config 5's reduced-precision path) and do not leak out of the call
+    kw.update(epochs=1, mixed_precision='O2', experiment_id=str(tmp_path / 'exp_o2'))
+    hist3 = train_or_resume(is_resuming_training=False, **kw)
+    assert np.isfinite(hist3[0]['train'][3]) and HF.get_conv_precision() == 'bf16x6'
 
 
 def test_seg_metrics_golden(golden):
