@@ -94,6 +94,10 @@ PROTOTYPES = {
     'dsrl_mse_workspace_bytes': (sz, [i64]),
     'dsrl_mse_fwd': (i32, [fp, fp, i64, fp, fp, sz, stream_t]),
     'dsrl_mse_bwd': (i32, [fp, fp, i64, fp, fp, stream_t]),
+    'dsrl_ce_fused_workspace_bytes': (sz, [i64]),
+    'dsrl_ce_fused': (i32, [fp, i32, fp, i64, i32, i32, fp, i32, fp, fp, fp, sz, stream_t]),
+    'dsrl_mse_fused': (i32, [fp, fp, i64, f32, fp, fp, fp, fp, sz, stream_t]),
+    'dsrl_loss_mix': (i32, [fp, fp, fp, f32, f32, fp, fp, stream_t]),
     'dsrl_fa_saved_floats': (sz, [i32] * 5),
     'dsrl_fa_workspace_bytes': (sz, [i32] * 5),
     'dsrl_fa_fwd': (i32, [fp, fp, i32, i32, i32, i32, i64, i64, i64, i64, i32, i32, fp, fp, fp, sz, stream_t]),

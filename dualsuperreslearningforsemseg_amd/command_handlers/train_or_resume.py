@@ -88,6 +88,7 @@ class TrainStep:
         self.zero = t.zeros((), device=dev)
         self._pending, self._free = [], []           # (pinned host buffer, event) of iterations in flight / reusable
         self.use_graph = (os.environ.get('DSRL_GRAPH', '1') != '0') if graph is None else bool(graph)
+        self.fused_losses = os.environ.get('DSRL_FUSED_LOSSES', '1') != '0'
         self._graphs, self._warm = {}, {}
         self.rng = self.hyper = self._hyper_host = self._hyper_vals = None
         self.host_enqueue_s = 0.0
@@ -119,8 +120,14 @@ class TrainStep:
         self.flag.zero_()
         with t.set_grad_enabled(do_train):
             outs = self.model(input_image)                                                 # :420
-            HF.nan_check_(self.flag, *[o for o in outs if o.is_cuda])                      # the four NaN asserts, :426-433
-            ce, ms, fa, total = self.losses(outs, input_org, target)
+            if self.fused_losses:
+                # CE + MSE + FA, their gradients, the NaN asserts (:426-433) and the loss mix (:435-438) in one launch set
+                vals = HF.fused_losses(outs, target, input_org, self.ignore, self.w1, self.w2, self.stage, self.flag, self.fa.subsample_factor)
+                total = vals[3]
+            else:
+                HF.nan_check_(self.flag, *[o for o in outs if o.is_cuda])                  # the four NaN asserts, :426-433
+                ce, ms, fa, total = self.losses(outs, input_org, target)
+                vals = None
             if do_train:
                 total.backward()                                                           # :444 (eager: chunked RCCL all-reduce overlaps)
                 if in_graph and flat.world > 1:
@@ -133,8 +140,9 @@ class TrainStep:
                     flat.sgd_step(hp[0], hp[1], hp[2], hyper=self.hyper if dev_mode else None, reduce=False)
                 else:
                     flat.sgd_step(hp[0], hp[1], hp[2], hyper=self.hyper if dev_mode else None)     # :445
-        vals = t.cat([t.stack([ce, ms, fa, total]).detach().float(), self.flag.float()])
-        return outs, vals
+        if vals is None:
+            vals = t.cat([t.stack([ce, ms, fa, total]).detach().float(), self.flag.float()])
+        return outs, vals.detach()
 
     def _set_hyper(self, hp):
         vals = (float(hp[0]), float(hp[1]), float(hp[2]), 1.0 / self.flat.world)

@@ -82,6 +82,127 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
 }
 
+// ---------------------------------------------------------------------------------------------- fused loss pass
+// One pass over the logits instead of two: the kernel computes the per-pixel CE terms AND writes d(CE)/d(logits) for an upstream
+// gradient of 1 (the loss is the root of the backward pass), checks the logits for NaN on the way (the reference's per-output NaN
+// asserts, train_or_resume.py:426-433) and stages 256 pixels x C logits through LDS with 16-byte accesses when the tensor is dense.
+// The mean's denominator (pixels that are not ignored) comes from a pre-pass over the uint8 target (4 MB at 8 x 512 x 1024).
+constexpr int kCountBlocks = 64;
+__global__ __launch_bounds__(256) void count_valid_kernel(const unsigned char* __restrict__ target, long long P, int ignore_index, unsigned* __restrict__ part) {
+    __shared__ unsigned sh[4];
+    unsigned n = 0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < P; e += (long long)gridDim.x * 256) n += (target[e] != ignore_index) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void ce_fused_kernel(const float* __restrict__ logits, int ld, const unsigned char* __restrict__ target, long long P, int C,
+                                                        int ignore_index, const unsigned* __restrict__ cnt_part, float* __restrict__ dl, int lddl,
+                                                        double* __restrict__ part, int* __restrict__ nan_flag, int vec_in, int vec_out) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];         // [256][C]
+    __shared__ double shd[4];
+    __shared__ float sh_scale;
+    if (threadIdx.x == 0) {
+        unsigned long long n = 0;
+        for (int i = 0; i < kCountBlocks; ++i) n += cnt_part[i];
+        sh_scale = 1.f / (float)n;              // n = 0: every pixel ignored, the loss is 0/0 = NaN as in torch and no gradient element uses the scale
+    }
+    __syncthreads();
+    const float scale = sh_scale;
+    double loss = 0.0, cnt = 0.0;
+    bool bad = false;
+    for (long long p0 = (long long)blockIdx.x * 256; p0 < P; p0 += (long long)gridDim.x * 256) {
+        const int np = (int)min(256ll, P - p0);
+        const int nf = np * C;
+        __syncthreads();
+        if (vec_in) {           // dense rows: 256 pixels are one contiguous run that starts on a 16-byte boundary
+            const float4* src = reinterpret_cast<const float4*>(logits + p0 * C);
+            for (int t = threadIdx.x; t < (nf >> 2); t += 256) reinterpret_cast<float4*>(tile)[t] = src[t];
+            for (int t = (nf & ~3) + threadIdx.x; t < nf; t += 256) tile[t] = logits[p0 * C + t];
+        } else {
+            for (int t = threadIdx.x; t < nf; t += 256) { const int r = t / C, c = t - r * C; tile[t] = logits[(p0 + r) * ld + c]; }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < np) {
+            const int tg = target[p0 + threadIdx.x];
+            float* v = tile + threadIdx.x * C;
+            float m = v[0];
+            for (int c = 1; c < C; ++c) m = fmaxf(m, v[c]);
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s += expf(v[c] - m);
+            bad |= !(s == s);                   // any NaN logit poisons the sum (fmaxf alone would skip it)
+            if (tg != ignore_index) {
+                loss += (double)(m + logf(s) - v[min(tg, C - 1)]);
+                cnt += 1.0;
+                if (dl) {
+                    const float inv = scale / s;
+                    for (int c = 0; c < C; ++c) v[c] = expf(v[c] - m) * inv - (c == tg ? scale : 0.f);
+                }
+            } else if (dl) {
+                for (int c = 0; c < C; ++c) v[c] = 0.f;
+            }
+        }
+        if (dl) {
+            __syncthreads();
+            if (vec_out) {
+                float4* dst = reinterpret_cast<float4*>(dl + p0 * C);
+                for (int t = threadIdx.x; t < (nf >> 2); t += 256) dst[t] = reinterpret_cast<const float4*>(tile)[t];
+                for (int t = (nf & ~3) + threadIdx.x; t < nf; t += 256) dl[p0 * C + t] = tile[t];
+            } else {
+                for (int t = threadIdx.x; t < nf; t += 256) { const int r = t / C, c = t - r * C; dl[(p0 + r) * lddl + c] = tile[t]; }
+            }
+        }
+    }
+    const double l = block_sum_d(loss, shd);
+    const double n = block_sum_d(cnt, shd);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = l; part[2 * blockIdx.x + 1] = n; }
+    if (nan_flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
+}
+// MSE forward and backward in one pass: partial sums of (a-b)^2 and da = (a-b) * 2 * grad_scale / n; NaN check of `a`
+__global__ __launch_bounds__(256) void mse_fused_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float sc, float* __restrict__ da,
+                                                         double* __restrict__ part, int* __restrict__ nan_flag, int vec) {
+    __shared__ double shd[4];
+    double s = 0.0;
+    bool bad = false;
+    if (vec) {
+        const long long n4 = n >> 2;
+        const float4* a4 = reinterpret_cast<const float4*>(a); const float4* b4 = reinterpret_cast<const float4*>(b); float4* d4 = reinterpret_cast<float4*>(da);
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) {
+            const float4 x = a4[e], y = b4[e];
+            const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+            bad |= !(x.x == x.x) | !(x.y == x.y) | !(x.z == x.z) | !(x.w == x.w);
+            s += (double)(d0 * d0) + (double)(d1 * d1) + (double)(d2 * d2) + (double)(d3 * d3);
+            if (da) d4[e] = make_float4(d0 * sc, d1 * sc, d2 * sc, d3 * sc);
+        }
+        for (long long e = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+            const float d = a[e] - b[e];
+            bad |= !(a[e] == a[e]);
+            s += (double)(d * d);
+            if (da) da[e] = d * sc;
+        }
+    } else {
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+            const float d = a[e] - b[e];
+            bad |= !(a[e] == a[e]);
+            s += (double)(d * d);
+            if (da) da[e] = d * sc;
+        }
+    }
+    const double t = block_sum_d(s, shd);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+    if (nan_flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
+}
+// vals = {CE, w1 * MSE, w2 * FA, their sum, NaN flag}: the five scalars one iteration reads back (train_or_resume.py:435-438, 457-460)
+__global__ void loss_mix_kernel(const float* __restrict__ ce, const float* __restrict__ mse, const float* __restrict__ fa, float w1, float w2,
+                                const int* __restrict__ nan_flag, float* __restrict__ vals) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float c = ce[0], m = mse ? w1 * mse[0] : 0.f, f = fa ? w2 * fa[0] : 0.f;
+        vals[0] = c; vals[1] = m; vals[2] = f; vals[3] = c + m + f; vals[4] = nan_flag ? (float)nan_flag[0] : 0.f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- MSE
 __global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, double* __restrict__ part) {
     __shared__ double shd[4];
@@ -435,6 +556,47 @@ extern "C" int dsrl_mse_bwd(const float* a, const float* b, int64_t n, const flo
     if (int e = bind_stream_device(st)) return e;
     hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 1024), 8192)), dim3(256), 0, st, a, b, (long long)n, grad_out, da);
     return launch_status("mse_bwd_kernel");
+}
+
+extern "C" size_t dsrl_ce_fused_workspace_bytes(int64_t P) { return (size_t)2 * loss_blocks(P) * sizeof(double) + 256; }
+extern "C" int dsrl_ce_fused(const float* logits, int ld, const uint8_t* target, int64_t P, int C, int ignore_index, float* dlogits, int lddl,
+                             float* loss_out, int* nan_flag, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_REQUIRE(logits && target && loss_out && ws && P > 0 && C > 0 && C <= 60 && ld >= C && (!dlogits || lddl >= C), DSRL_E_BADARG, "ce_fused: bad arguments (C=%d)", C);
+    DSRL_REQUIRE(ws_bytes >= dsrl_ce_fused_workspace_bytes(P) && ((uintptr_t)ws % 8) == 0, DSRL_E_WORKSPACE, "ce_fused: workspace too small or misaligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const int nb = loss_blocks(P);
+    double* part = (double*)ws;
+    unsigned* cnt = (unsigned*)(part + 2 * nb);
+    hipLaunchKernelGGL(count_valid_kernel, dim3(kCountBlocks), dim3(256), 0, st, target, (long long)P, ignore_index, cnt);
+    if (int e = launch_status("count_valid_kernel")) return e;
+    const int vec_in = (ld == C && ((uintptr_t)logits % 16) == 0) ? 1 : 0;          // 256 * C floats per tile: every tile starts 16-byte aligned
+    const int vec_out = (dlogits && lddl == C && ((uintptr_t)dlogits % 16) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(ce_fused_kernel, dim3(nb), dim3(256), (size_t)256 * C * sizeof(float), st, logits, ld, target, (long long)P, C, ignore_index,
+                       (const unsigned*)cnt, dlogits, lddl, part, nan_flag, vec_in, vec_out);
+    if (int e = launch_status("ce_fused_kernel")) return e;
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)part, nb, loss_out);
+    return launch_status("ce_finalize_kernel");
+}
+extern "C" int dsrl_mse_fused(const float* a, const float* b, int64_t n, float grad_scale, float* da, float* loss_out, int* nan_flag,
+                              void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_REQUIRE(a && b && loss_out && ws && n > 0, DSRL_E_BADARG, "mse_fused: bad arguments");
+    DSRL_REQUIRE(ws_bytes >= dsrl_mse_workspace_bytes(n), DSRL_E_WORKSPACE, "mse_fused: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    const int nb = loss_blocks(n / 4 + 1);
+    const int vec = (((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && (!da || ((uintptr_t)da % 16) == 0)) ? 1 : 0;
+    hipLaunchKernelGGL(mse_fused_kernel, dim3(nb), dim3(256), 0, st, a, b, (long long)n, 2.f * grad_scale / (float)n, da, (double*)ws, nan_flag, vec);
+    if (int e = launch_status("mse_fused_kernel")) return e;
+    hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, (long long)n, loss_out);
+    return launch_status("mse_finalize_kernel");
+}
+extern "C" int dsrl_loss_mix(const float* ce, const float* mse, const float* fa, float w1, float w2, const int* nan_flag, float* vals, dsrl_stream_t stream) {
+    DSRL_REQUIRE(ce && vals, DSRL_E_BADARG, "loss_mix: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(loss_mix_kernel, dim3(1), dim3(64), 0, st, ce, mse, fa, w1, w2, nan_flag, vals);
+    return launch_status("loss_mix_kernel");
 }
 
 static int fa_dims(int H, int W, int k, int& hp, int& wp) {

@@ -870,7 +870,8 @@ class _PointwiseStrided(torch.autograd.Function):
     """1x1 conv, stride s, one output channel, no bias (DSRL.py:88-93)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride):
+    def forward(ctx, x, w, stride, out_slot=None):
+        ctx.out_slot = out_slot
         x = pm_dense(x)
         _need_gpu(w)
         N, Cc, H, W = x.shape
@@ -890,16 +891,24 @@ class _PointwiseStrided(torch.autograd.Function):
         x, wf = ctx.saved_tensors
         N, Cc, H, W = x.shape
         dy = dy.contiguous()
-        dx = new_cl((N, Cc, H, W), x)
+        # x also feeds the fused loss (fused_losses): that node ran first (it is the root of the backward pass) and published the dense
+        # gradient it returned for x; our contribution lives on the stride grid only (1/64 of the pixels) and is added into that buffer
+        # instead of being materialised as a mostly-zero tensor that autograd would then add with a full pass
+        slot = ctx.out_slot
+        acc = (slot is not None and not slot.closed and slot.buf is not None and tuple(slot.buf.shape) == (N, Cc, H, W)
+               and _ld_of(slot.buf) == Cc)
+        dx = slot.buf if acc else new_cl((N, Cc, H, W), x)
         dw = torch.empty(Cc, device=x.device, dtype=torch.float32)
         ws = _ws(cquery('dsrl_pointwise_strided_bwd_workspace_bytes', N, H, W, Cc, ctx.stride), x)
-        call('dsrl_pointwise_strided_bwd', x.data_ptr(), wf.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), 0,
+        call('dsrl_pointwise_strided_bwd', x.data_ptr(), wf.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), int(acc),
              N, H, W, Cc, ctx.stride, ws.data_ptr(), ws.numel(), _stream())
-        return dx, dw.view(ctx.wshape), None
+        if slot is not None and not acc:
+            slot.closed = True
+        return (None if acc else dx), dw.view(ctx.wshape), None, None
 
 
-def pointwise_strided(x, weight, stride):
-    return _PointwiseStrided.apply(x, weight, int(stride))
+def pointwise_strided(x, weight, stride, out_slot=None):
+    return _PointwiseStrided.apply(x, weight, int(stride), out_slot)
 
 
 # ------------------------------------------------------------------------------------------------ losses
@@ -964,6 +973,96 @@ class _MSE(torch.autograd.Function):
 
 def mse_loss(a, b):
     return _MSE.apply(a, b)
+
+
+class _FusedLosses(torch.autograd.Function):
+    """vals = [CE, w1 * MSE, w2 * FA, total, NaN flag] of train_or_resume.py:435-438 with the big gradients produced in the FORWARD pass:
+    one pass over the logits gives the CE value and d(CE)/d(logits), one over the SISR output the MSE value and its gradient
+    (dsrl_ce_fused / dsrl_mse_fused), both also check their input for NaN.  Contract: `vals[3]` is the root of the backward pass, i.e.
+    its incoming gradient is 1 (TrainStep calls vals[3].backward()); the stored gradients are returned as they are."""
+
+    @staticmethod
+    def forward(ctx, sssr, sisr, ft1, ft2, target, org, ignore_index, w1, w2, stage, flag, k):
+        want = bool(ctx.needs_input_grad[0])          # forward-only (validation, no_grad): no gradient buffers are written
+        logits, ld = pm(sssr)
+        _need_gpu(target)
+        if target.dtype != torch.uint8:
+            target = target.to(torch.uint8)
+        target = target.contiguous()
+        N, Cc, H, W = logits.shape
+        P = N * H * W
+        if target.numel() != P:
+            raise DsrlHipError(f'fused_losses: target has {target.numel()} pixels, logits {P}')
+        st = _stream()
+        dev = logits.device
+        scal = torch.empty(8, device=dev, dtype=torch.float32)          # [0:2] CE + pixel count, [2] MSE
+        vals = torch.empty(5, device=dev, dtype=torch.float32)
+        dl = new_cl((N, Cc, H, W), logits) if want else None
+        ws = _ws(cquery('dsrl_ce_fused_workspace_bytes', P), logits)
+        call('dsrl_ce_fused', logits.data_ptr(), ld, target.data_ptr(), P, Cc, int(ignore_index), None if dl is None else dl.data_ptr(), Cc,
+             scal.data_ptr(), flag.data_ptr(), ws.data_ptr(), ws.numel(), st)
+        da = None
+        mse_ptr = fa_ptr = None
+        ctx.fa = None
+        if stage > 1:
+            a = pm_dense(sisr); b = pm_dense(org)
+            if a.shape != b.shape:
+                raise DsrlHipError(f'fused_losses: SISR output {tuple(a.shape)} vs input_org {tuple(b.shape)}')
+            da = new_cl(tuple(a.shape), a) if want else None
+            ws2 = _ws(cquery('dsrl_mse_workspace_bytes', a.numel()), a)
+            mse_ptr = scal.data_ptr() + 8
+            call('dsrl_mse_fused', a.data_ptr(), b.data_ptr(), a.numel(), float(w1), None if da is None else da.data_ptr(), mse_ptr, flag.data_ptr(),
+                 ws2.data_ptr(), ws2.numel(), st)
+        if stage > 2:
+            _need_gpu(ft1, ft2); _f32(ft1); _f32(ft2)
+            if ft1.stride() != ft2.stride() or ft1.data_ptr() % 4 or ft2.data_ptr() % 4:
+                ft1, ft2 = ft1.contiguous(), ft2.contiguous()
+            nan_check_(flag, ft1, ft2)
+            B, Cf, Hf, Wf = ft1.shape
+            fa_out = torch.empty(1, device=dev, dtype=torch.float32)
+            saved = torch.empty(cquery('dsrl_fa_saved_floats', B, Cf, Hf, Wf, k), device=dev, dtype=torch.float32)
+            ws3 = _ws(cquery('dsrl_fa_workspace_bytes', B, Cf, Hf, Wf, k), ft1)
+            sb, sc, sh, sw = ft1.stride()
+            call('dsrl_fa_fwd', ft1.data_ptr(), ft2.data_ptr(), B, Cf, Hf, Wf, sb, sc, sh, sw, k, 0, fa_out.data_ptr(), saved.data_ptr(),
+                 ws3.data_ptr(), ws3.numel(), st)
+            fa_ptr = fa_out.data_ptr()
+            ctx.fa = (ft1, ft2, saved, k, fa_out)
+        call('dsrl_loss_mix', scal.data_ptr(), mse_ptr, fa_ptr, float(w1), float(w2), flag.data_ptr(), vals.data_ptr(), st)
+        ctx.grads = (dl, da)
+        ctx.w2 = float(w2)
+        ctx.slots = (getattr(sssr, '_dsrl_out_slot', None), getattr(sisr, '_dsrl_out_slot', None) if stage > 1 else None)
+        ctx.keep = scal
+        return vals
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, da = ctx.grads
+        if dl is None:
+            raise DsrlHipError('fused_losses: backward without a gradient-enabled forward')
+        d1 = d2 = None
+        if ctx.fa is not None:
+            ft1, ft2, saved, k, _ = ctx.fa
+            B, Cf, Hf, Wf = ft1.shape
+            gw = torch.full((1,), ctx.w2, device=ft1.device, dtype=torch.float32)
+            d1 = torch.empty((B, Cf, Hf, Wf), device=ft1.device, dtype=torch.float32)
+            d2 = torch.empty_like(d1)
+            sb, sc, sh, sw = ft1.stride()
+            call('dsrl_fa_bwd', ft1.data_ptr(), ft2.data_ptr(), B, Cf, Hf, Wf, sb, sc, sh, sw, k, 0, gw.data_ptr(), saved.data_ptr(),
+                 d1.data_ptr(), d2.data_ptr(), None, 0, _stream())
+        # publish the two dense gradients: the stride-8 feature transformers add their sparse contributions into them (GradSlot protocol)
+        for slot, buf in zip(ctx.slots, (dl, da)):
+            if slot is not None and buf is not None and not slot.closed and slot.buf is None:
+                slot.buf = buf
+        return dl, da, d1, d2, None, None, None, None, None, None, None, None
+
+
+def fused_losses(outs, target, input_org, ignore_index, w1, w2, stage, flag, subsample_factor=8):
+    """-> 5-float device tensor [CE, w1*MSE, w2*FA, total, NaN flag]; `outs` = DSRL.forward's 4-tuple.  vals[3].backward() is the only
+    supported backward (the function is the root of the pass); `flag` is the int32 NaN flag the fused kernels OR into."""
+    sssr, sisr, ft1, ft2 = outs
+    dummy = sssr.new_zeros(1)
+    return _FusedLosses.apply(sssr, sisr if stage > 1 else dummy, ft1 if stage > 2 else dummy, ft2 if stage > 2 else dummy, target,
+                              input_org if stage > 1 else dummy, int(ignore_index), float(w1), float(w2), int(stage), flag, int(subsample_factor))
 
 
 _RED = {'mean': 0, 'sum': 1, 'none': 2}

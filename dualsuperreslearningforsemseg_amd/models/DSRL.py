@@ -111,6 +111,10 @@ class DSRL(BaseModel):
         if self.stage > 1:
             SISR_output = self.SISR_decoder(cat_features, grad_slot=slot) if slot is not None else self.SISR_decoder(cat_features)   # DSRL.py:177
             if self.stage > 2:
+                if HF.grad_slots_enabled and t.is_grad_enabled() and SSSR_output.requires_grad:
+                    # each output feeds its feature transformer and the loss: with functional.fused_losses the loss publishes the dense
+                    # gradient and the stride-8 transformer adds its sparse one into it (no 320 MB mostly-zero tensor + add pass)
+                    SSSR_output._dsrl_out_slot, SISR_output._dsrl_out_slot = HF.GradSlot(), HF.GradSlot()
                 SSSR_transform_output = self.SSSR_feature_transformer(SSSR_output)            # DSRL.py:181
                 SISR_transform_output = self.SISR_feature_transformer(SISR_output)            # DSRL.py:184
         return SSSR_output, SISR_output, SSSR_transform_output, SISR_transform_output

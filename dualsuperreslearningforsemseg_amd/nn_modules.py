@@ -27,7 +27,8 @@ class HipConv2d(nn.Conv2d):
         if self.out_channels == 1 and k == (1, 1) and self.bias is None and self.in_channels % 4 != 0:
             if grad_slot is not None:
                 grad_slot.closed = True         # this consumer reports its own gradient: nobody may accumulate into a shared buffer
-            return HF.pointwise_strided(x, self.weight, _single(self.stride))          # feature transformers, DSRL.py:88-93
+            # feature transformers, DSRL.py:88-93; x may carry the slot it shares with the fused loss (functional.fused_losses)
+            return HF.pointwise_strided(x, self.weight, _single(self.stride), getattr(x, '_dsrl_out_slot', None))
         return HF.conv2d(x, self.weight, self.bias, _single(self.stride), _single(self.padding), _single(self.dilation), grad_slot=grad_slot)
 
 

@@ -268,6 +268,17 @@ int dsrl_ce_bwd(const float* logits, int ld, const uint8_t* target, int64_t P, i
 size_t dsrl_mse_workspace_bytes(int64_t n);
 int dsrl_mse_fwd(const float* a, const float* b, int64_t n, float* loss_out, void* ws, size_t ws_bytes, dsrl_stream_t stream);
 int dsrl_mse_bwd(const float* a, const float* b, int64_t n, const float* grad_out, float* da, dsrl_stream_t stream);
+/* Fused loss pass (train_or_resume.py:116-117, 426-438): ONE pass over the logits computes CrossEntropyLoss(ignore_index,
+ * mean) into loss_out[0] (loss_out[1] = pixels counted) AND writes d(loss)/d(logits) for an upstream gradient of 1 into dlogits
+ * (nullable: forward only), and ORs 1 into nan_flag (nullable) if a logit is NaN. dsrl_mse_fused does the same for MSELoss:
+ * da = grad_scale * d(mse)/da. dsrl_loss_mix writes {CE, w1*MSE, w2*FA, sum, (float)*nan_flag} to vals[5] (mse / fa nullable: stages 1, 2). */
+size_t dsrl_ce_fused_workspace_bytes(int64_t P);
+int dsrl_ce_fused(const float* logits, int ld, const uint8_t* target, int64_t P, int C, int ignore_index, float* dlogits /*nullable*/, int lddl,
+                  float* loss_out /*[2]*/, int* nan_flag /*nullable*/, void* ws, size_t ws_bytes, dsrl_stream_t stream);
+int dsrl_mse_fused(const float* a, const float* b, int64_t n, float grad_scale, float* da /*nullable*/, float* loss_out, int* nan_flag /*nullable*/,
+                   void* ws, size_t ws_bytes, dsrl_stream_t stream);
+int dsrl_loss_mix(const float* ce, const float* mse /*nullable*/, const float* fa /*nullable*/, float w1, float w2, const int* nan_flag /*nullable*/,
+                  float* vals /*[5]*/, dsrl_stream_t stream);
 
 /* FALoss (models/losses/FALoss.py:8-34). fm1/fm2 are (B,C,H,W) with element strides (sb,sc,sh,sw).
  * reduction: 0 mean, 1 sum, 2 none (out has B*C*n*n floats, n = (W/k)^2).

@@ -605,6 +605,63 @@ def test_head_train_with_dropout_vs_oracle():
     check(host(a.grad), out.inputs[0].g, 2e-3)
 
 
+@pytest.mark.parametrize('stage', [1, 2, 3])
+def test_fused_losses_match_separate_kernels_and_oracle(stage):
+    """functional.fused_losses (CE forward + backward in one pass over the logits, MSE likewise, the NaN asserts folded in, the
+    stride-8 feature transformers adding their sparse gradient into the published dense one) against the separate loss kernels and the
+    fp64 oracle: same five scalars, same parameter and input gradients."""
+    x16, x4, target, org = gen.make_head_inputs(202, 2, 2, 4, gen.SMALL)
+    res = []
+    for fused in (False, True):
+        head, P = make_head(gen.SMALL, stage, 101, True)
+        a = dev(x16).requires_grad_(True); b = dev(x4).requires_grad_(True)
+        outs = head(a, b)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        if fused:
+            vals = HF.fused_losses(outs, dev(target), dev(org), gen.IGNORE, 0.1, 1.0, stage, flag)
+            vals[3].backward()
+            L = [float(v) for v in vals[:4]]
+            assert float(vals[4]) == 0.0 and int(flag) == 0
+            if stage > 2:
+                assert outs[0]._dsrl_out_slot.buf is not None and not outs[0]._dsrl_out_slot.closed          # the transformers accumulated in place
+        else:
+            Lt = hip_losses(outs, dev(target), dev(org), stage)
+            Lt[3].backward()
+            L = [float(v) for v in Lt]
+        res.append((L, {k: host(p.grad) for k, p in head.named_parameters()}, host(a.grad), host(b.grad)))
+    out = O.head_forward({k: v.astype(np.float64) for k, v in P.items()}, x16.astype(np.float64), x4.astype(np.float64), stage, True)
+    Lo = O.total_loss(out, target, org.astype(np.float64), stage)
+    check(np.array(res[1][0]), np.array(Lo), 1e-4, 'fused losses vs oracle')
+    check(np.array(res[1][0]), np.array(res[0][0]), 1e-6, 'fused vs separate losses')
+    for k in res[0][1]:
+        check(res[1][1][k], res[0][1][k], 1e-5, 'grad ' + k)
+    check(res[1][2], res[0][2], 1e-5, 'dx16'); check(res[1][3], res[0][3], 1e-5, 'dx4')
+
+
+def test_fused_losses_nan_flag_and_eval_mode():
+    """The fused kernels raise the NaN flag for a NaN logit / SISR value, and run forward-only (no gradient buffers) under no_grad."""
+    rs = np.random.RandomState(5)
+    sssr = dev(rs.standard_normal((2, 19, 16, 32)).astype(np.float32)); sisr = dev(rs.standard_normal((2, 3, 16, 32)).astype(np.float32))
+    org = dev(rs.standard_normal((2, 3, 16, 32)).astype(np.float32))
+    ft1 = dev(rs.uniform(0.1, 1, (2, 1, 16, 32)).astype(np.float32)); ft2 = dev(rs.uniform(0.1, 1, (2, 1, 16, 32)).astype(np.float32))
+    tgt = dev(rs.randint(0, 19, (2, 16, 32)).astype(np.uint8))
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        v = HF.fused_losses((sssr, sisr, ft1, ft2), tgt, org, 255, 0.1, 1.0, 3, flag, 8)
+    ce = O.cross_entropy(host(sssr).astype(np.float64), host(tgt).astype(np.uint8), 255)
+    ms = O.mse(host(sisr).astype(np.float64), host(org).astype(np.float64))
+    fa = O.fa_loss(host(ft1).astype(np.float64), host(ft2).astype(np.float64), 8)
+    check(host(v[:4]), np.array([ce, 0.1 * ms, fa, ce + 0.1 * ms + fa]), 1e-5)
+    assert float(v[4]) == 0
+    for which in (0, 1):
+        flag.zero_()
+        bad = [sssr.clone(), sisr.clone()]
+        bad[which][1, 2, 3, 4] = float('nan')
+        with torch.no_grad():
+            v = HF.fused_losses((bad[0], bad[1], ft1, ft2), tgt, org, 255, 0.1, 1.0, 3, flag, 8)
+        assert int(flag) == 1 and float(v[4]) == 1.0, which
+
+
 def test_train_steps_golden(golden):
     """Two SGD steps of the small head on the flat-arena optimiser reproduce the reference's parameters."""
     from dualsuperreslearningforsemseg_amd.ddp import FlatParams
