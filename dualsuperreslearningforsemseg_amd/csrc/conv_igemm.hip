@@ -1296,8 +1296,11 @@ static TileCfg pick_cfg(long long M, int N) {
 // wgrad: rows are output channels K, columns input channels C.  Measured on MI355X (tools/sweep_wgrad.py): 128x64 tiles
 // (64x64 when K <= 64) with ~4.5 blocks per CU beat the larger tiles on every layer shape of the step.
 static TileCfg pick_cfg_wgrad(int K, int C) {
-    const int forced = env_int("DSRL_FORCE_CFG", -1);
+    int forced = env_int("DSRL_FORCE_CFG", -1);
+    if (forced < 0) forced = env_int("DSRL_WGRAD_CFG", -1);
     if (forced >= 0 && forced < kNumCfg) return (TileCfg)forced;
+    const int big = env_int("DSRL_WGRAD_BIG_CFG", -1);          // experiment: this tile for layers with K >= 128 and C >= 128
+    if (big >= 0 && big < kNumCfg && K >= 128 && C >= 128) return (TileCfg)big;
     if (C <= 32) return T128x32;
     return K <= 64 ? T64x64 : T128x64;
 }

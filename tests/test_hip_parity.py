@@ -16,6 +16,7 @@ from hip_helpers import *      # noqa: E402,F401,F403
 from hip_helpers import DEV, HF, D, check, dev, host, make_head, hip_losses, rel_err   # noqa: E402
 
 TOL = 1e-3
+HEAD_GRAD_BOUND, ARENA_GRAD_BOUND = 2e-3, 1e-1         # fixed bounds of test_full_model_total_loss_backward_with_fa_vs_oracle (measured: 3e-4 and 3.5e-2)
 
 
 @pytest.fixture(autouse=True)
@@ -924,6 +925,56 @@ def test_full_model_vs_oracle(mode):
     report['all gradients (L2)'] = (l2(g_hip, g_64), l2(g_32, g_64))
     assert report['all gradients (L2)'][0] <= 2.0 * report['all gradients (L2)'][1] + 1e-4, report['all gradients (L2)']
     print({k: f'hip {a:.1e} / f32-oracle {b:.1e}' for k, (a, b) in report.items()})
+
+
+def test_full_model_total_loss_backward_with_fa_vs_oracle():
+    """The WHOLE loss (CE + w1 MSE + w2 FA, train_or_resume.py:435-438) back-propagated through the assembled model at 128x256 input, B=2
+    (feature-transformer maps 32x64 -> 8x8 similarity matrices), through the production loss path (functional.fused_losses: fused CE/MSE
+    kernels, sparse transformer gradient accumulated into the published dense one) against the fp64 oracle, default (fp32-equivalent)
+    arithmetic, with FIXED bounds: losses 1e-3, logits 5e-3 of their range; gradients in the L2 norm over the whole arena and for the tensors
+    the FA term reaches first."""
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    torch.manual_seed(11)
+    model = D.DSRL(3, cs)
+    with torch.no_grad():
+        for m in model.modules():
+            if hasattr(m, 'bn3'):
+                m.bn3.weight.fill_(0.5)
+        model.SSSR_feature_transformer[1].bias.fill_(0.3); model.SISR_feature_transformer[1].bias.fill_(0.3)     # away from FALoss's all-zero NaN corner
+    sd = {k: v.numpy() for k, v in model.state_dict().items() if 'num_batches' not in k}
+    model = model.to(DEV).to(memory_format=torch.channels_last).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    rs = np.random.RandomState(1)
+    x = rs.standard_normal((2, 3, 128, 256)).astype(np.float32)
+    tg = rs.randint(0, 19, (2, 256, 512)).astype(np.uint8); tg[rs.uniform(size=tg.shape) < 0.1] = 255
+    org = rs.standard_normal((2, 3, 256, 512)).astype(np.float32)
+    outs = model(dev(x, cl=False))
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    vals = HF.fused_losses(outs, dev(tg), dev(org), 255, 0.1, 1.0, 3, flag)
+    vals[3].backward()
+    out = O.model_forward({k: v.astype(np.float64) for k, v in sd.items()}, x.astype(np.float64), 3, True)
+    L64 = O.total_loss(out, tg, org.astype(np.float64), 3, backward=True)
+    assert out.SSSR_ft.v.shape == (2, 1, 32, 64) and float(L64[2]) > 0
+    check(host(vals[:4]), np.array(L64), 1e-3, 'losses (CE, MSE, FA, total)')
+    check(host(outs[0]), out.SSSR.v, 5e-3, 'logits')
+    check(host(outs[2]), out.SSSR_ft.v, 5e-3, 'SSSR_ft'); check(host(outs[3]), out.SISR_ft.v, 5e-3, 'SISR_ft')
+
+    def l2(a, b):
+        a = np.asarray(a, np.float64).ravel(); b = np.asarray(b, np.float64).ravel()
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    P = dict(model.named_parameters())
+    rep = {k: l2(host(P[k].grad), out.params[k].g) for k in ('SSSR_feature_transformer.0.weight', 'SISR_feature_transformer.0.weight', 'SSSR_decoder.upsample16_pred.6.weight',
+                                                           'SISR_decoder.0.weight', 'SSSR_decoder.cat_conv.0.weight', 'feature_extractor.aspp.branches.5.0.weight',
+                                                           'feature_extractor.backbone.layer4.2.conv3.weight', 'feature_extractor.backbone.layer1.0.conv1.weight')}
+    names = [k for k in P if P[k].grad is not None and k in out.params]
+    cat = lambda f: np.concatenate([np.asarray(f(k), np.float64).ravel() for k in names])
+    rep['all gradients (L2)'] = l2(cat(lambda k: host(P[k].grad)), cat(lambda k: out.params[k].g))
+    print({k: '%.2e' % v for k, v in rep.items()})
+    for k in ('SSSR_feature_transformer.0.weight', 'SISR_feature_transformer.0.weight', 'SSSR_decoder.upsample16_pred.6.weight', 'SISR_decoder.0.weight'):
+        assert rep[k] <= HEAD_GRAD_BOUND, (k, rep[k])
+    assert rep['all gradients (L2)'] <= ARENA_GRAD_BOUND, rep
 
 
 def test_train_or_resume_end_to_end(tmp_path):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Aggregates rocprofv3 --pmc passes of bench.py into profiles/round1_pmc_traffic.json.
+"""Aggregates rocprofv3 --pmc passes of bench.py into profiles/roundN_pmc_traffic.json.
 
 usage: pmc_traffic.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <out.json>
 Per conv kernel family (the names bench.py's roofline uses, from dsrl_prof_kernel_name) the average HBM-side bytes per launch:
@@ -14,6 +14,9 @@ def family(name):
         return f"conv_igemm_split_kernel<{'bf16x3' if m.group(6) == '2' else 'bf16x6'}> ({'dgrad' if m.group(5) == 'true' else 'forward'})"
     m = re.search(r'conv_wgrad_split_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, \d+)?>', name)
     if m:
+        return f"conv_wgrad_split_kernel<{'bf16x3' if m.group(5) == '2' else 'bf16x6'}>"
+    m = re.search(r'conv_wgrad_group_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>', name)
+    if m:           # the grouped launch of the same kernel body: same family (bench.py's roofline name)
         return f"conv_wgrad_split_kernel<{'bf16x3' if m.group(5) == '2' else 'bf16x6'}>"
     m = re.search(r'conv_igemm_f32_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)', name)
     if m:
@@ -42,6 +45,6 @@ for fam in sorted(set(fetch) | set(write)):
     out[fam] = {'launches_sampled': int(fetch[fam][1]), 'FETCH_SIZE_KB_per_launch_raw': round(f, 1), 'WRITE_SIZE_KB_per_launch': round(w, 1),
                 'hbm_bytes_per_launch': int((2 * f + w) * 1024),
                 'note': 'FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); separate --pmc '
-                        'passes of bench.py --steps 3 --warmup 1 --no-prof --no-cpu-baseline with DSRL_OVERLAP_WGRAD=0'}
+                        'passes of bench.py --steps 3 --warmup 3 --no-prof --no-cpu-baseline'}
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out, indent=1))
