@@ -332,7 +332,7 @@ def main():
         gb = args.batch * world
         by_arith = {default_mode: round(gb * args.steps / elapsed, 1)}
         for mode in ('bf16x6', 'mixed', 'fp32'):
-            if mode == default_mode:
+            if mode == default_mode or (mode == 'fp32' and world > 1):        # exact-product fp32 MFMA: single-GPU figure only
                 continue
             HF.set_conv_precision(mode)
             el, _ = timed(args.warmup, args.steps)

@@ -168,12 +168,15 @@ class TrainStep:
         if os.environ.get('DSRL_GRAPH_OVERLAP', '0') == '0':
             HF.overlap_wgrad = False
         c.keep = HF.graph_keepalive = []          # pinned host tables the captured copies read on every replay
+        HF.capture_host, HF.capture_host_off = t.empty(2 << 20, dtype=t.uint8, pin_memory=True), 0      # allocated BEFORE the capture starts
+        c.keep.append(HF.capture_host)
         try:
             with t.cuda.graph(c.graph, capture_error_mode=os.environ.get('DSRL_GRAPH_CAPTURE_MODE', 'thread_local')):
                 c.outs, c.vals = self._body(c.img, c.org, c.tgt, hp, True, in_graph=True)
         finally:
             HF.overlap_wgrad = overlap_was
             HF.graph_keepalive = None
+            HF.capture_host = None
         # nothing ran during the capture: take back the host-side bookkeeping of that phantom iteration
         HF._rng_state['step'] = step_before
         c.bns = [m for m, n in zip(bns, before) if getattr(m, '_dsrl_batches', 0) != n]

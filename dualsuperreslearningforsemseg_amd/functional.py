@@ -94,6 +94,7 @@ def join_side_streams():
 # neither the side stream nor per-layer pixel splits.  Off: DSRL_WGRAD_GROUP=0 (per-layer launches, overlapped on the side stream).
 group_wgrad = os.environ.get('DSRL_WGRAD_GROUP', '1') != '0'
 graph_keepalive = None          # a list while a hipGraph capture is in progress: host buffers the captured copies read on every replay
+capture_host, capture_host_off = None, 0      # pinned arena for host tables written during a capture (allocated before it starts)
 
 
 class WgradQueue:
@@ -118,7 +119,17 @@ class WgradQueue:
         like = items[0][0]
         tbytes = int(lib.dsrl_conv2d_wgrad_group_table_bytes(n))
         ws = _ws(int(lib.dsrl_conv2d_wgrad_group_workspace_bytes(ctypes.addressof(probs), n)), like)
-        host = torch.empty(tbytes, dtype=torch.uint8, pin_memory=True)
+        if graph_keepalive is not None:
+            # under capture no pinned memory may be allocated (hipHostMalloc is not capturable): the table comes out of the pinned arena
+            # the capturing TrainStep set aside, and that arena lives as long as the graph (its copy node re-reads it on every replay)
+            global capture_host_off
+            off = (capture_host_off + 255) & ~255
+            if capture_host is None or off + tbytes > capture_host.numel():
+                raise DsrlHipError('WgradQueue.flush under graph capture: the pinned table arena is missing or too small')
+            host = capture_host[off:off + tbytes]
+            capture_host_off = off + tbytes
+        else:
+            host = torch.empty(tbytes, dtype=torch.uint8, pin_memory=True)
         dev = torch.empty(tbytes, dtype=torch.uint8, device=like.device)
         call('dsrl_conv2d_wgrad_group_plan', ctypes.addressof(probs), n, host.data_ptr(), tbytes, dev.data_ptr(), ws.data_ptr(), ws.numel())
         dev.copy_(host, non_blocking=True)
