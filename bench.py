@@ -152,8 +152,8 @@ def decoder_stack_roofline(torch, HF, B, H, W, reps=10):
               ('SISR 3x3 304->192', 304, h4, w4, 192, 3, 1, 1)]
     mode = HF.get_conv_precision()
     arith = {'fp32': (0, 0, 0), 'bf16x3': (1, 1, 1), 'bf16x6': (2, 2, 2), 'mixed': (2, 1, 1)}[mode]       # forward, dgrad, wgrad
-    tot = {'forward': [0.0, 0.0], 'dgrad': [0.0, 0.0], 'wgrad': [0.0, 0.0]}
-    layers = {}
+    tot = {'forward': [0.0, 0.0], 'dgrad': [0.0, 0.0], 'wgrad_per_layer': [0.0, 0.0], 'wgrad': [0.0, 0.0]}
+    layers, keep = {}, []
     dev = torch.device('cuda', torch.cuda.current_device())
     for name, C, h, w, K, R, pad, dil in shapes:
         x = torch.randn((B, C, h, w), device=dev).contiguous(memory_format=torch.channels_last)
@@ -173,9 +173,20 @@ def decoder_stack_roofline(torch, HF, B, H, W, reps=10):
         t_f = _time_ms(lambda: _lib.call('dsrl_conv2d_fwd', x.data_ptr(), C, wt.data_ptr(), None, y.data_ptr(), K, *shp, wsf.data_ptr(), wsf.numel(), st), reps, torch)
         t_d = _time_ms(lambda: _lib.call('dsrl_conv2d_dgrad', dy.data_ptr(), Kp, wt.data_ptr(), None, dx.data_ptr(), C, *shp, wsd.data_ptr(), wsd.numel(), st), reps, torch)
         t_w = _time_ms(lambda: _lib.call('dsrl_conv2d_wgrad', x.data_ptr(), C, dy.data_ptr(), Kp, dw.data_ptr(), *shp, wsw.data_ptr(), wsw.numel(), st), reps, torch)
-        layers[name] = {'gflop': round(gf, 2), 'forward_tflops': round(gf / t_f, 1), 'dgrad_tflops': round(gf / t_d, 1), 'wgrad_tflops': round(gf / t_w, 1)}
-        for k, t in (('forward', t_f), ('dgrad', t_d), ('wgrad', t_w)):
+        layers[name] = {'gflop': round(gf, 2), 'forward_tflops': round(gf / t_f, 1), 'dgrad_tflops': round(gf / t_d, 1), 'wgrad_per_layer_tflops': round(gf / t_w, 1)}
+        for k, t in (('forward', t_f), ('dgrad', t_d), ('wgrad_per_layer', t_w)):
             tot[k][0] += gf; tot[k][1] += t
+        keep.append((x, dy, dw, Kp, shp))
+    # the production path launches the weight gradients of a backward pass as grouped grids (dsrl_conv2d_wgrad_group_*): the whole stack at once
+    if mode != 'fp32':
+        def grouped():
+            q = HF.WgradQueue()
+            for x, dy, dw, Kp, shp in keep:
+                q.add(x, shp[3], dy, Kp, dw, shp)
+            q.flush()
+        tot['wgrad'] = [tot['wgrad_per_layer'][0], _time_ms(grouped, reps, torch)]
+    else:
+        tot['wgrad'] = list(tot['wgrad_per_layer'])
     out = {'conv_arithmetic': mode, 'layers': layers,
            'note': 'each conv launched alone through the C ABI (dgrad includes its own filter transpose), events on the launch stream, '
                    f'{reps} launches each; achieved = in-bounds FLOP / time; peak = dense bf16 MFMA 2516.6 TF / (3 | 6 MFMAs per product) or 157.3 TF fp32'}
@@ -185,6 +196,9 @@ def decoder_stack_roofline(torch, HF, B, H, W, reps=10):
         ach = tot[k][0] / tot[k][1]
         out[k] = {'achieved': round(ach, 1), 'peak': round(peak, 1), 'frac': round(ach / peak, 4), 'arithmetic': ARITH_NAME[arith[i]], 'ms': round(tot[k][1], 3)}
         all_f += tot[k][0]; all_t += tot[k][1]
+    out['wgrad']['how'] = 'all ten weight gradients of the stack as ONE grouped launch set (the production path; host table build included in the bracket)'
+    out['wgrad_per_layer_launches'] = {'achieved': round(tot['wgrad_per_layer'][0] / tot['wgrad_per_layer'][1], 1), 'ms': round(tot['wgrad_per_layer'][1], 3),
+                                       'frac': round(tot['wgrad_per_layer'][0] / tot['wgrad_per_layer'][1] / MFMA_PEAK_TFLOPS[arith[2]], 4)}
     out['all_passes'] = {'achieved': round(all_f / all_t, 1), 'ms': round(all_t, 3),
                          'frac_of_time_weighted_peak': round(sum(tot[k][1] * (tot[k][0] / tot[k][1]) / MFMA_PEAK_TFLOPS[arith[i]]
                                                                  for i, k in enumerate(('forward', 'dgrad', 'wgrad'))) / all_t, 4)}
@@ -203,16 +217,21 @@ def hbm_roofline(torch, HF, flat, B, H, W, reps=10):
         rows.append({'kernel': name, 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
                      'algorithmic_bytes': int(nbytes), 'avg_launch_ms': round(ms, 4), 'launches_per_step': calls})
 
-    logits = torch.randn((B, 19, Ho, Wo), device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    from dualsuperreslearningforsemseg_amd import _lib
+    logits = torch.randn((B, 19, Ho, Wo), device=dev).contiguous(memory_format=torch.channels_last)
     tgt = torch.randint(0, 19, (B, Ho, Wo), device=dev, dtype=torch.uint8)
-    loss = HF.cross_entropy(logits, tgt, 255)
-    add('ce_fwd (CrossEntropy forward, 19 logits/pixel)', P * 19 * 4 + P, _time_ms(lambda: HF.cross_entropy(logits.detach(), tgt, 255), reps, torch))
-    add('ce_bwd (CrossEntropy backward)', 2 * P * 19 * 4 + P, _time_ms(lambda: torch.autograd.grad(loss, logits, retain_graph=True), reps, torch))
-    a = torch.randn((B, 3, Ho, Wo), device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    dl, out2, flag = torch.empty_like(logits), torch.empty(2, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = HF._ws(HF.cquery('dsrl_ce_fused_workspace_bytes', P), logits)
+    st = HF._stream()
+    add('ce_fused (CrossEntropy forward + d/dlogits + NaN check in one pass; with its count / finalize launches)', 2 * P * 19 * 4 + 2 * P,
+        _time_ms(lambda: _lib.call('dsrl_ce_fused', logits.data_ptr(), 19, tgt.data_ptr(), P, 19, 255, dl.data_ptr(), 19, out2.data_ptr(), flag.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), st), reps, torch))
+    a = torch.randn((B, 3, Ho, Wo), device=dev).contiguous(memory_format=torch.channels_last)
     b = torch.randn((B, 3, Ho, Wo), device=dev).contiguous(memory_format=torch.channels_last)
-    ml = HF.mse_loss(a, b)
-    add('mse_fwd', 2 * P * 3 * 4, _time_ms(lambda: HF.mse_loss(a.detach(), b), reps, torch))
-    add('mse_bwd', 3 * P * 3 * 4, _time_ms(lambda: torch.autograd.grad(ml, a, retain_graph=True), reps, torch))
+    da = torch.empty_like(a)
+    ws2 = HF._ws(HF.cquery('dsrl_mse_workspace_bytes', a.numel()), a)
+    add('mse_fused (MSE forward + gradient + NaN check in one pass)', 3 * P * 3 * 4,
+        _time_ms(lambda: _lib.call('dsrl_mse_fused', a.data_ptr(), b.data_ptr(), a.numel(), 0.1, da.data_ptr(), out2.data_ptr(), flag.data_ptr(), ws2.data_ptr(), ws2.numel(), st), reps, torch))
     x = torch.randn((B, 19, H, W), device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     wt = torch.randn((19, 19, 2, 2), device=dev).requires_grad_(True)
     bias = torch.zeros(19, device=dev, requires_grad=True)

@@ -9,7 +9,7 @@ import csv, glob, json, re, sys, collections
 
 
 def family(name):
-    m = re.search(r'conv_igemm_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)(?:, \d+)?>', name)
+    m = re.search(r'conv_igemm_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)(?:, \d+)?(?:, (?:true|false))?>', name)
     if m:
         return f"conv_igemm_split_kernel<{'bf16x3' if m.group(6) == '2' else 'bf16x6'}> ({'dgrad' if m.group(5) == 'true' else 'forward'})"
     m = re.search(r'conv_wgrad_split_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, \d+)?>', name)
