@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (imported first so the HIP runtime the allocator uses is the one the library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, os.environ.get('DSRL_LIB_FILE', 'libdsrl_hip.so'))         # DSRL_LIB_FILE: timing-experiment builds (tools/)
+LIB_PATH = os.path.join(_HERE, 'libdsrl_hip.so')
 
 fp = C.c_void_p          # device pointers travel as integers
 i32 = C.c_int
@@ -50,10 +50,6 @@ PROTOTYPES = {
     'dsrl_conv2d_wgrad_group_workspace_bytes': (sz, [fp, i32]),
     'dsrl_conv2d_wgrad_group_plan': (i32, [fp, i32, fp, sz, fp, fp, sz]),
     'dsrl_conv2d_wgrad_group_launch': (i32, [fp, fp, stream_t]),
-    'dsrl_conv2d_presplit_bytes': (sz, [i64, i32, i32, i32]),
-    'dsrl_conv2d_presplit_filters': (i32, [fp, i32, i64, i32, stream_t]),
-    'dsrl_conv2d_presplit_register': (i32, [fp, fp, i32, i32]),
-    'dsrl_conv2d_presplit_clear': (i32, []),
     'dsrl_conv_precision': (i32, [i32]),
     'dsrl_conv2d_inbounds_macs': (i64, _conv_shape),
     'dsrl_conv2d_rowfold_fwd_workspace_bytes': (sz, [i32] * 9),

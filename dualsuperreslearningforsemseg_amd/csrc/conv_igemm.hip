@@ -14,7 +14,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
-#include <unordered_map>
 #include <vector>
 
 namespace dsrl {
@@ -51,9 +50,6 @@ struct ConvArgs {
     // partial sums of g = dy * [y > 0] and g * xhat per (row block, channel) in bstats [2][parts][K] (null: off)
     const float* bn_x; const float* bn_y; const float* bn_mean; const float* bn_invstd; float* bstats;
     int bn_ldx, bn_ldy, bn_relu;
-    // split kernels: the filter operand pre-split into bf16 planes (dsrl_conv2d_presplit_filters: [row][tap][32-channel chunk][plane][32]
-    // bf16, channel tail zero-padded), or null: the kernel then splits the fp32 filter values itself
-    const void* wp; unsigned wp_bytes;
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (private L2 each). Remap the linear block id so that every XCD works on a contiguous
@@ -65,11 +61,6 @@ __device__ inline int xcd_contiguous(int bid, int n) {
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 constexpr unsigned kOOB = 0x80000000u;      // any offset >= 2^31 is outside every descriptor: loads return 0, stores are dropped
-using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
-__device__ inline uint2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
-    return make_uint2(v.x, v.y);
-}
 __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
@@ -316,10 +307,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
 //   * KG > 1 ("K groups", for grids of at most ~1.5 tiles per CU): the block has KG groups of 4 waves, group g runs the same pipeline
 //     on chunks g, g+KG, ... with its own two LDS stages, and the KG accumulator sets are summed through LDS in a fixed order at the
 //     end - the latency-hiding of split-K (more waves per SIMD) without slab traffic or a reduce launch.
-//   * PREB: the filter operand arrives pre-split (ConvArgs::wp, one batched dsrl_split_planes per training step): its rows are fetched as
-//     NPL 8-byte bf16 groups and go to LDS as they are - the block does no conversion arithmetic for them (every row block of a
-//     layer used to repeat the split of the same filter values: M / BM times).
-template <int MR, int NR, int WGM, int WGN, bool DGRAD, int NPL, int KG = 1, bool PREB = false>
+template <int MR, int NR, int WGM, int WGN, bool DGRAD, int NPL, int KG = 1>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_kernel(const ConvArgs a) {
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
     constexpr int A_IT = (BM + 63) / 64, B_IT = (BN + 63) / 64;      // 64 rows per staging pass (4 lanes per row)
@@ -356,15 +344,12 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
     }
     const int RS = a.R * a.S;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = PREB ? __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)a.wp_bytes, 0x00020000)
-                                           : __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
-    constexpr unsigned CHB = 64u * NPL;                  // PREB: bytes of one (row, tap, 32-channel chunk): NPL planes of 32 bf16
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
     unsigned b_off[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int k = n0 + r0 + 64 * i;
-        if (PREB) b_off[i] = (k < a.K && b_rows) ? (unsigned)k * (unsigned)(RS * a.cchunks) * CHB : kOOB;
-        else b_off[i] = (k < a.K && b_rows) ? (unsigned)k * (unsigned)(RS * a.C) * 4u : kOOB;
+        b_off[i] = (k < a.K && b_rows) ? (unsigned)k * (unsigned)(RS * a.C) * 4u : kOOB;
     }
 
     // ---- taps that touch at least one in-bounds input pixel for this tile (block-uniform)
@@ -434,53 +419,32 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
     };
     // register sets: R[v][half], v < A_IT: pixel rows, v >= A_IT: filter rows
     float4 R0[NV][2], R1[NV][2];
-    constexpr int PB = PREB ? B_IT : 1;
-    // PREB: the pre-split filter rows instead of R[A_IT + i]: per plane ONE 16-byte piece per lane and chunk - lane c4 of a row holds
-    // channels 8*c4 .. 8*c4+7 of the chunk, i.e. 16-byte half (c4 & 1) of the row of half-step (c4 >> 1)
-    float4 P0[PB][NPL], P1[PB][NPL];
 #pragma unroll
     for (int v = 0; v < NV; ++v) { R0[v][0] = R0[v][1] = R1[v][0] = R1[v][1] = make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-    for (int i = 0; i < PB; ++i)
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) P0[i][pl] = P1[i][pl] = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto gload = [&](float4 (*R)[2], float4 (*Pq)[NPL], int t, int ch) {
+    auto gload = [&](float4 (*R)[2], int t, int ch) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int c = ch * 32 + hf * 16 + c4 * 4;
             const unsigned coff = c < a.C ? (unsigned)c * 4u : kOOB;          // channel tail of the last chunk reads as zeros
+            const unsigned woff = coff + (unsigned)(t * a.C) * 4u;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) R[i][hf] = buf_load4(xr, a_off[i] + coff);
-            if constexpr (!PREB) {
-                const unsigned woff = coff + (unsigned)(t * a.C) * 4u;
 #pragma unroll
-                for (int i = 0; i < B_IT; ++i) R[A_IT + i][hf] = buf_load4(wr, b_off[i] + woff);
-            }
-        }
-        if constexpr (PREB) {
-            const unsigned woff = (unsigned)(t * a.cchunks + ch) * CHB + (unsigned)c4 * 16u;       // the planes' channel tail is zero-padded
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i)
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) Pq[i][pl] = buf_load4(wr, b_off[i] + woff + 64u * pl);
+            for (int i = 0; i < B_IT; ++i) R[A_IT + i][hf] = buf_load4(wr, b_off[i] + woff);
         }
     };
     int nextq = q0 + grp, tap_set = -1;         // next chunk of this group; tap whose a_off[] is current
-    auto issue = [&](float4 (*R)[2], float4 (*Pq)[NPL]) {
+    auto issue = [&](float4 (*R)[2]) {
         if (nextq >= q1) {
             if (KG > 1) {                           // an exhausted group keeps iterating with the others: feed it zeros
 #pragma unroll
                 for (int v = 0; v < NV; ++v) R[v][0] = R[v][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int i = 0; i < PB; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) Pq[i][pl] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             return;
         }
         advance(nextq - pos);
         if (tap != tap_set) { set_tap(tap); tap_set = tap; }
-        gload(R, Pq, tap, cc);
+        gload(R, tap, cc);
         nextq += KG;
     };
 
@@ -489,16 +453,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
     const int frag_row = lane & 31;
     const int r_swz = ((lane >> 5) ^ ((frag_row >> 3) & 1)) << 4;
     float res[4] = {0.f, 0.f, 0.f, 0.f};
-    const int p_swz = ((c4 & 1) ^ ((r0 >> 3) & 1)) << 4;           // PREB: my 16-byte piece's place in its (swizzled) 32-byte row
-    auto cstep = [&](char* nb, float4 (*R)[2], float4 (*Pq)[NPL], int hf, int c) {        // plane c % NPL of staged value c / NPL
+    auto cstep = [&](char* nb, float4 (*R)[2], int hf, int c) {        // plane c % NPL of staged value c / NPL
         const int v = c / NPL, pl = c % NPL;
-        if constexpr (PREB) {
-            if (v >= A_IT) {                        // pre-split filter row: the lanes that hold this half-step's pieces store them as fetched
-                if (b_rows && (c4 >> 1) == hf)
-                    *reinterpret_cast<float4*>(nb + (NPL * BM + pl * BN + r0 + 64 * (v - A_IT)) * ROWB + p_swz) = Pq[v - A_IT][pl];
-                return;
-            }
-        }
         if (pl == 0) { const float4 x = R[v][hf]; res[0] = x.x; res[1] = x.y; res[2] = x.z; res[3] = x.w; }
         const bf16x4 t = {(__bf16)res[0], (__bf16)res[1], (__bf16)res[2], (__bf16)res[3]};
         if (v < A_IT) {
@@ -513,7 +469,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
     };
     constexpr int NMFMA = MR * NR * (NPL * (NPL + 1) / 2), CSTEPS = NV * NPL;
     constexpr int MPS = NMFMA / CSTEPS > 0 ? NMFMA / CSTEPS : 1;
-    auto pipe = [&](const char* cur, char* nxt, float4 (*R)[2], float4 (*Pq)[NPL], int hf) {
+    auto pipe = [&](const char* cur, char* nxt, float4 (*R)[2], int hf) {
         // every fragment read first (the compiler cannot prove the two stages disjoint: a read placed after a write would wait)
         bf16x8 fa[MR][NPL], fb[NR][NPL];
 #pragma unroll
@@ -538,33 +494,33 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa], fb[j][sum - pa], acc[i][j], 0, 0, 0);
-                        if (m % MPS == 0 && m / MPS < CSTEPS) cstep(nxt, R, Pq, hf, m / MPS);
+                        if (m % MPS == 0 && m / MPS < CSTEPS) cstep(nxt, R, hf, m / MPS);
                         __builtin_amdgcn_sched_barrier(0);
                         ++m;
                     }
 #pragma unroll
-        for (int c = (NMFMA + MPS - 1) / MPS; c < CSTEPS; ++c) cstep(nxt, R, Pq, hf, c);
+        for (int c = (NMFMA + MPS - 1) / MPS; c < CSTEPS; ++c) cstep(nxt, R, hf, c);
     };
 
     const int nloc = (q1 - q0 + KG - 1) / KG;   // pipeline iterations: the same for every group (barriers are block-wide)
     if (q0 < q1) {
-        issue(R0, P0);
-        issue(R1, P1);
+        issue(R0);
+        issue(R1);
 #pragma unroll
-        for (int c = 0; c < CSTEPS; ++c) cstep(S0, R0, P0, 0, c);
+        for (int c = 0; c < CSTEPS; ++c) cstep(S0, R0, 0, c);
         __syncthreads();
     }
     for (int q = 0; q < nloc; q += 2) {
-        pipe(S0, S1, R0, P0, 1);        // MFMAs of local chunk q / half 0, convert chunk q / half 1
-        issue(R0, P0);                  // local chunk q+2
+        pipe(S0, S1, R0, 1);            // MFMAs of local chunk q / half 0, convert chunk q / half 1
+        issue(R0);                      // local chunk q+2
         __syncthreads();
-        pipe(S1, S0, R1, P1, 0);        // MFMAs of chunk q / half 1, convert chunk q+1 / half 0 (past the end: stale for KG = 1 and unused, zeros for KG > 1)
+        pipe(S1, S0, R1, 0);            // MFMAs of chunk q / half 1, convert chunk q+1 / half 0 (past the end: stale for KG = 1 and unused, zeros for KG > 1)
         __syncthreads();
         if (q + 1 < nloc) {
-            pipe(S0, S1, R1, P1, 1);
-            issue(R1, P1);              // local chunk q+3
+            pipe(S0, S1, R1, 1);
+            issue(R1);                  // local chunk q+3
             __syncthreads();
-            pipe(S1, S0, R0, P0, 0);
+            pipe(S1, S0, R0, 0);
             __syncthreads();
         }
     }
@@ -1278,62 +1234,6 @@ static int valid_count(int n_in, int n_out, int stride, int pad, int off) {
     return c;
 }
 
-// ---- pre-split filter operands
-// One launch for every filter of the model (table row = {src, dst, rows, taps, channels, first work item}, bisection like the batched
-// transpose): the fp32 filter [row][tap][C] becomes bf16 planes [row][tap][ceil(C/32)][NPL][32] (channel tail zero-padded): plane 0 =
-// bf16(x), plane 1 = bf16(x - t0), plane 2 = bf16(x - t0 - t1) - exactly the terms the split kernels form on the fly (cstep), so a
-// launch computes the same products either way.  A work item = 8 channels of one (row, tap): two float4 in, NPL x 16 bytes out.
-template <int NPL>
-__global__ __launch_bounds__(256) void presplit_batched_kernel(const long long* __restrict__ table, int n, long long total) {
-    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
-        int lo = 0, hi = n - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (table[6 * mid + 5] <= it) lo = mid; else hi = mid - 1;
-        }
-        const long long* e = table + 6 * lo;
-        const float* __restrict__ src = reinterpret_cast<const float*>(e[0]);
-        char* __restrict__ dst = reinterpret_cast<char*>(e[1]);
-        const int RS = (int)e[3], C = (int)e[4];
-        const int cch = (C + 31) >> 5;
-        long long q = it - e[5];
-        const int piece = (int)(q & 3); q >>= 2;
-        const int ch = (int)(q % cch); q /= cch;
-        const int tap = (int)(q % RS);
-        const long long row = q / RS;
-        const int c = ch * 32 + piece * 8;
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const float4 x = (c + 4 * u < C) ? *reinterpret_cast<const float4*>(src + (row * RS + tap) * C + c + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
-            v[4 * u] = x.x; v[4 * u + 1] = x.y; v[4 * u + 2] = x.z; v[4 * u + 3] = x.w;
-        }
-        char* out = dst + ((row * RS + tap) * cch + ch) * (64ll * NPL) + piece * 16;
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            bf16x8 t;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = (__bf16)v[u];
-            *reinterpret_cast<bf16x8*>(out + 64 * pl) = t;
-            if (pl + 1 < NPL) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] -= (float)t[u];
-            }
-        }
-    }
-}
-// fp32 filter tensor -> its current planes, registered by the caller between "planes refreshed" and "weights updated"
-struct PresplitEntry { const void* planes; int npl; };
-static std::mutex g_presplit_mu;
-static std::unordered_map<const void*, PresplitEntry> g_presplit;
-static const void* presplit_lookup(const void* w, int npl) {
-    if (!npl) return nullptr;
-    std::lock_guard<std::mutex> g(g_presplit_mu);
-    if (g_presplit.empty()) return nullptr;
-    const auto it = g_presplit.find(w);
-    return (it != g_presplit.end() && it->second.npl == npl) ? it->second.planes : nullptr;
-}
-
 // ---- launch timing (opt-in)
 struct ProfRec { hipEvent_t a, b; int family; double flops, bytes; };
 static std::mutex g_prof_mu;
@@ -1463,14 +1363,13 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
             // accumulator sets of the final reduction, whichever is larger (up to 96 KiB: opt-in attribute, set once per instantiation)
             grid = dim3((unsigned)(a.mtiles * a.ntiles), 1u, 1u);
             const size_t lds = std::max(stages * kg, (size_t)(kg - 1) * (bm / 32) * (bn / 32) / 4 * 16384);
-#define DSRL_LAUNCH_KG1(a_, b_, c_, d_, NPL_, KG_, PRE_)                                                                                   \
-            {                                                                                                                               \
-                static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_, PRE_>, \
-                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);                 \
-                (void)attr;                                                                                                                 \
-                hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_, PRE_>), grid, dim3(256 * KG_), lds, st, a);     \
+#define DSRL_LAUNCH_KG(a_, b_, c_, d_, NPL_, KG_)                                                                                     \
+            {                                                                                                                          \
+                static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_>, \
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);            \
+                (void)attr;                                                                                                            \
+                hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_>), grid, dim3(256 * KG_), lds, st, a);      \
             }
-#define DSRL_LAUNCH_KG(a_, b_, c_, d_, NPL_, KG_) { if (a.wp) DSRL_LAUNCH_KG1(a_, b_, c_, d_, NPL_, KG_, true) else DSRL_LAUNCH_KG1(a_, b_, c_, d_, NPL_, KG_, false) }
             if (cfg == T64x64) {
                 if (kg == 4) { if (npl == 2) DSRL_LAUNCH_KG(1, 1, 2, 2, 2, 4) else DSRL_LAUNCH_KG(1, 1, 2, 2, 3, 4) }
                 else { if (npl == 2) DSRL_LAUNCH_KG(1, 1, 2, 2, 2, 2) else DSRL_LAUNCH_KG(1, 1, 2, 2, 3, 2) }
@@ -1480,21 +1379,16 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
                 if (npl == 2) DSRL_LAUNCH_KG(1, 2, 2, 2, 2, 2) else DSRL_LAUNCH_KG(1, 2, 2, 2, 3, 2)
             }
 #undef DSRL_LAUNCH_KG
-#undef DSRL_LAUNCH_KG1
             return launch_status("conv_igemm_split_kernel<K groups>");
         }
         const size_t lds2 = stages;
-#define DSRL_LAUNCH_SPLIT(a_, b_, c_, d_)                                                                                                 \
-        if (a.wp) {                                                                                                                       \
-            if (npl == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, true>), grid, dim3(256), lds2, st, a); \
-            else hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 3, 1, true>), grid, dim3(256), lds2, st, a);          \
-        } else if (npl == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2>), grid, dim3(256), lds2, st, a);       \
+#define DSRL_LAUNCH_SPLIT(a_, b_, c_, d_)                                                                                    \
+        if (npl == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2>), grid, dim3(256), lds2, st, a); \
         else hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 3>), grid, dim3(256), lds2, st, a);
         DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_SPLIT)
 #undef DSRL_LAUNCH_SPLIT
         return launch_status(npl == 2 ? "conv_igemm_split_kernel<bf16x3>" : "conv_igemm_split_kernel<bf16x6>");
     }
-    a.wp = nullptr;
     const size_t lds1 = (size_t)(bm + bn) * LDS_LD * sizeof(float);
     const bool dbuf = env_int("DSRL_IGEMM_DBUF", 0) != 0;     // measured: no gain from the two-stage LDS variant; kept selectable
 #define DSRL_LAUNCH_IGEMM(a_, b_, c_, d_) hipLaunchKernelGGL((conv_igemm_f32_kernel<a_, b_, c_, d_, DGRAD>), grid, dim3(256), lds1, st, a)
@@ -1636,12 +1530,6 @@ static int fwd_impl(const float* x, int ldx, const float* w, const float* bias, 
     const long long xb = span_bytes((long long)N * H * W, ldx, C), wb = (long long)K * R * S * C * 4, yb = p.splits > 1 ? (long long)p.M * K * 4 : span_bytes(p.M, ldy, K);
     DSRL_REQUIRE_31(xb, "conv2d_fwd(x)"); DSRL_REQUIRE_31(wb, "conv2d_fwd(w)"); DSRL_REQUIRE_31(yb, "conv2d_fwd(y)");
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
-    {
-        const int npl = conv_planes(PASS_FWD);
-        const long long pb = (long long)K * R * S * p.cchunks * 64 * npl;          // [K][RS][chunks][npl][32] bf16
-        a.wp = pb < (1ll << 31) ? presplit_lookup(w, npl) : nullptr;
-        a.wp_bytes = (unsigned)pb;
-    }
     ProfScope prof(prof_family(PASS_FWD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
     if (p.splits > 1) {
         a.y = (float*)ws; a.ldy = K; a.bias = nullptr;
@@ -1732,10 +1620,6 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
         const long long xb = span_bytes((long long)N * Ho * Wo, lddy, Kp), wb = (long long)C * R * S * Kp * 4, yb = p.splits > 1 ? (long long)p.M * C * 4 : span_bytes(p.M, lddx, C);
         DSRL_REQUIRE_31(xb, "conv2d_dgrad(dy)"); DSRL_REQUIRE_31(wb, "conv2d_dgrad(w)"); DSRL_REQUIRE_31(yb, "conv2d_dgrad(dx)");
         a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
-        const int npl = conv_planes(PASS_DGRAD);
-        const long long pb = (long long)C * R * S * p.cchunks * 64 * npl;          // planes of the transposed filter [C][RS][chunks of Kp][npl][32]
-        a.wp = (wt_in && pb < (1ll << 31)) ? presplit_lookup(wt_in, npl) : nullptr;
-        a.wp_bytes = (unsigned)pb;
     }
     ProfScope prof(prof_family(PASS_DGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
     if (p.splits > 1) {
@@ -2167,33 +2051,6 @@ extern "C" int dsrl_conv2d_rowfold_wgrad(const float* x, int ldx, const float* d
                            (const float*)ws, p.psplits, a.slab, dw, K, R, Cfold, p.tl);
         return launch_status("wgrad_reduce_kernel");
     }
-    return DSRL_OK;
-}
-
-extern "C" size_t dsrl_conv2d_presplit_bytes(int64_t rows, int taps, int channels, int npl) {
-    return (rows > 0 && taps > 0 && channels > 0 && (npl == 2 || npl == 3)) ? (size_t)rows * taps * ((channels + 31) / 32) * 64 * npl : 0;
-}
-extern "C" int dsrl_conv2d_presplit_filters(const int64_t* table, int n, int64_t total_items, int npl, dsrl_stream_t stream) {
-    DSRL_REQUIRE(table && n > 0 && total_items > 0 && (npl == 2 || npl == 3), DSRL_E_BADARG, "conv2d_presplit_filters: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    if (int e = bind_stream_device(st)) return e;
-    const dim3 grid((unsigned)std::min<long long>(ceil_div(total_items, 256), 16384));
-    if (npl == 2) hipLaunchKernelGGL(presplit_batched_kernel<2>, grid, dim3(256), 0, st, (const long long*)table, n, (long long)total_items);
-    else hipLaunchKernelGGL(presplit_batched_kernel<3>, grid, dim3(256), 0, st, (const long long*)table, n, (long long)total_items);
-    return launch_status("presplit_batched_kernel");
-}
-extern "C" int dsrl_conv2d_presplit_register(const float* const* w, const void* const* planes, int n, int npl) {
-    DSRL_REQUIRE(w && planes && n > 0 && (npl == 2 || npl == 3), DSRL_E_BADARG, "conv2d_presplit_register: bad arguments");
-    std::lock_guard<std::mutex> g(g_presplit_mu);
-    for (int i = 0; i < n; ++i) {
-        DSRL_REQUIRE(w[i] && planes[i] && ((uintptr_t)planes[i] % 8) == 0, DSRL_E_BADARG, "conv2d_presplit_register: null or misaligned pointer in entry %d", i);
-        g_presplit[(const void*)w[i]] = PresplitEntry{planes[i], npl};
-    }
-    return DSRL_OK;
-}
-extern "C" int dsrl_conv2d_presplit_clear(void) {
-    std::lock_guard<std::mutex> g(g_presplit_mu);
-    g_presplit.clear();
     return DSRL_OK;
 }
 

@@ -178,64 +178,6 @@ class FlatParams:
         if self._wt_table is not None and os.environ.get('DSRL_BATCHED_TRANSPOSE', '1') != '0':
             HF.call('dsrl_conv2d_transpose_filters_batched', self._wt_table.data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
             self.wt_valid = True
-            self._refresh_presplit_filters()
-
-    # ------------------------------------------------------------------ pre-split filter operands of the split-precision conv kernels
-    _NPL = {'fp32': (0, 0), 'bf16x3': (2, 2), 'bf16x6': (3, 3), 'mixed': (3, 2)}          # bf16 planes per operand: forward, dgrad
-
-    def _refresh_presplit_filters(self):
-        """The forward / dgrad kernels would split every filter value into bf16 planes once per row block of a layer; here every filter
-        and every transposed filter of the model is split ONCE per step (two batched launches) and registered with the library
-        (include/dsrl_hip.h: dsrl_conv2d_presplit_filters, dsrl_conv2d_presplit_register).  The planes are valid until the SGD update
-        changes the weights (sgd_step clears the registry); results are bit-identical to the in-kernel split."""
-        # MEASURED SLOWER, hence opt-in (DSRL_PRESPLIT=1): forward 5.58 -> 5.72 ms and dgrad 6.17 -> 6.23 ms per step plus 0.24 ms for the two
-        # split launches (profiles/round2_summary.md).  The conversions it removes were not what bounds the kernels, the 1.5x larger filter
-        # fetch (6 bytes per value instead of 4) costs as much as they did.  (A timing experiment that skipped the conversions on garbage
-        # data had promised -1.6 ms: NaN operands draw less power, the chip clocked higher - bench on real data.)
-        if os.environ.get('DSRL_PRESPLIT', '0') == '0':
-            return
-        import ctypes
-        npl_f, npl_d = self._NPL[HF.get_conv_precision()]
-        if not npl_f:
-            return
-        st = HF._stream()
-        key = (npl_f, npl_d)
-        if getattr(self, '_ps_key', None) != key:
-            self._ps_key = key
-            lib = HF._lib.load()
-            rows_f, rows_d, fw, dw = [], [], [], []
-            bytes_f = bytes_d = items_f = items_d = 0
-            for p in self.params:
-                wt = getattr(p, '_dsrl_wt', None)
-                if wt is None:
-                    continue            # not a conv filter the implicit-GEMM kernels read
-                K, C, R, S = p.shape
-                Kp = (K + 3) & ~3
-                rows_f.append([p.data_ptr(), bytes_f, K, R * S, C, items_f])
-                bytes_f += int(lib.dsrl_conv2d_presplit_bytes(K, R * S, C, npl_f)); items_f += K * R * S * ((C + 31) // 32) * 4
-                rows_d.append([wt.data_ptr(), bytes_d, C, R * S, Kp, items_d])
-                bytes_d += int(lib.dsrl_conv2d_presplit_bytes(C, R * S, Kp, npl_d)); items_d += C * R * S * ((Kp + 31) // 32) * 4
-                fw.append(p.data_ptr()); dw.append(wt.data_ptr())
-            self.pp_flat = torch.empty(bytes_f, device=self.device, dtype=torch.uint8)
-            self.wtp_flat = torch.empty(bytes_d, device=self.device, dtype=torch.uint8)
-            for r in rows_f:
-                r[1] += self.pp_flat.data_ptr()
-            for r in rows_d:
-                r[1] += self.wtp_flat.data_ptr()
-            arr = lambda v: (ctypes.c_void_p * len(v))(*v)
-            self._ps_tables = (torch.tensor(rows_f, dtype=torch.int64, device=self.device), items_f, torch.tensor(rows_d, dtype=torch.int64, device=self.device), items_d,
-                               arr(fw), arr([r[1] for r in rows_f]), arr(dw), arr([r[1] for r in rows_d]), len(fw))
-        tf, items_f, td, items_d, fw, fp_, dw, dp, n = self._ps_tables
-        HF.call('dsrl_conv2d_presplit_filters', tf.data_ptr(), n, items_f, npl_f, st)
-        HF.call('dsrl_conv2d_presplit_filters', td.data_ptr(), n, items_d, npl_d, st)
-        HF.call('dsrl_conv2d_presplit_register', fw, fp_, n, npl_f)
-        HF.call('dsrl_conv2d_presplit_register', dw, dp, n, npl_d)
-        self._ps_registered = True
-
-    def _drop_presplit_filters(self):
-        if getattr(self, '_ps_registered', False):
-            HF.call('dsrl_conv2d_presplit_clear')
-            self._ps_registered = False
 
     def zero_grad(self):
         self.g_flat.zero_()
@@ -287,7 +229,6 @@ class FlatParams:
         else:
             HF.sgd_step_(self.p_flat, self.g_flat, self.m_flat, lr, momentum, weight_decay, 1.0 / self.world)
         self.wt_valid = False               # the filters changed: the transposed copies are stale until the next refresh
-        self._drop_presplit_filters()       # ... and so are their bf16 planes
 
     def _trainable_in_model_order(self):
         return [p for p in self.model.parameters() if p.requires_grad]

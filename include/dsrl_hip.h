@@ -15,7 +15,7 @@
  *   - Every function enqueues on `stream` (a hipStream_t) and returns immediately; no allocation, no host
  *     synchronisation (the two read-out functions dsrl_prof_read and dsrl_bn_fused_barrier_timeouts excepted); re-entrant from
  *     the autograd worker thread. Process-wide state is limited to four settings (dsrl_conv_precision, dsrl_bn_fused_max_blocks,
- *     dsrl_prof_enable, dsrl_rng_bind_device_key), the pre-split filter registry (dsrl_conv2d_presplit_*) and the self-resetting arrival counter of the fused BatchNorm kernels'
+ *     dsrl_prof_enable, dsrl_rng_bind_device_key) and the self-resetting arrival counter of the fused BatchNorm kernels'
  *     device-wide barrier. The fused BatchNorm launches of one device share that counter, so they must not overlap each other: the
  *     first one pins its stream, launches on any other stream (outside graph capture) take the three-kernel path.
  *   - The caller owns all buffers including `ws` (workspace, >= the matching *_workspace_bytes()).
@@ -96,22 +96,6 @@ size_t dsrl_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int 
 int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                       void* ws, size_t ws_bytes, dsrl_stream_t stream);
-/* Pre-split filter operands. The split-precision forward / dgrad kernels form bf16 planes of BOTH operands on the fly; every row block
- * of a layer repeats that arithmetic for the same filter values. dsrl_conv2d_presplit_filters does it once for every filter of a model
- * in one launch: `table` (device, n rows of six int64) = {src fp32 filter [rows][taps][channels] (channels % 4 == 0, 16-byte aligned),
- * dst planes, rows, taps, channels, first work item}, where a filter has rows * taps * ceil(channels / 32) * 4 work items and
- * total_items is their sum; dst = bf16 [rows][taps][ceil(channels/32)][npl][32] (dsrl_conv2d_presplit_bytes; npl = 2 for bf16x3, 3 for
- * bf16x6; channel tail zero-padded; the same terms the kernels compute, so results are bit-identical).
- * dsrl_conv2d_presplit_register tells the library that planes[i] holds the CURRENT planes of the fp32 filter tensor w[i] (the `w` argument
- * of dsrl_conv2d_fwd*: rows = K, channels = C; or the transposed filter `wt_in` of dsrl_conv2d_dgrad*: rows = C, channels = K rounded up
- * to 4): such launches then fetch the planes instead of converting. The caller re-splits after every update of the weights and calls
- * dsrl_conv2d_presplit_clear() when the planes go stale (ddp.FlatParams: one launch per arena per step, clear in the SGD update).
- * Process-wide state, guarded by a mutex. */
-size_t dsrl_conv2d_presplit_bytes(int64_t rows, int taps, int channels, int npl);
-int dsrl_conv2d_presplit_filters(const int64_t* table, int n, int64_t total_items, int npl, dsrl_stream_t stream);
-int dsrl_conv2d_presplit_register(const float* const* w, const void* const* planes, int n, int npl);
-int dsrl_conv2d_presplit_clear(void);
-
 /* Grouped weight gradients: every dsrl_conv2d_wgrad of a backward pass as a few grids (one per tile configuration, blocks ordered
  * longest first) plus one slab reduce, instead of one launch + reduce per layer. The weight gradients of a pass depend on nothing
  * but (x, dy) of their layer and are read by the optimiser only, so the caller may collect the problems while backward runs and

@@ -51,5 +51,4 @@ def _unbind_device_rng():
     if _has_gpu():
         from dualsuperreslearningforsemseg_amd import _lib, functional as HF
         _lib.call('dsrl_rng_bind_device_key', None)
-        _lib.call('dsrl_conv2d_presplit_clear')
         HF.wgrad_queue = None

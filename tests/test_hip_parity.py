@@ -751,35 +751,6 @@ def test_gradient_sink_matches_autograd_accumulation():
             assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
 
 
-@pytest.mark.parametrize('mode', ['bf16x6', 'mixed'])
-def test_presplit_filters_bit_identical(monkeypatch, mode):
-    """DSRL_PRESPLIT=1 (filters split into bf16 planes once per step: dsrl_conv2d_presplit_filters + registry, the PREB kernel variants)
-    computes the very same products as the in-kernel split: bit-identical outputs and gradients, and the registry is emptied by the
-    SGD update."""
-    from dualsuperreslearningforsemseg_amd.ddp import FlatParams
-    HF.set_conv_precision(mode)
-    x16, x4, target, org = gen.make_head_inputs(202, 2, 2, 4, gen.SMALL)
-    res = []
-    for on in ('0', '1'):
-        monkeypatch.setenv('DSRL_PRESPLIT', on)
-        head, _ = make_head(gen.SMALL, 3, 101, True)
-        flat = FlatParams(head)
-        flat.zero_grad()
-        flat.refresh_transposed_filters()
-        assert getattr(flat, '_ps_registered', False) == (on == '1')
-        a = dev(x16).requires_grad_(True); b = dev(x4).requires_grad_(True)
-        outs = head(a, b)
-        hip_losses(outs, dev(target), dev(org), 3)[3].backward()
-        flat.finish_reduction()
-        g = {k: host(p.grad) for k, p in head.named_parameters()}
-        g['x16'], g['x4'], g['SSSR'] = host(a.grad), host(b.grad), host(outs[0])
-        res.append(g)
-        flat.sgd_step(0.01, 0.9, 5e-4)
-        assert not getattr(flat, '_ps_registered', False)
-    bad = {k: float(np.abs(res[0][k] - res[1][k]).max()) for k in res[0] if not np.array_equal(res[0][k], res[1][k])}
-    assert not bad, bad
-
-
 def test_batched_filter_transposes_match_per_layer_path():
     """ddp.FlatParams.refresh_transposed_filters (one dsrl_conv2d_transpose_filters_batched launch for every conv filter of the
     model) feeds the dgrad kernels the same transposed filters as the per-call transpose: bit-identical gradients; the copies
