@@ -87,11 +87,28 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 // gradient of 1 (the loss is the root of the backward pass), checks the logits for NaN on the way (the reference's per-output NaN
 // asserts, train_or_resume.py:426-433) and stages 256 pixels x C logits through LDS with 16-byte accesses when the tensor is dense.
 // The mean's denominator (pixels that are not ignored) comes from a pre-pass over the uint8 target (4 MB at 8 x 512 x 1024).
-constexpr int kCountBlocks = 64;
+constexpr int kCountBlocks = 256;
 __global__ __launch_bounds__(256) void count_valid_kernel(const unsigned char* __restrict__ target, long long P, int ignore_index, unsigned* __restrict__ part) {
     __shared__ unsigned sh[4];
     unsigned n = 0;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < P; e += (long long)gridDim.x * 256) n += (target[e] != ignore_index) ? 1u : 0u;
+    // 16 labels per load; the head up to the first 16-byte boundary and the tail are counted byte by byte by block 0
+    const long long head = min(P, (long long)((16 - ((uintptr_t)target & 15)) & 15));
+    const long long nv = (P - head) >> 4;
+    const uint4* v = reinterpret_cast<const uint4*>(target + head);
+    const unsigned ig = (unsigned)ignore_index & 0xffu;
+    const bool can_match = ignore_index >= 0 && ignore_index <= 255;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nv; e += (long long)gridDim.x * 256) {
+        const uint4 q = v[e];
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) n += (!can_match || ((w[u] >> (8 * b)) & 0xffu) != ig) ? 1u : 0u;
+    }
+    if (blockIdx.x == 0) {
+        for (long long e = threadIdx.x; e < head; e += 256) n += (target[e] != ignore_index) ? 1u : 0u;
+        for (long long e = head + (nv << 4) + threadIdx.x; e < P; e += 256) n += (target[e] != ignore_index) ? 1u : 0u;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = n;
@@ -104,10 +121,10 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const float* __restrict__
     extern __shared__ __attribute__((aligned(16))) float tile[];         // [256][C]
     __shared__ double shd[4];
     __shared__ float sh_scale;
-    if (threadIdx.x == 0) {
-        unsigned long long n = 0;
-        for (int i = 0; i < kCountBlocks; ++i) n += cnt_part[i];
-        sh_scale = 1.f / (float)n;              // n = 0: every pixel ignored, the loss is 0/0 = NaN as in torch and no gradient element uses the scale
+    {
+        static_assert(kCountBlocks == 256, "one partial count per thread");
+        const double n = block_sum_d((double)cnt_part[threadIdx.x], shd);       // exact: counts < 2^53
+        if (threadIdx.x == 0) sh_scale = 1.f / (float)n;        // n = 0: every pixel ignored, the loss is 0/0 = NaN as in torch and no gradient element uses the scale
     }
     __syncthreads();
     const float scale = sh_scale;
@@ -246,14 +263,46 @@ struct FaSmem {
     float scal[4];
 };
 
+// k x k average pooling of one map into X (hp x wp).  The usual case (k = 8, unit column stride, 16-byte aligned rows) uses T = 1, 2, 4 or 8
+// consecutive lanes per cell - as many as 256 threads allow - each summing k / T rows with two independent 16-byte loads per row (all loads
+// of a thread are in flight together; the per-cell loop of 64 dependent scalar loads this replaces took ~30 us per map), the lane partials
+// combined by a fixed xor tree: deterministic.
 __device__ void fa_pool(const float* __restrict__ fm, long long sh_, long long sw_, int hp, int wp, int k, float* X) {
     const float inv = 1.f / (float)(k * k);
-    for (int cell = threadIdx.x; cell < hp * wp; cell += 256) {
-        const int i = cell / wp, j = cell - i * wp;
-        float s = 0.f;
-        for (int r = 0; r < k; ++r)
-            for (int q = 0; q < k; ++q) s += fm[(long long)(i * k + r) * sh_ + (long long)(j * k + q) * sw_];
-        X[cell] = s * inv;
+    const int ncells = hp * wp;
+    if (k == 8 && sw_ == 1 && (sh_ & 3) == 0 && ((uintptr_t)fm & 15) == 0) {
+        int T = 1;
+        while (T < 8 && ncells * (T * 2) <= 256) T *= 2;
+        const int sub = threadIdx.x & (T - 1), per = 256 / T;
+        for (int c0 = 0; c0 < ncells; c0 += per) {
+            const int cell = c0 + (int)(threadIdx.x / T);
+            float s = 0.f;
+            if (cell < ncells) {
+                const int i = cell / wp, j = cell - i * wp;
+                const float* base = fm + (long long)(i * 8) * sh_ + j * 8;
+                float4 v[8][2];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (r < 8 / T) {
+                        const float* row = base + (long long)(sub + r * T) * sh_;
+                        v[r][0] = *reinterpret_cast<const float4*>(row); v[r][1] = *reinterpret_cast<const float4*>(row + 4);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (r < 8 / T) s += ((v[r][0].x + v[r][0].y) + (v[r][0].z + v[r][0].w)) + ((v[r][1].x + v[r][1].y) + (v[r][1].z + v[r][1].w));
+            }
+            for (int o = 1; o < T; o <<= 1) s += __shfl_xor(s, o, 64);
+            if (cell < ncells && sub == 0) X[cell] = s * inv;
+        }
+    } else {
+        for (int cell = threadIdx.x; cell < ncells; cell += 256) {
+            const int i = cell / wp, j = cell - i * wp;
+            float s = 0.f;
+            for (int r = 0; r < k; ++r)
+                for (int q = 0; q < k; ++q) s += fm[(long long)(i * k + r) * sh_ + (long long)(j * k + q) * sw_];
+            X[cell] = s * inv;
+        }
     }
     __syncthreads();
 }
@@ -558,7 +607,7 @@ extern "C" int dsrl_mse_bwd(const float* a, const float* b, int64_t n, const flo
     return launch_status("mse_bwd_kernel");
 }
 
-extern "C" size_t dsrl_ce_fused_workspace_bytes(int64_t P) { return (size_t)2 * loss_blocks(P) * sizeof(double) + 256; }
+extern "C" size_t dsrl_ce_fused_workspace_bytes(int64_t P) { return (size_t)2 * loss_blocks(P) * sizeof(double) + kCountBlocks * sizeof(unsigned); }
 extern "C" int dsrl_ce_fused(const float* logits, int ld, const uint8_t* target, int64_t P, int C, int ignore_index, float* dlogits, int lddl,
                              float* loss_out, int* nan_flag, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
     DSRL_REQUIRE(logits && target && loss_out && ws && P > 0 && C > 0 && C <= 60 && ld >= C && (!dlogits || lddl >= C), DSRL_E_BADARG, "ce_fused: bad arguments (C=%d)", C);
