@@ -209,7 +209,11 @@ class FlatParams:
         forward + backward); the caller's stream waits for them.  Used when backward ran from a hipGraph, where no hook fires."""
         if self.world == 1:
             return
-        works = [dist.all_reduce(self.g_flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for a, b, _ in self.chunks]
+        # nothing overlaps with these collectives, so they are as large as possible (ring all-reduce bandwidth over xGMI grows with the message
+        # size): the whole 239.5 MB arena in pieces of DSRL_REDUCE_ALL_MB (default 256, i.e. one call)
+        per = max(1, int(os.environ.get('DSRL_REDUCE_ALL_MB', '256'))) << 18          # floats
+        works = [dist.all_reduce(self.g_flat[a:min(a + per, self.numel)], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                 for a in range(0, self.numel, per)]
         for w in works:
             w.wait()
 

@@ -1135,13 +1135,20 @@ def sgd_step_dev_(p, g, buf, hyper):
 class DeviceRng:
     """Device-resident twin of the host dropout key (begin_forward): three 64-bit words {key, step, base}.  While bound, every
     dropout-bearing kernel of the device reads `key` when it runs and advance() enqueues the per-step derivation, so that a step
-    captured in a hipGraph draws fresh masks on every replay (include/dsrl_hip.h: dsrl_rng_bind_device_key)."""
+    captured in a hipGraph draws fresh masks on every replay (include/dsrl_hip.h: dsrl_rng_bind_device_key).  The binding is one address
+    per device: advance() re-binds its own state if another DeviceRng took the device in between (a captured launch keeps the address it
+    was captured with)."""
+    _active = {}            # device index -> the DeviceRng whose state address is currently bound
 
     def __init__(self, device):
         self.state = torch.zeros(3, dtype=torch.int64, device=device)
         self.sync_from_host()
-        with torch.cuda.device(device):
+        self._bind()
+
+    def _bind(self):
+        with torch.cuda.device(self.state.device):
             call('dsrl_rng_bind_device_key', self.state.data_ptr())
+        DeviceRng._active[self.state.device.index] = self
 
     def sync_from_host(self):
         def s64(v):
@@ -1150,11 +1157,15 @@ class DeviceRng:
         self.state.copy_(torch.tensor([s64(_derive(_rng_state['step'])), s64(_rng_state['step']), s64(_rng_state['seed'])], dtype=torch.int64))
 
     def advance(self):
+        if DeviceRng._active.get(self.state.device.index) is not self:
+            self._bind()
         call('dsrl_rng_advance_key', self.state.data_ptr(), _stream())
 
     def release(self):
-        with torch.cuda.device(self.state.device):
-            call('dsrl_rng_bind_device_key', None)
+        if DeviceRng._active.get(self.state.device.index) is self:
+            with torch.cuda.device(self.state.device):
+                call('dsrl_rng_bind_device_key', None)
+            del DeviceRng._active[self.state.device.index]
 
 
 def nan_check_(flag, *tensors):

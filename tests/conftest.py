@@ -51,4 +51,5 @@ def _unbind_device_rng():
     if _has_gpu():
         from dualsuperreslearningforsemseg_amd import _lib, functional as HF
         _lib.call('dsrl_rng_bind_device_key', None)
+        HF.DeviceRng._active.clear()
         HF.wgrad_queue = None
