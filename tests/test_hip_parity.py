@@ -977,6 +977,60 @@ def test_full_model_total_loss_backward_with_fa_vs_oracle():
     assert rep['all gradients (L2)'] <= ARENA_GRAD_BOUND, rep
 
 
+def test_full_model_vs_stock_torch_fp64():
+    """The assembled network (ResNet-101 OS16 + head + CE / MSE / FA) against an INDEPENDENT implementation of the same graph: stock torch.nn
+    CPU modules in float64 (oracle/torch_cpu_model.py: the ATen arithmetic the reference's `--device cpu` path executes, itself pinned to the
+    reference's full-width head vectors by tests/test_oracle_vs_golden.py).  The backbone has no reference fixture (torchvision's Bottleneck is
+    absent), so this is its second, ATen-side pin next to the numpy oracle.  128x256 input, B=2, train-mode BN, dropout off; fixed bounds."""
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    from oracle.torch_cpu_model import TorchCpuDSRL, total_loss
+    torch.manual_seed(21)
+    model = D.DSRL(3, cs)
+    with torch.no_grad():
+        for m in model.modules():
+            if hasattr(m, 'bn3'):
+                m.bn3.weight.fill_(0.5)
+        model.SSSR_feature_transformer[1].bias.fill_(0.3); model.SISR_feature_transformer[1].bias.fill_(0.3)
+    ref = TorchCpuDSRL(3)
+    missing, unexpected = ref.load_state_dict({k: v.detach().clone() for k, v in model.state_dict().items()}, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    ref = ref.double().train()
+    model = model.to(DEV).to(memory_format=torch.channels_last).train()
+    for net in (model, ref):
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.eval()
+    rs = np.random.RandomState(2)
+    x = rs.standard_normal((2, 3, 128, 256)).astype(np.float32)
+    tg = rs.randint(0, 19, (2, 256, 512)).astype(np.uint8); tg[rs.uniform(size=tg.shape) < 0.1] = 255
+    org = rs.standard_normal((2, 3, 256, 512)).astype(np.float32)
+    outs = model(dev(x, cl=False))
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    vals = HF.fused_losses(outs, dev(tg), dev(org), 255, 0.1, 1.0, 3, flag)
+    vals[3].backward()
+    r_outs = ref(torch.from_numpy(x).double())
+    r_L = total_loss(r_outs, torch.from_numpy(tg), torch.from_numpy(org).double(), 3)
+    r_L[3].backward()
+    check(host(vals[:4]), np.array([float(v.detach()) for v in r_L]), 1e-3, 'losses (CE, MSE, FA, total)')
+    check(host(outs[0]), r_outs[0].detach().numpy(), 5e-3, 'logits')
+    check(host(outs[1]), r_outs[1].detach().numpy(), 5e-3, 'SISR')
+    assert (host(outs[0]).argmax(1) == r_outs[0].detach().numpy().argmax(1)).mean() > 0.999
+
+    def l2(a, b):
+        a = np.asarray(a, np.float64).ravel(); b = np.asarray(b, np.float64).ravel()
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    P, R = dict(model.named_parameters()), dict(ref.named_parameters())
+    rep = {k: l2(host(P[k].grad), R[k].grad.numpy()) for k in ('SSSR_decoder.upsample16_pred.6.weight', 'SISR_decoder.0.weight', 'SSSR_decoder.cat_conv.0.weight',
+                                                              'feature_extractor.aspp.branches.5.0.weight', 'feature_extractor.backbone.layer4.2.conv3.weight',
+                                                              'feature_extractor.backbone.layer2.0.downsample.0.weight', 'feature_extractor.backbone.conv1.weight')}
+    names = [k for k in P if P[k].grad is not None]
+    cat = lambda f: np.concatenate([np.asarray(f(k), np.float64).ravel() for k in names])
+    rep['all gradients (L2)'] = l2(cat(lambda k: host(P[k].grad)), cat(lambda k: R[k].grad.numpy()))
+    print({k: '%.2e' % v for k, v in rep.items()})
+    assert rep['SSSR_decoder.upsample16_pred.6.weight'] <= HEAD_GRAD_BOUND and rep['SISR_decoder.0.weight'] <= HEAD_GRAD_BOUND, rep
+    assert rep['all gradients (L2)'] <= ARENA_GRAD_BOUND, rep
+
+
 def test_train_or_resume_end_to_end(tmp_path):
     """The reference's entry point (command_handlers/train_or_resume.py:24-26 signature): two epochs on synthetic batches, a
     checkpoint in the reference's dict format, final.weights, then a resume that continues from the checkpoint."""
