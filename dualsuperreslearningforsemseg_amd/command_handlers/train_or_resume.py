@@ -128,6 +128,8 @@ class TrainStep:
                 HF.nan_check_(self.flag, *[o for o in outs if o.is_cuda])                  # the four NaN asserts, :426-433
                 ce, ms, fa, total = self.losses(outs, input_org, target)
                 vals = None
+            if in_graph and os.environ.get('DSRL_GRAPH_FAIL_TEST'):
+                raise RuntimeError('DSRL_GRAPH_FAIL_TEST: simulated failure in the middle of a capture')      # tests/test_rccl_gpu.py
             if do_train:
                 total.backward()                                                           # :444 (eager: chunked RCCL all-reduce overlaps)
                 if in_graph and flat.world > 1:
@@ -186,6 +188,31 @@ class TrainStep:
         self._graphs[key] = c
         return c
 
+    def _capture_or_fall_back(self, key, input_image, input_org, target, hp):
+        """A capture that fails (a runtime that refuses something inside it) must not end the training run: this TrainStep then keeps
+        launching eagerly - the same kernels and, with more than one rank, the same collectives in the same order, so ranks that captured and
+        ranks that did not stay in step.  Nothing of a failed capture has executed; its host-side bookkeeping is rolled back."""
+        import sys
+        bns = [m for m in self.model.modules() if isinstance(m, t.nn.modules.batchnorm._BatchNorm)]
+        before = [getattr(m, '_dsrl_batches', 0) for m in bns]
+        step_before, overlap_was = HF._rng_state['step'], HF.overlap_wgrad
+        try:
+            return self._capture(key, input_image, input_org, target, hp)
+        except Exception as e:          # noqa: BLE001
+            print(f'[dsrl] hipGraph capture failed ({type(e).__name__}: {str(e)[:200]}); this TrainStep continues with eager launches', file=sys.stderr, flush=True)
+            self.use_graph = False
+            HF.overlap_wgrad, HF.graph_keepalive, HF.capture_host, HF.wgrad_queue = overlap_was, None, None, None
+            HF._rng_state['step'] = step_before
+            for m, n in zip(bns, before):
+                if hasattr(m, '_dsrl_batches'):
+                    m._dsrl_batches = n
+            try:
+                t.cuda.set_stream(t.cuda.default_stream(self.flat.device))
+                t.cuda.synchronize(self.flat.device)
+            except Exception:           # noqa: BLE001
+                pass
+            return None
+
     def _replay(self, c, input_image, input_org, target):
         flat = self.flat
         for dst, src in ((c.img, input_image), (c.org, input_org), (c.tgt, target)):
@@ -223,7 +250,7 @@ class TrainStep:
             key = self._graph_key(input_image, input_org, target)
             c = self._graphs.get(key)
             if c is None and self._warm.get(key, 0) >= self.GRAPH_WARMUP:
-                c = self._capture(key, input_image, input_org, target, hp)
+                c = self._capture_or_fall_back(key, input_image, input_org, target, hp)
             if c is None:
                 self._warm[key] = self._warm.get(key, 0) + 1
                 outs, vals = self._body(input_image, input_org, target, hp, True)

@@ -128,3 +128,32 @@ def test_graph_replay_matches_eager_bitwise():
     assert res[False][3] == res[True][3] == 6
     # dropout really changes from step to step (same batch 0 at steps 0, 2, 4 but different losses already at step 2 vs a frozen key is
     # covered by the bitwise equality with the eager run, whose key advances on the host)
+
+
+def test_failed_capture_falls_back_to_eager(monkeypatch):
+    """If the hipGraph capture fails, the TrainStep keeps training with eager launches (same results as a TrainStep that never tried)."""
+    from dualsuperreslearningforsemseg_amd import functional as HF
+    import dualsuperreslearningforsemseg_amd as D
+    from dualsuperreslearningforsemseg_amd import ddp
+    from dualsuperreslearningforsemseg_amd.command_handlers.train_or_resume import SyntheticCityscapes, TrainStep
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    res = {}
+    for fail in (False, True):
+        if fail:
+            monkeypatch.setenv('DSRL_GRAPH_FAIL_TEST', '1')
+        torch.manual_seed(54321)
+        model = D.DSRL(3, cs)
+        with torch.no_grad():
+            for m in model.modules():
+                if hasattr(m, 'bn3'):
+                    m.bn3.weight.fill_(0.5)
+        model = model.to(DEV).to(memory_format=torch.channels_last).train()
+        flat = ddp.FlatParams(model)
+        HF.set_dropout_seed(99)
+        step = TrainStep(model, flat, 3, 0.1, 1.0, cs.IGNORE_CLASS_LABEL, graph=fail)
+        (img, org), (tgt, _) = next(iter(SyntheticCityscapes(2, (64, 128), torch.device(DEV), length=1)))
+        res[fail] = [step(img, org, tgt, 0.006, 0.9, 5e-4, True)[0] for _ in range(5)]
+        if fail:
+            assert step.graph_replays == 0 and not step.use_graph
+        step.release()
+    assert res[False] == res[True], (res[False][-1], res[True][-1])
