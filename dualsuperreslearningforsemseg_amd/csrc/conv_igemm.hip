@@ -903,7 +903,11 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
     const int dh = r * a.dil - a.pad, dw_ = s * a.dil - a.pad;
     const long long nchunks = (a.P + 31) / 32;
     const int ch0 = (int)(nchunks * zsplit / a.psplits), ch1 = (int)(nchunks * (zsplit + 1) / a.psplits);
-    const int HoWo = a.Ho * a.Wo;
+    // Loop-invariant fields as values: in a grouped launch `a` is a table entry in global memory, and a field read inside the chunk loop
+    // would be a scalar load + wait per use (the stores of the loop keep the compiler from hoisting them).
+    const int g_lddy = a.lddy, g_ldx = a.ldx, g_H = a.H, g_W = a.W, g_Wo = a.Wo, g_stride = a.stride;
+    const unsigned g_mHW = a.mHW, g_sHW = a.sHW, g_mW = a.mW, g_sW = a.sW;
+    const int HoWo = a.Ho * g_Wo;
 
     const int a_col = (tid % A_V) * 4, a_row = tid / A_V;
     const int b_col = (tid % B_V) * 4, b_row = tid / B_V;
@@ -933,17 +937,17 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int p = pb + a_row + i * A_RP;
-            ra[i] = buf_load4(dr, (p < Pi ? (unsigned)p * (unsigned)a.lddy * 4u : kOOB) + a_coff);
+            ra[i] = buf_load4(dr, (p < Pi ? (unsigned)p * (unsigned)g_lddy * 4u : kOOB) + a_coff);
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int p = pb + b_row + i * B_RP;
             unsigned off = kOOB;
             if (p < Pi) {
-                const int n = fast_div(p, a.mHW, a.sHW), rem = p - n * HoWo;
-                const int ho = fast_div(rem, a.mW, a.sW), wo = rem - ho * a.Wo;
-                const int hi = ho * a.stride + dh, wi = wo * a.stride + dw_;
-                if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) off = (unsigned)((n * a.H + hi) * a.W + wi) * (unsigned)a.ldx * 4u;
+                const int n = fast_div(p, g_mHW, g_sHW), rem = p - n * HoWo;
+                const int ho = fast_div(rem, g_mW, g_sW), wo = rem - ho * g_Wo;
+                const int hi = ho * g_stride + dh, wi = wo * g_stride + dw_;
+                if (hi >= 0 && hi < g_H && wi >= 0 && wi < g_W) off = (unsigned)((n * g_H + hi) * g_W + wi) * (unsigned)g_ldx * 4u;
             }
             rb[i] = buf_load4(xr, off + b_coff);
         }
@@ -951,13 +955,13 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
     // a 32-pixel chunk whose pixels all read zero padding for this tap contributes nothing: skip it (block-uniform test)
     auto chunk_live = [&](int ch) -> bool {
         const int pf = ch * 32, pl = min(pf + 32, Pi) - 1;
-        const int nf = pf / HoWo, nl = pl / HoWo;
+        const int nf = fast_div(pf, g_mHW, g_sHW), nl = fast_div(pl, g_mHW, g_sHW);
         if (nf != nl) return true;
-        const int hf = (pf - nf * HoWo) / a.Wo, hl = (pl - nl * HoWo) / a.Wo;
-        if (hl * a.stride + dh < 0 || hf * a.stride + dh >= a.H) return false;
+        const int hf = fast_div(pf - nf * HoWo, g_mW, g_sW), hl = fast_div(pl - nl * HoWo, g_mW, g_sW);
+        if (hl * g_stride + dh < 0 || hf * g_stride + dh >= g_H) return false;
         if (hf == hl) {
-            const int wf = pf - nf * HoWo - hf * a.Wo, wl = pl - nl * HoWo - hl * a.Wo;
-            if (wl * a.stride + dw_ < 0 || wf * a.stride + dw_ >= a.W) return false;
+            const int wf = pf - nf * HoWo - hf * g_Wo, wl = pl - nl * HoWo - hl * g_Wo;
+            if (wl * g_stride + dw_ < 0 || wf * g_stride + dw_ >= g_W) return false;
         }
         return true;
     };
