@@ -1819,6 +1819,21 @@ static size_t group_table_bytes(int n) {
 }
 static int group_target_px() { return std::max(256, env_int("DSRL_WGRAD_GROUP_PX", 4096)); }
 struct GroupItem { WgradArgs a; TileCfg cfg; int bm, bn; double cost, flops, bytes; size_t slab_bytes; };
+// Pixel ranges of one problem. Default: one range per ~DSRL_WGRAD_GROUP_PX output pixels. A problem that this leaves with fewer than 8 ranges
+// spreads the blocks of a range (taps x tiles) over all 8 XCDs, and every XCD's L2 then fetches the whole of x and dy; with 8 ranges each XCD
+// owns one and fetches an eighth. DSRL_WGRAD_XCD_SPLIT=1 takes 8 ranges where the slab traffic this adds (8 slabs written and read back)
+// is smaller than the operand re-fetches it removes.
+static int group_psplits(long long P, int K, int R, int S, int C, long long x_pixels) {
+    const long long chunks = ceil_div(P, 32);
+    const int forced = env_int("DSRL_FORCE_PSPLITS", 0);
+    long long sp = forced > 0 ? forced : (P + group_target_px() / 2) / group_target_px();
+    sp = std::max<long long>(1, std::min<long long>(sp, std::max<long long>(1, chunks / 4)));
+    if (forced <= 0 && sp < 8 && chunks >= 64 && env_int("DSRL_WGRAD_XCD_SPLIT", 0)) {
+        const double operands = 4.0 * ((double)x_pixels * C + (double)P * K), slabs = 4.0 * (double)K * R * S * C;
+        if (16.0 * slabs < 7.0 * operands) sp = 8;
+    }
+    return (int)std::min<long long>(sp, 256);
+}
 static int group_item(const dsrl_wgrad_problem& q, int npl, GroupItem& it) {
     const int N = q.N, H = q.H, W = q.W, C = q.C, K = q.K, R = q.R, S = q.S, stride = q.stride, pad = q.pad, dil = q.dil;
     if (int e = check_conv(q.x, q.dy, q.dw, N, H, W, C, K, R, S, stride, pad, dil)) return e;
@@ -1834,11 +1849,7 @@ static int group_item(const dsrl_wgrad_problem& q, int npl, GroupItem& it) {
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db;
     a.ntaps = p.tl.n;
     for (int i = 0; i < p.tl.n; ++i) a.taps[i] = p.tl.taps[i];
-    const long long chunks = ceil_div(p.P, 32);
-    const int forced = env_int("DSRL_FORCE_PSPLITS", 0);
-    long long sp = forced > 0 ? forced : (p.P + group_target_px() / 2) / group_target_px();
-    sp = std::max<long long>(1, std::min<long long>(sp, std::max<long long>(1, chunks / 4)));
-    a.psplits = (int)std::min<long long>(sp, 256);
+    a.psplits = group_psplits(p.P, K, R, S, C, (long long)N * H * W);
     a.kg = 1; a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
     a.nblocks = a.kctiles * a.ntaps * a.psplits;
     a.dw_final = q.dw; a.dw = q.dw;
@@ -1865,10 +1876,7 @@ extern "C" size_t dsrl_conv2d_wgrad_group_workspace_bytes(const dsrl_wgrad_probl
         if (q.N <= 0 || q.H <= 0 || q.W <= 0 || q.C <= 0 || q.K <= 0 || q.R <= 0 || q.S <= 0 || q.stride <= 0 || q.dil <= 0 || q.pad < 0) continue;
         if (out_size(q.H, q.R, q.stride, q.pad, q.dil) <= 0 || out_size(q.W, q.S, q.stride, q.pad, q.dil) <= 0) continue;
         const long long P = (long long)q.N * out_size(q.H, q.R, q.stride, q.pad, q.dil) * out_size(q.W, q.S, q.stride, q.pad, q.dil);
-        const long long chunks = ceil_div(P, 32);
-        const int forced = env_int("DSRL_FORCE_PSPLITS", 0);
-        long long sp = forced > 0 ? forced : (P + group_target_px() / 2) / group_target_px();
-        sp = std::min<long long>(std::max<long long>(1, std::min<long long>(sp, std::max<long long>(1, chunks / 4))), 256);
+        const int sp = dsrl::group_psplits(P, q.K, q.R, q.S, q.C, (long long)q.N * q.H * q.W);
         if (sp > 1) total += align_up((size_t)sp * q.K * q.R * q.S * q.C * sizeof(float), 256);
     }
     return total;
