@@ -312,7 +312,17 @@ __global__ __launch_bounds__(256) void convt2x2_dw_finalize_kernel(const float* 
     const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int o = blockIdx.x * 32 + ol;
     double s = 0;
-    if (o < NOUT + CO) for (int b = sl; b < nblocks; b += 8) s += part[(long long)b * (NOUT + CO) + o];
+    if (o < NOUT + CO) {
+        int b = sl;
+        for (; b + 56 < nblocks; b += 64) {        // eight loads in flight; the order of the additions is the plain loop's
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(b + 8 * u) * (NOUT + CO) + o];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nblocks; b += 8) s += part[(long long)b * (NOUT + CO) + o];
+    }
     sh[sl][ol] = s;
     __syncthreads();
     if (sl != 0 || o >= NOUT + CO) return;
@@ -321,6 +331,190 @@ __global__ __launch_bounds__(256) void convt2x2_dw_finalize_kernel(const float* 
         const int ci = o / (4 * CO), col = o % (4 * CO), ij = col / CO, co = col % CO;
         dw[(ci * CO + co) * 4 + ij] = (float)s;
     } else if (db) db[o - NOUT] = (float)s;
+}
+
+// Fused backward (round 2): dy is read ONCE for dx, dw and db (the separate dx / dw kernels above each stream it, and the dw kernel spends
+// two LDS reads per multiply-add).  A block walks row segments of 64 input pixels (grid-stride; the next segment's 16-byte buffer loads are
+// in flight while the current one is computed from LDS; rows past the end of a ragged last segment read as zeros through the descriptor):
+//   * dx: thread (tap, 4 pixels, group of 5 input channels) keeps a 4 x 5 register tile: per output channel four gradient words and one
+//     b128 + b32 filter read for 20 multiply-adds; the four taps of a pixel sit in one lane quad and are summed with two DPP quad permutes
+//     (191 us on the 8 x 256 x 512 input of the step's last ConvTranspose; one lane per (pixel, tap) with five b128 filter reads per output channel: 206 us);
+//   * dw: thread (group of 5 input channels, 4 adjacent columns of [tap][co], pixel sub-range) keeps a 5 x 4 register tile: b128 + b128 + b32
+//     per 20 multiply-adds. The unused sixth-row slot ci = CI of the input tile holds 1.0, so its row of the tile is the column sum: db for free;
+//   * the per-block partials keep the layout convt2x2_dw_finalize_kernel merges.
+// Requires W % 4 == 0 (16-byte aligned segments); the host falls back to the two-kernel path otherwise.
+__device__ __forceinline__ float quad_xor_add(float v, int which) {      // v + v of lane ^ 1 (which = 1) / lane ^ 2 (which = 2)
+    const int i = __float_as_int(v);
+    const int o = which == 1 ? __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, false) : __builtin_amdgcn_update_dpp(i, i, 0x4E, 0xF, 0xF, false);
+    return v + __int_as_float(o);
+}
+template <int CI, int CO>
+__global__ __launch_bounds__(256, 4) void convt2x2_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+                                                                  float* __restrict__ dx, float* __restrict__ part, int N, int H, int W,
+                                                                  int nseg_per_row, int nseg) {
+    constexpr int TP = 64, COLS = 4 * CO, NCOLG = CO, RG = 5, NCG = (CI + RG - 1) / RG, XA = NCG * 8;
+    constexpr int TPS = NCG * NCOLG;                                        // threads per pixel sub-range of the dw tile
+    constexpr int NSUB = 256 / TPS < 8 ? 256 / TPS : 8;
+    static_assert(NSUB >= 1 && NCG <= 4 && CI < NCG * RG && (TP * CI) % 4 == 0 && (2 * TP * CO) % 4 == 0, "tile does not fit the block");
+    constexpr int NOUT = CI * COLS;
+    constexpr int XV = TP * CI / 4, DV = 2 * TP * CO / 4;                   // float4 per x segment / per dy row segment
+    constexpr int XR = (XV + 255) / 256, DR = (DV + 255) / 256;             // load rounds
+    constexpr int BUF = TP * COLS > NSUB * NCG * RG * COLS ? TP * COLS : NSUB * NCG * RG * COLS;
+    __shared__ __attribute__((aligned(16))) float wsh[4 * CO * NCG * 8];   // [tap][co][ci group][8]
+    __shared__ __attribute__((aligned(16))) float buf[BUF];                // gradients [px][tap][co]; at the end the dw tiles of the sub-ranges
+    __shared__ __attribute__((aligned(16))) float xa[TP * XA];             // inputs [px][ci group][8] (slot ci = CI holds 1.0)
+    const int tid = threadIdx.x;
+    for (int t = tid; t < 4 * CO * NCG * 8; t += 256) {
+        const int r = t % 8, g = (t / 8) % NCG, co = (t / (8 * NCG)) % CO, ij = t / (8 * NCG * CO), ci = g * RG + r;
+        wsh[t] = (r < RG && ci < CI) ? w[(ci * CO + co) * 4 + ij] : 0.f;
+    }
+    for (int t = tid; t < TP * XA; t += 256) xa[t] = (t % XA) == (CI / RG) * 8 + CI % RG ? 1.f : 0.f;
+
+    // per-thread constants of the staging: byte offsets of its float4 in the segment (beyond the descriptor when the round has no work for it)
+    // and the four LDS word indices each float4 scatters to
+    unsigned xoff[XR], doff[DR];
+    int xl[XR][4], dl[DR][4];
+#pragma unroll
+    for (int k = 0; k < XR; ++k) {
+        const int v = tid + 256 * k;
+        xoff[k] = v < XV ? (unsigned)v * 16u : 0x80000000u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int t = (4 * v + e) % (TP * CI), px = t / CI, ci = t % CI; xl[k][e] = px * XA + (ci / RG) * 8 + ci % RG; }
+    }
+#pragma unroll
+    for (int k = 0; k < DR; ++k) {
+        const int v = tid + 256 * k;
+        doff[k] = v < DV ? (unsigned)v * 16u : 0x80000000u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int t = (4 * v + e) % (2 * TP * CO), px = t / (2 * CO), rem = t % (2 * CO); dl[k][e] = px * COLS + rem; }
+    }
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+    float4 RX[XR], RD[2][DR];
+    auto ld4 = [](__amdgpu_buffer_rsrc_t r, unsigned off) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    auto gload = [&](int seg) {
+        const int row = seg / nseg_per_row;                                  // n*H + h
+        const int w0 = (seg - row * nseg_per_row) * TP, npx = min(TP, W - w0);
+        const int n = row / H, h = row - n * H;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(x + ((long long)row * W + w0) * CI), 0, npx * CI * 4, 0x00020000);
+        const float* d = dy + (((long long)(n * 2 * H + 2 * h)) * (2 * W) + 2 * w0) * CO;
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)d, 0, 2 * npx * CO * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(d + 2ll * W * CO), 0, 2 * npx * CO * 4, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < XR; ++k) RX[k] = ld4(xr, xoff[k]);
+#pragma unroll
+        for (int k = 0; k < DR; ++k) { RD[0][k] = ld4(r0, doff[k]); RD[1][k] = ld4(r1, doff[k]); }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int k = 0; k < XR; ++k)
+            if (tid + 256 * k < XV) { xa[xl[k][0]] = RX[k].x; xa[xl[k][1]] = RX[k].y; xa[xl[k][2]] = RX[k].z; xa[xl[k][3]] = RX[k].w; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < DR; ++k)
+                if (tid + 256 * k < DV) {
+                    float* b = buf + i * 2 * CO;
+                    b[dl[k][0]] = RD[i][k].x; b[dl[k][1]] = RD[i][k].y; b[dl[k][2]] = RD[i][k].z; b[dl[k][3]] = RD[i][k].w;
+                }
+    };
+
+    float dwacc[RG][4];
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dwacc[r][c] = 0.f;
+    // dx: lane quad = the four taps; 16 pixel groups of 4; wave = input-channel group (waves beyond NCG idle in this phase)
+    const int tap = tid & 3, pxg = (tid >> 2) & 15, ciq = tid >> 6;
+    const bool dw_thread = tid < NSUB * TPS;
+    const int sub = tid / TPS, cg = (tid % TPS) / NCOLG, colg = tid % NCOLG;
+
+    int seg = (int)blockIdx.x;
+    if (seg < nseg) gload(seg);
+    for (; seg < nseg; seg += (int)gridDim.x) {
+        const int row = seg / nseg_per_row;
+        const int w0 = (seg - row * nseg_per_row) * TP, npx = min(TP, W - w0);
+        __syncthreads();                        // the previous segment's readers are done
+        lstore();
+        __syncthreads();
+        if (seg + (int)gridDim.x < nseg) gload(seg + (int)gridDim.x);
+        // ---- dx
+        if (ciq < NCG) {
+            float acc[4][RG];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int r = 0; r < RG; ++r) acc[p][r] = 0.f;
+            const float* g = buf + (pxg * 4) * COLS + tap * CO;
+            const float* wq = wsh + (tap * CO * NCG + ciq) * 8;
+#pragma unroll
+            for (int co = 0; co < CO; ++co) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wq + co * NCG * 8);
+                const float w5 = wq[co * NCG * 8 + 4];
+                const float wv[RG] = {w4.x, w4.y, w4.z, w4.w, w5};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float gv = g[p * COLS + co];
+#pragma unroll
+                    for (int r = 0; r < RG; ++r) acc[p][r] = fmaf(gv, wv[r], acc[p][r]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int r = 0; r < RG; ++r) acc[p][r] = quad_xor_add(quad_xor_add(acc[p][r], 1), 2);
+            // lane `tap` of the quad stores pixel pxg*4 + tap: five consecutive channels
+            const int px = pxg * 4 + tap;
+            if (px < npx) {
+                float* o = dx + ((long long)row * W + w0 + px) * CI + ciq * RG;
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const float v = tap == 0 ? acc[0][r] : tap == 1 ? acc[1][r] : tap == 2 ? acc[2][r] : acc[3][r];
+                    if (ciq * RG + r < CI) o[r] = v;
+                }
+            }
+        }
+        // ---- dw (+ db through the ones slot)
+        if (dw_thread) {
+#pragma unroll 2
+            for (int px = sub; px < TP; px += NSUB) {
+                const float4 dv = *reinterpret_cast<const float4*>(buf + px * COLS + colg * 4);
+                const float4 x4 = *reinterpret_cast<const float4*>(xa + px * XA + cg * 8);
+                const float x5 = xa[px * XA + cg * 8 + 4];
+                const float xv[RG] = {x4.x, x4.y, x4.z, x4.w, x5};
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    dwacc[r][0] = fmaf(xv[r], dv.x, dwacc[r][0]); dwacc[r][1] = fmaf(xv[r], dv.y, dwacc[r][1]);
+                    dwacc[r][2] = fmaf(xv[r], dv.z, dwacc[r][2]); dwacc[r][3] = fmaf(xv[r], dv.w, dwacc[r][3]);
+                }
+            }
+        }
+    }
+    // ---- merge the pixel sub-ranges (fixed order) and leave the block's partials; row CI of the tile = column sums of dy = db per tap
+    __syncthreads();
+    if (dw_thread) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) buf[sub * (NCG * RG * COLS) + (cg * RG + r) * COLS + colg * 4 + c] = dwacc[r][c];
+    }
+    __syncthreads();
+    float* po = part + (long long)blockIdx.x * (NOUT + CO);
+    for (int o = tid; o < NOUT + CO; o += 256) {
+        float s = 0.f;
+        if (o < NOUT) {
+#pragma unroll
+            for (int u = 0; u < NSUB; ++u) s += buf[u * (NCG * RG * COLS) + o];
+        } else {
+#pragma unroll
+            for (int u = 0; u < NSUB; ++u)
+#pragma unroll
+                for (int ij = 0; ij < 4; ++ij) s += buf[u * (NCG * RG * COLS) + CI * COLS + ij * CO + (o - NOUT)];
+        }
+        po[o] = s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- PixelShuffle
@@ -466,6 +660,7 @@ extern "C" int dsrl_convt2x2_fwd(const float* x, const float* w, const float* bi
     set_error("convt2x2_fwd: channel counts %d->%d not instantiated (19->19, 8->8)", Cin, Cout);
     return DSRL_E_UNSUPPORTED;
 }
+static bool env_flag_convt_fused() { const char* v = getenv("DSRL_CONVT_FUSED_BWD"); return !v || atoi(v) != 0; }   // 0: the separate dx / dw kernels
 static int convt_dw_blocks(int N, int H, int W) { return (int)std::min<long long>(1024, (long long)N * H * ceil_div(W, 64)); }
 extern "C" size_t dsrl_convt2x2_bwd_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
     return (size_t)convt_dw_blocks(N, H, W) * (Cin * Cout * 4 + Cout) * sizeof(float);
@@ -478,7 +673,15 @@ extern "C" int dsrl_convt2x2_bwd(const float* x, const float* w, const float* dy
     const int nseg_per_row = (int)ceil_div(W, 64);
     const long long nseg = (long long)N * H * nseg_per_row;
     dim3 gdx((unsigned)ceil_div(W, 128), (unsigned)(N * H));
+    const bool fused = W % 4 == 0 && nseg < (1ll << 31) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && env_flag_convt_fused();
 #define DSRL_CONVT_BWD_BODY                                                                                                         \
+    if (fused) {                                                                                                                    \
+        hipLaunchKernelGGL((convt2x2_bwd_fused_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, x, w, dy, dx, (float*)ws, N, H, W, nseg_per_row, (int)nseg); \
+        if (int e = launch_status("convt2x2_bwd_fused_kernel")) return e;                                                           \
+        hipLaunchKernelGGL((convt2x2_dw_finalize_kernel<CI, CO>), dim3((unsigned)ceil_div(CI * CO * 4 + CO, 32)), dim3(256), 0, st, \
+                           (const float*)ws, nb, dw, dbias);                                                                        \
+        return launch_status("convt2x2_dw_finalize_kernel");                                                                        \
+    }                                                                                                                               \
     hipLaunchKernelGGL((convt2x2_dx_kernel<CI, CO>), gdx, dim3(256), 0, st, dy, w, dx, N, H, W);                                    \
     if (int e = launch_status("convt2x2_dx_kernel")) return e;                                                                      \
     hipLaunchKernelGGL((convt2x2_dw_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, x, dy, (float*)ws, N, H, W, nseg_per_row, nseg);   \

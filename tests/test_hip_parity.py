@@ -170,17 +170,27 @@ def test_convT_golden(golden):
     check(host(x.grad), g['convT.dx'], 1e-5); check(host(w.grad), g['convT.dw'], 1e-5); check(host(b.grad), g['convT.db'], 1e-5)
 
 
-def test_convT_vs_oracle_ragged():
+@pytest.mark.parametrize('shape', [(2, 19, 5, 150), (2, 19, 7, 200), (1, 19, 3, 64), (3, 19, 4, 12), (2, 8, 6, 72)])
+def test_convT_vs_oracle_ragged(shape, monkeypatch):
+    # W = 150: the two-kernel backward (segments not 16-byte aligned); W % 4 == 0: the fused backward (dy read once), with a ragged
+    # last segment (200 = 3 * 64 + 8, 72, 12) and with exactly one (64); 8 -> 8 channels: the second instantiation
     rs = np.random.RandomState(9)
-    x = rs.standard_normal((2, 19, 5, 150)).astype(np.float32); w = rs.standard_normal((19, 19, 2, 2)).astype(np.float32)
-    xt = dev(x).requires_grad_(True); wt = dev(w, cl=False).requires_grad_(True)
-    y = HF.conv_transpose2d_k2s2(xt, wt, None)
-    yo = O.conv_transpose2d_k2s2(x.astype(np.float64), w.astype(np.float64))
-    check(host(y), yo, 1e-5)
+    C = shape[1]
+    x = rs.standard_normal(shape).astype(np.float32); w = rs.standard_normal((C, C, 2, 2)).astype(np.float32); b = rs.standard_normal(C).astype(np.float32)
+    yo = O.conv_transpose2d_k2s2(x.astype(np.float64), w.astype(np.float64)) + b.astype(np.float64)[None, :, None, None]
     dy = rs.standard_normal(yo.shape).astype(np.float32)
-    y.backward(dev(dy))
-    dxo, dwo, _ = O.conv_transpose2d_k2s2_bwd(x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64))
-    check(host(xt.grad), dxo, 1e-5); check(host(wt.grad), dwo, 1e-5)
+    dxo, dwo, dbo = O.conv_transpose2d_k2s2_bwd(x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64), has_bias=True)
+    grads = {}
+    for fused in ('1', '0'):
+        monkeypatch.setenv('DSRL_CONVT_FUSED_BWD', fused)
+        xt = dev(x).requires_grad_(True); wt = dev(w, cl=False).requires_grad_(True); bt = dev(b).requires_grad_(True)
+        y = HF.conv_transpose2d_k2s2(xt, wt, bt)
+        check(host(y), yo, 1e-5)
+        y.backward(dev(dy))
+        check(host(xt.grad), dxo, 1e-5); check(host(wt.grad), dwo, 1e-5); check(host(bt.grad), dbo, 1e-5)
+        grads[fused] = (host(xt.grad), host(wt.grad), host(bt.grad))
+    for a, c in zip(grads['1'], grads['0']):
+        check(a, c, 1e-5)
 
 
 @pytest.mark.parametrize('name', ['up2', 'up4', 'up_bcast', 'up_odd'])
