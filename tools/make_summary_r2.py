@@ -33,7 +33,8 @@ groups = [
     ('BatchNorm three-kernel path (large / odd-width tensors) + eval apply', r'bn_(partial|finalize|apply|bwd_partial|bwd_finalize|bwd_apply)', r'stats_apply'),
     ('fused loss pass: count_valid, ce_fused, mse_fused, fa_fwd/bwd, finalizers, loss_mix', r'ce_fused|mse_fused|count_valid|fa_fwd|fa_bwd|ce_finalize|mse_finalize|loss_mix', None),
     ('ConvTranspose 19->19 forward / dx / dw', r'convt2x2', None),
-    ('bilinear, pixel shuffle, pools, pointwise stride-8, dropout, colsum, concat copies', r'bilinear|pixel_shuffle|maxpool|gap_|pointwise|dropout_kernel|colsum|copyBuffer|pad_image|nchw', None),
+    ('bilinear, pixel shuffle, pools, pointwise stride-8, dropout, colsum, concat copies', r'bilinear|pixel_shuffle|maxpool|gap_|pointwise|dropout_kernel|colsum|copyBufferRect|pad_image|nchw', None),
+    ('NOT per step: parameter upload / arena set-up copies of the process (__amd_rocclr_copyBuffer, ~1300 launches once), shown divided by the step count', r'__amd_rocclr_copyBuffer$', None),
     ('SGD + filter transposes + dropout-key advance + NaN check', r'sgd|weight_transpose|rng_advance|nan_check', None),
     ('remaining ATen elementwise / fill kernels', r'at::native|fillBuffer', None),
 ]
@@ -55,7 +56,7 @@ hipGraphLaunch); the same step timed over the same {d['steps']} steps / {d['warm
 CPU baselines on the box's host cores: stock torch.nn CPU graph {d.get('cpu_baseline', {}).get('value')} images/s on {d.get('cpu_baseline', {}).get('cores')} threads; numpy oracle
 {d.get('cpu_baseline_numpy_port', {}).get('value')} images/s.
 
-Total kernel time per step: {tot:.2f} ms
+Total kernel time per step: {tot:.2f} ms, of which {g[groups[12][0]][1]:.2f} ms is the one-time set-up row (per step without it: {tot - g[groups[12][0]][1]:.2f} ms)
 
 | group | ms/step | launches/step | avg us |
 |---|---|---|---|
