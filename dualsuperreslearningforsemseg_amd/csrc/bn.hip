@@ -233,7 +233,17 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double a = 0;
-    if (c < C) for (int i = sl; i < nbx; i += 8) a += part[(long long)i * C + c];
+    if (c < C) {
+        int i = sl;
+        for (; i + 56 < nbx; i += 64) {             // eight loads in flight; the additions keep the plain loop's order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(i + 8 * u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; i < nbx; i += 8) a += part[(long long)i * C + c];
+    }
     sh[sl][cl] = a;
     __syncthreads();
     if (sl != 0 || c >= C) return;
@@ -874,6 +884,179 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_apply_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------- dense tensors, C % 4 != 0 ("flat" kernels)
+// A dense [P][C] tensor (ld == C) is one float array: float4 number f holds the elements 4f .. 4f+3 and element e belongs to channel e % C.
+// A thread that strides by T float4 with 4T % C == 0 meets the same four channels in every float4 it loads, so the odd channel counts of the
+// tail (19 classes at 256x512 and 512x1024, the one-channel feature transformers) stream with 16-byte loads like every other tensor; the
+// one-float-per-lane kernels above remain for strided or unaligned operands.  Blocks of 512 threads, T = the largest multiple of
+// C / gcd(C, 4) below 512; the per-thread sums share one shift per channel and block, so the block merge is a plain sum by channel.
+constexpr int kFlatThreads = 512;
+__device__ inline void flat_reduce(float (*sh)[4 * kFlatThreads], float (*sh2)[kFlatThreads], int nv, int C, int T, int phase0, float* out) {
+    // sh[v][e], e = 4*thread + slot, belongs to channel (phase0 + e) % C; returns in out[v] (threads < C) the channel totals. Three levels in a
+    // fixed order: G = 512 / C row slots per channel, then 16, then one - a one-channel tensor would otherwise leave 512 additions to one thread.
+    const int t = threadIdx.x, G = kFlatThreads / C, c = t % C, r = t / C;
+    __syncthreads();
+    if (r < G) {
+        const int e0 = (c - phase0 + C) % C;
+        for (int v = 0; v < nv; ++v) {
+            float a = 0.f;
+            for (int e = e0 + C * r; e < 4 * T; e += C * G) a += sh[v][e];
+            sh2[v][r * C + c] = a;
+        }
+    }
+    __syncthreads();
+    const int G2 = G > 16 ? 16 : G;
+    if (G > 16 && r < 16) {
+        for (int v = 0; v < nv; ++v) {
+            float a = 0.f;
+            for (int q = r; q < G; q += 16) a += sh2[v][q * C + c];
+            sh[v][r * C + c] = a;
+        }
+    }
+    __syncthreads();
+    if (t < C)
+        for (int v = 0; v < nv; ++v) {
+            float a = 0.f;
+            for (int q = 0; q < G2; ++q) a += (G > 16 ? sh[v][q * C + t] : sh2[v][q * C + t]);
+            out[v] = a;
+        }
+}
+__global__ __launch_bounds__(kFlatThreads) void bn_partial_flat_kernel(const float* __restrict__ x, long long total4, long long P, int C, int T,
+                                                                      long long per_block4, float* __restrict__ part, int nbx) {
+    __shared__ float sh[3][4 * kFlatThreads];
+    __shared__ float sh2[3][kFlatThreads];
+    const int t = threadIdx.x;
+    const long long b0 = min(total4, blockIdx.x * per_block4), b1 = min(total4, b0 + per_block4);
+    const long long r0 = min(P - 1, (4 * b0) / C);                         // a row of this block: its values are the shifts
+    const int phase0 = (int)((4 * b0) % C);
+    float n = 0.f, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t < T) {
+        float k0[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) k0[k] = x[r0 * C + (phase0 + 4 * t + k) % C];
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+#pragma unroll 4
+        for (long long f = b0 + t; f < b1; f += T) {
+            const float4 v = x4[f];
+            const float d0 = v.x - k0[0], d1 = v.y - k0[1], d2 = v.z - k0[2], d3 = v.w - k0[3];
+            s1[0] += d0; s2[0] += d0 * d0; s1[1] += d1; s2[1] += d1 * d1; s1[2] += d2; s2[2] += d2 * d2; s1[3] += d3; s2[3] += d3 * d3;
+            n += 1.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sh[0][4 * t + k] = n; sh[1][4 * t + k] = s1[k]; sh[2][4 * t + k] = s2[k]; }
+    float tot[3];
+    flat_reduce(sh, sh2, 3, C, T, phase0, tot);
+    if (t < C) {
+        float mean = 0.f, m2 = 0.f;
+        if (tot[0] > 0.f) { mean = x[r0 * C + t] + tot[1] / tot[0]; m2 = fmaxf(tot[2] - tot[1] * tot[1] / tot[0], 0.f); }
+        const long long o = (long long)blockIdx.x * C + t;
+        part[o] = tot[0]; part[(long long)nbx * C + o] = mean; part[2ll * nbx * C + o] = m2;
+    }
+}
+__global__ __launch_bounds__(kFlatThreads) void bn_bwd_partial_flat_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                                          long long total4, int C, int T, long long per_block4,
+                                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                          int relu, float drop_p, float* __restrict__ part, int nbx) {
+    __shared__ float sh[3][4 * kFlatThreads];
+    __shared__ float sh2[3][kFlatThreads];
+    const int t = threadIdx.x;
+    const long long b0 = min(total4, blockIdx.x * per_block4), b1 = min(total4, b0 + per_block4);
+    const int phase0 = (int)((4 * b0) % C);
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t < T) {
+        float mu[4], is[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int c = (phase0 + 4 * t + k) % C; mu[k] = mean[c]; is[k] = invstd[c]; }
+        const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+        const bool need_y = relu || drop_p > 0.f;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const float4* y4 = reinterpret_cast<const float4*>(y);
+        const float4* d4 = reinterpret_cast<const float4*>(dy);
+#pragma unroll 2
+        for (long long f = b0 + t; f < b1; f += T) {
+            const float4 dv = d4[f], xv = x4[f];
+            const float4 yv = need_y ? y4[f] : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float g0 = masked_grad(dv.x, yv.x, relu, drop_p, ks), g1 = masked_grad(dv.y, yv.y, relu, drop_p, ks);
+            const float g2 = masked_grad(dv.z, yv.z, relu, drop_p, ks), g3 = masked_grad(dv.w, yv.w, relu, drop_p, ks);
+            sg[0] += g0; sgx[0] += g0 * ((xv.x - mu[0]) * is[0]); sg[1] += g1; sgx[1] += g1 * ((xv.y - mu[1]) * is[1]);
+            sg[2] += g2; sgx[2] += g2 * ((xv.z - mu[2]) * is[2]); sg[3] += g3; sgx[3] += g3 * ((xv.w - mu[3]) * is[3]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sh[0][4 * t + k] = sg[k]; sh[1][4 * t + k] = sgx[k]; }
+    float tot[2];
+    flat_reduce(sh, sh2, 2, C, T, phase0, tot);
+    if (t < C) {
+        const long long o = (long long)blockIdx.x * C + t;
+        part[o] = tot[0]; part[(long long)nbx * C + o] = tot[1];
+    }
+}
+__global__ __launch_bounds__(kFlatThreads) void bn_apply_flat_kernel(const float* __restrict__ x, float* __restrict__ y, long long total4, int C, int T,
+                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    const float* __restrict__ res, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream) {
+    const unsigned long long seed = seed_arg.dev ? *seed_arg.dev : seed_arg.value;
+    const int t = threadIdx.x;
+    if (t >= T) return;
+    const long long f0 = (long long)blockIdx.x * T + t, stride = (long long)gridDim.x * T;      // 4 * stride % C == 0: the channels of a thread never change
+    float sc[4], sf[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int c = (int)((4 * f0 + k) % C); sc[k] = gamma[c] * invstd[c]; sf[k] = beta[c] - mean[c] * sc[k]; }
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* r4 = reinterpret_cast<const float4*>(res);
+    float4* y4 = reinterpret_cast<float4*>(y);
+#pragma unroll 2
+    for (long long f = f0; f < total4; f += stride) {
+        const float4 xv = x4[f];
+        float v[4] = {fmaf(xv.x, sc[0], sf[0]), fmaf(xv.y, sc[1], sf[1]), fmaf(xv.z, sc[2], sf[2]), fmaf(xv.w, sc[3], sf[3])};
+        if (res) { const float4 r = r4[f]; v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        if (drop_p > 0.f) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (philox_uniform((unsigned long long)(4 * f + k), seed, rng_stream) >= drop_p) ? v[k] * ks : 0.f;
+        }
+        y4[f] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+// column sums of a [P][C] tensor with C % 4 == 0: one float4 per thread and row (colsum_partial_kernel reads one float per lane)
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __restrict__ x, int ld, long long P, int C, long long rows_per_block,
+                                                               float* __restrict__ part) {
+    __shared__ float sh[4][256];
+    const ChanMap4 m = chan_map4(C, blockIdx.y);
+    const long long row0 = blockIdx.x * rows_per_block, row1 = min(P, row0 + rows_per_block);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m.q >= 0) {
+#pragma unroll 4
+        for (long long p = row0 + m.slot; p < row1; p += m.G) { const float4 v = LD4(x, p, ld, m.q); s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[j][threadIdx.x] = s[j];
+    __syncthreads();
+    if (m.q >= 0 && m.slot == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = s[j];
+            for (int g = 1; g < m.G; ++g) a += sh[j][g * m.cq + (m.q - m.q0)];
+            part[(long long)blockIdx.x * C + 4 * m.q + j] = a;
+        }
+    }
+}
+
+// flat kernels apply to dense operands only: every pixel stride equals C, 16-byte aligned bases, P*C a multiple of 4
+static int flat_stride(int C, int64_t P, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+    if (C % 4 == 0 || (P * C) % 4) return 0;
+    for (int l : lds) if (l != C) return 0;
+    for (const void* p : ptrs) if (p && ((uintptr_t)p % 16)) return 0;
+    int g = 1;
+    if (C % 2 == 0) g = 2;
+    const int cp = C / g;
+    return cp <= kFlatThreads / 2 ? kFlatThreads - kFlatThreads % cp : 0;
+}
 static bool vec4_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
     if (C % 4) return false;
     for (int l : lds) if (l % 4) return false;
@@ -958,6 +1141,9 @@ extern "C" int dsrl_bn_stats(const float* x, int ldx, int64_t P, int C, float ep
     const long long rpb = ceil_div(P, nbx);
     if (vec4_ok(C, {ldx}, {x}))
         hipLaunchKernelGGL(bn_partial4_kernel, dim3(nbx, (unsigned)ceil_div(C / 4, 256)), dim3(256), 0, st, x, ldx, (long long)P, C, rpb, (float*)ws, nbx);
+    else if (const int T = flat_stride(C, P, {ldx}, {x}))
+        hipLaunchKernelGGL(bn_partial_flat_kernel, dim3(nbx), dim3(kFlatThreads), 0, st, x, (long long)(P * C / 4), (long long)P, C, T,
+                           (long long)ceil_div(P * C / 4, (int64_t)nbx), (float*)ws, nbx);
     else
         hipLaunchKernelGGL(bn_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ldx, (long long)P, C, rpb, (float*)ws, nbx);
     if (int e = launch_status("bn_partial_kernel")) return e;
@@ -983,6 +1169,9 @@ extern "C" int dsrl_bn_apply(const float* x, int ldx, float* y, int ldy, int64_t
     if (vec4_ok(C, {ldx, ldy, residual ? ldr : 0}, {x, y, residual}))
         hipLaunchKernelGGL(bn_apply4_kernel, apply_grid4(P, C), dim3(256), 0, st, x, ldx, y, ldy, (long long)P, C, mean, invstd, gamma, beta, residual, ldr,
                            relu, drop_p, seed_arg(seed), (unsigned)rng_stream);
+    else if (const int T = flat_stride(C, P, {ldx, ldy, residual ? ldr : C}, {x, y, residual}))
+        hipLaunchKernelGGL(bn_apply_flat_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, ceil_div(P * C / 4, (int64_t)T * 2)))), dim3(kFlatThreads), 0, st,
+                           x, y, (long long)(P * C / 4), C, T, mean, invstd, gamma, beta, residual, relu, drop_p, seed_arg(seed), (unsigned)rng_stream);
     else
         hipLaunchKernelGGL(bn_apply_kernel, apply_grid(P, C), dim3(256), 0, st, x, ldx, y, ldy, (long long)P, C, mean, invstd, gamma, beta, residual, ldr,
                            relu, drop_p, seed_arg(seed), (unsigned)rng_stream);
@@ -1071,6 +1260,9 @@ extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, con
     if (v4)
         hipLaunchKernelGGL(bn_bwd_partial4_kernel, dim3(nbx, (unsigned)ceil_div(C / 4, 256)), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, (long long)P, C, rpb,
                            mean, invstd, relu, drop_p, part, nbx);
+    else if (const int T = flat_stride(C, P, {ldx, y ? ldy : C, lddy}, {x, y, dy}))
+        hipLaunchKernelGGL(bn_bwd_partial_flat_kernel, dim3(nbx), dim3(kFlatThreads), 0, st, x, y, dy, (long long)(P * C / 4), C, T,
+                           (long long)ceil_div(P * C / 4, (int64_t)nbx), mean, invstd, relu, drop_p, part, nbx);
     else
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, (long long)P, C, rpb,
                            mean, invstd, relu, drop_p, part, nbx);
@@ -1111,7 +1303,10 @@ extern "C" int dsrl_colsum(const float* x, int ld, int64_t P, int C, float* out,
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
     const int nbx = row_blocks(P);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ld, (long long)P, C, (long long)ceil_div(P, nbx), (float*)ws);
+    if (vec4_ok(C, {ld}, {x}))
+        hipLaunchKernelGGL(colsum_partial4_kernel, dim3(nbx, (unsigned)ceil_div(C / 4, 256)), dim3(256), 0, st, x, ld, (long long)P, C, (long long)ceil_div(P, nbx), (float*)ws);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nbx, (unsigned)ceil_div(C, 256)), dim3(256), 0, st, x, ld, (long long)P, C, (long long)ceil_div(P, nbx), (float*)ws);
     if (int e = launch_status("colsum_partial_kernel")) return e;
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)ceil_div(C, 32)), dim3(256), 0, st, (const float*)ws, nbx, C, out);
     return launch_status("colsum_finalize_kernel");

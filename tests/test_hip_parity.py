@@ -61,6 +61,19 @@ def test_conv_golden(golden, name):
         check(host(b.grad), g[f'{name}.db'], 1e-5, 'db')
 
 
+@pytest.mark.parametrize('K', [192, 19, 48, 6])
+def test_conv_bias_gradient_column_sums(K):
+    """db of a biased conv = column sums of dy: the float4 kernel (K % 4 == 0: the 192-channel SISR conv, the 48-channel shortcut) and the
+    one-float-per-lane kernel (19 classes), several row blocks, against fp64."""
+    rs = np.random.RandomState(K)
+    x = rs.standard_normal((2, 8, 40, 44)).astype(np.float32); w = (rs.standard_normal((K, 8, 1, 1)) * 0.3).astype(np.float32); b = rs.standard_normal(K).astype(np.float32)
+    xt = dev(x).requires_grad_(True); wt = dev(w).requires_grad_(True); bt = dev(b).requires_grad_(True)
+    y = HF.conv2d(xt, wt, bt, 1, 0, 1)
+    dy = rs.standard_normal((2, K, 40, 44)).astype(np.float32)
+    y.backward(dev(dy))
+    check(host(bt.grad), dy.astype(np.float64).sum((0, 2, 3)), 1e-5, 'db')
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'bf16x6', 'mixed', 'bf16x3'])
 @pytest.mark.parametrize('shape', [(2, 304, 32, 64, 192, 3, 1, 1, 1), (2, 512, 16, 32, 256, 3, 1, 6, 6), (2, 256, 33, 47, 100, 3, 2, 1, 1),
                                    (4, 1024, 16, 32, 256, 1, 1, 0, 1)])
@@ -230,10 +243,14 @@ def test_batchnorm_golden(golden, mode):
     assert int(bn.state_dict()['num_batches_tracked']) == (1 if mode == 'train' else 0)
 
 
-@pytest.mark.parametrize('C', [1, 19, 48, 256, 304, 2048])
+@pytest.mark.parametrize('C', [1, 19, 48, 256, 304, 2048, (2, 19, 128, 128), (4, 6, 9, 10), (1, 1, 64, 128), (3, 19, 5, 7), (2, 3, 66, 34)])
 def test_batchnorm_relu_dropout_residual_vs_oracle(C):
-    rs = np.random.RandomState(C)
-    x = (rs.standard_normal((2, C, 6, 10)) * 2 + 0.5).astype(np.float32); res = rs.standard_normal(x.shape).astype(np.float32)
+    # channel counts that are not multiples of 4 run the "flat" 16-byte kernels when the tensor is dense and P*C % 4 == 0 (19 classes with
+    # several float4 strides per thread, 6 = the gcd-2 case, 1 and 3 channels) and the one-float-per-lane kernels otherwise ((3, 19, 5, 7))
+    shape = C if isinstance(C, tuple) else (2, C, 6, 10)
+    C = shape[1]
+    rs = np.random.RandomState(C + shape[2])
+    x = (rs.standard_normal(shape) * 2 + 0.5).astype(np.float32); res = rs.standard_normal(x.shape).astype(np.float32)
     gamma = rs.uniform(0.5, 1.5, C).astype(np.float32); beta = rs.standard_normal(C).astype(np.float32)
     bn = D.nn_modules.HipBatchNorm2d(C).to(DEV)
     with torch.no_grad():
