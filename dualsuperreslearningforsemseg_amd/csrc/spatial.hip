@@ -36,6 +36,29 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
     }
 }
 
+// four channels per thread (C, the pixel strides % 4 == 0, 16-byte aligned bases): the index arithmetic is paid once per float4 and in 32 bits;
+// the arithmetic per element is the scalar kernel's, so the results are bit-identical
+__global__ __launch_bounds__(256) void bilinear_fwd4_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                             int N, int H, int W, int C4, int Ho, int Wo, float sh, float sw) {
+    const unsigned total = (unsigned)N * Ho * Wo * C4;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned q = e % C4; unsigned pix = e / C4;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho), n = (int)(pix / Ho);
+        int h0, hp, w0, wp; float lh, lw;
+        ac_src(ho, sh, H, h0, hp, lh); ac_src(wo, sw, W, w0, wp, lw);
+        const float* b = x + ((long long)(n * H + h0) * W + w0) * ldx + 4 * q;
+        const float4 x00 = *reinterpret_cast<const float4*>(b), x01 = *reinterpret_cast<const float4*>(b + (long long)wp * ldx);
+        const float4 x10 = *reinterpret_cast<const float4*>(b + (long long)hp * W * ldx), x11 = *reinterpret_cast<const float4*>(b + ((long long)hp * W + wp) * ldx);
+        float4 v;
+        v.x = (1.f - lh) * ((1.f - lw) * x00.x + lw * x01.x) + lh * ((1.f - lw) * x10.x + lw * x11.x);
+        v.y = (1.f - lh) * ((1.f - lw) * x00.y + lw * x01.y) + lh * ((1.f - lw) * x10.y + lw * x11.y);
+        v.z = (1.f - lh) * ((1.f - lw) * x00.z + lw * x01.z) + lh * ((1.f - lw) * x10.z + lw * x11.z);
+        v.w = (1.f - lh) * ((1.f - lw) * x00.w + lw * x01.w) + lh * ((1.f - lw) * x10.w + lw * x11.w);
+        *reinterpret_cast<float4*>(y + ((long long)(n * Ho + ho) * Wo + wo) * ldy + 4 * q) = v;
+    }
+}
+
 __device__ inline float ac_weight(int dst, float scale, int n_in, int src) {
     int i0, ip; float l1;
     ac_src(dst, scale, n_in, i0, ip, l1);
@@ -85,6 +108,47 @@ __global__ __launch_bounds__(256) void bilinear_bwd_h_kernel(const float* __rest
             if (wh != 0.f) acc += wh * tmp[(((long long)n * Ho + ho) * W + w) * C + c];
         }
         dx[((long long)(n * H + h) * W + w) * lddx + c] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void bilinear_bwd_w4_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ tmp,
+                                                               int N, int W, int C4, int Ho, int Wo, float sw) {
+    const unsigned total = (unsigned)N * Ho * W * C4;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned q = e % C4, pix = e / C4;
+        const int w = (int)(pix % W); const unsigned row = pix / W;          // row = n*Ho + ho
+        int wlo, whi;
+        ac_range(w, sw, Wo, wlo, whi);
+        const float* r = dy + (long long)row * Wo * lddy + 4 * q;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int wo = wlo; wo <= whi; ++wo) {
+            const float ww = ac_weight(wo, sw, W, w);
+            if (ww != 0.f) {
+                const float4 v = *reinterpret_cast<const float4*>(r + (long long)wo * lddy);
+                acc.x += ww * v.x; acc.y += ww * v.y; acc.z += ww * v.z; acc.w += ww * v.w;
+            }
+        }
+        *reinterpret_cast<float4*>(tmp + 4ll * e) = acc;
+    }
+}
+__global__ __launch_bounds__(256) void bilinear_bwd_h4_kernel(const float* __restrict__ tmp, float* __restrict__ dx, int lddx,
+                                                               int N, int H, int W, int C4, int Ho, float sh) {
+    const unsigned total = (unsigned)N * H * W * C4;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned q = e % C4; unsigned pix = e / C4;
+        const int w = (int)(pix % W); pix /= W;
+        const int h = (int)(pix % H), n = (int)(pix / H);
+        int hlo, hhi;
+        ac_range(h, sh, Ho, hlo, hhi);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ho = hlo; ho <= hhi; ++ho) {
+            const float wh = ac_weight(ho, sh, H, h);
+            if (wh != 0.f) {
+                const float4 v = *reinterpret_cast<const float4*>(tmp + ((((long long)n * Ho + ho) * W + w) * C4 + q) * 4);
+                acc.x += wh * v.x; acc.y += wh * v.y; acc.z += wh * v.z; acc.w += wh * v.w;
+            }
+        }
+        *reinterpret_cast<float4*>(dx + ((long long)(n * H + h) * W + w) * lddx + 4 * q) = acc;
     }
 }
 
@@ -152,6 +216,57 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
                 if (idx[o] == tap) acc += dy[o];
             }
         dx[e] = acc;
+    }
+}
+
+// four channels per thread (C % 4 == 0): float4 data, the four argmax bytes as one word; per-element arithmetic as above (bit-identical)
+__global__ __launch_bounds__(256) void maxpool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
+                                                            int N, int H, int W, int C4, int Ho, int Wo) {
+    const unsigned total = (unsigned)N * Ho * Wo * C4;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned q = e % C4; unsigned pix = e / C4;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho), n = (int)(pix / Ho);
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}; unsigned bi[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int h = 2 * ho - 1 + r;
+            if (h < 0 || h >= H) continue;
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) {
+                const int w = 2 * wo - 1 + s_;
+                if (w < 0 || w >= W) continue;
+                const float4 v4 = *reinterpret_cast<const float4*>(x + (((long long)(n * H + h) * W + w) * C4 + q) * 4);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; bi[k] = (unsigned)(r * 3 + s_); }
+            }
+        }
+        *reinterpret_cast<float4*>(y + 4ll * e) = make_float4(best[0], best[1], best[2], best[3]);
+        if (idx) *reinterpret_cast<unsigned*>(idx + 4ll * e) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+}
+__global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const unsigned char* __restrict__ idx, const float* __restrict__ dy, float* __restrict__ dx,
+                                                            int N, int H, int W, int C4, int Ho, int Wo) {
+    const unsigned total = (unsigned)N * H * W * C4;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned q = e % C4; unsigned pix = e / C4;
+        const int w = (int)(pix % W); pix /= W;
+        const int h = (int)(pix % H), n = (int)(pix / H);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ho = max(0, h / 2); ho <= min(Ho - 1, (h + 1) / 2); ++ho)
+            for (int wo = max(0, w / 2); wo <= min(Wo - 1, (w + 1) / 2); ++wo) {
+                const long long o = (((long long)(n * Ho + ho) * Wo + wo) * C4 + q) * 4;
+                const unsigned tap = (unsigned)((h - (2 * ho - 1)) * 3 + (w - (2 * wo - 1)));
+                const unsigned ib = *reinterpret_cast<const unsigned*>(idx + o);
+                const float4 g = *reinterpret_cast<const float4*>(dy + o);
+                if ((ib & 255u) == tap) acc[0] += g.x;
+                if (((ib >> 8) & 255u) == tap) acc[1] += g.y;
+                if (((ib >> 16) & 255u) == tap) acc[2] += g.z;
+                if ((ib >> 24) == tap) acc[3] += g.w;
+            }
+        *reinterpret_cast<float4*>(dx + 4ll * e) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
@@ -534,6 +649,39 @@ __global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float* __restr
     }
 }
 
+// Tiled through LDS: a block takes 32 consecutive pixels of one (n, h) row. Both sides are then contiguous in memory - the 32 records of
+// C = c*r*r floats on one side, r row segments of 32*r*c floats on the other - and the permutation happens in LDS ([pixel][channel][r*r + 1]:
+// the odd channel stride keeps the c planes of a pixel on different banks). Same values as the gather kernel above, only the traffic differs.
+constexpr int kPsTile = 32;
+__global__ __launch_bounds__(256) void pixel_shuffle_tiled_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H, int W, int c, int r, int inverse) {
+    extern __shared__ float tile[];                               // [kPsTile][c][r*r + 1]
+    const int rr = r * r, C = c * rr, cs = rr + 1, ps = c * cs;
+    const int tiles_w = (W + kPsTile - 1) / kPsTile;
+    const int tw = blockIdx.x % tiles_w, row = blockIdx.x / tiles_w;          // row = n*H + h
+    const int w0 = tw * kPsTile, npx = min(kPsTile, W - w0);
+    const int n = row / H, h = row % H;
+    const long long rec = ((long long)row * W + w0) * C;                     // first record of the tile in the (N,H,W,C) tensor
+    const int seg = npx * r * c;                                             // floats of one shuffled row segment
+    const long long Wr = (long long)W * r;
+    if (!inverse) {
+        for (int t = threadIdx.x; t < npx * C; t += 256) { const int px = t / C, k = t % C; tile[px * ps + (k / rr) * cs + k % rr] = src[rec + t]; }
+    } else {
+        for (int i = 0; i < r; ++i) {
+            const float* in = src + (((long long)(n * H + h) * r + i) * Wr + (long long)w0 * r) * c;
+            for (int t = threadIdx.x; t < seg; t += 256) { const int wl = t / (r * c), rem = t % (r * c), j = rem / c, ch = rem % c; tile[wl * ps + ch * cs + i * r + j] = in[t]; }
+        }
+    }
+    __syncthreads();
+    if (!inverse) {
+        for (int i = 0; i < r; ++i) {
+            float* out = dst + (((long long)(n * H + h) * r + i) * Wr + (long long)w0 * r) * c;
+            for (int t = threadIdx.x; t < seg; t += 256) { const int wl = t / (r * c), rem = t % (r * c), j = rem / c, ch = rem % c; out[t] = tile[wl * ps + ch * cs + i * r + j]; }
+        }
+    } else {
+        for (int t = threadIdx.x; t < npx * C; t += 256) { const int px = t / C, k = t % C; dst[rec + t] = tile[px * ps + (k / rr) * cs + k % rr]; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- 1x1 stride-s, single output
 __global__ __launch_bounds__(256) void pointwise_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
                                                              int N, int H, int W, int C, int s, int Ho, int Wo) {
@@ -612,6 +760,10 @@ static float ac_scale(int n_in, int n_out) { return n_out > 1 ? (float)(n_in - 1
 
 extern "C" int dsrl_bilinear_ac_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int Ho, int Wo, dsrl_stream_t stream) {
     DSRL_PROLOGUE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && ldx >= C && ldy >= C, "bilinear_ac_fwd")
+    if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (long long)N * Ho * Wo * C < (1ll << 32)) {
+        hipLaunchKernelGGL(bilinear_fwd4_kernel, dim3(flat_grid((long long)N * Ho * Wo * (C / 4))), dim3(256), 0, st, x, ldx, y, ldy, N, H, W, C / 4, Ho, Wo, ac_scale(H, Ho), ac_scale(W, Wo));
+        return launch_status("bilinear_fwd4_kernel");
+    }
     hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(flat_grid((long long)N * Ho * Wo * C)), dim3(256), 0, st, x, ldx, y, ldy, N, H, W, C, Ho, Wo, ac_scale(H, Ho), ac_scale(W, Wo));
     return launch_status("bilinear_fwd_kernel");
 }
@@ -620,6 +772,13 @@ extern "C" int dsrl_bilinear_ac_bwd(const float* dy, int lddy, float* dx, int ld
                                     void* ws, size_t ws_bytes, dsrl_stream_t stream) {
     DSRL_PROLOGUE(dy && dx && ws && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && lddy >= C && lddx >= C, "bilinear_ac_bwd")
     DSRL_REQUIRE(ws_bytes >= dsrl_bilinear_ac_bwd_workspace_bytes(N, H, W, C, Ho, Wo), DSRL_E_WORKSPACE, "bilinear_ac_bwd: workspace too small");
+    if (C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)ws % 16) == 0 &&
+        (long long)N * Ho * std::max(W, Wo) * C < (1ll << 32)) {
+        hipLaunchKernelGGL(bilinear_bwd_w4_kernel, dim3(flat_grid((long long)N * Ho * W * (C / 4))), dim3(256), 0, st, dy, lddy, (float*)ws, N, W, C / 4, Ho, Wo, ac_scale(W, Wo));
+        if (int e = launch_status("bilinear_bwd_w4_kernel")) return e;
+        hipLaunchKernelGGL(bilinear_bwd_h4_kernel, dim3(flat_grid((long long)N * H * W * (C / 4))), dim3(256), 0, st, (const float*)ws, dx, lddx, N, H, W, C / 4, Ho, ac_scale(H, Ho));
+        return launch_status("bilinear_bwd_h4_kernel");
+    }
     hipLaunchKernelGGL(bilinear_bwd_w_kernel, dim3(flat_grid((long long)N * Ho * W * C)), dim3(256), 0, st, dy, lddy, (float*)ws, N, W, C, Ho, Wo, ac_scale(W, Wo));
     if (int e = launch_status("bilinear_bwd_w_kernel")) return e;
     hipLaunchKernelGGL(bilinear_bwd_h_kernel, dim3(flat_grid((long long)N * H * W * C)), dim3(256), 0, st, (const float*)ws, dx, lddx, N, H, W, C, Ho, ac_scale(H, Ho));
@@ -638,12 +797,20 @@ extern "C" int dsrl_global_avgpool_bwd(const float* dy, float* dx, int lddx, int
 extern "C" int dsrl_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, dsrl_stream_t stream) {
     DSRL_PROLOGUE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "maxpool3x3s2_fwd")
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if (C % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)argmax % 4) == 0 && (long long)N * H * W * C < (1ll << 32)) {
+        hipLaunchKernelGGL(maxpool_fwd4_kernel, dim3(flat_grid((long long)N * Ho * Wo * (C / 4))), dim3(256), 0, st, x, y, argmax, N, H, W, C / 4, Ho, Wo);
+        return launch_status("maxpool_fwd4_kernel");
+    }
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(flat_grid((long long)N * Ho * Wo * C)), dim3(256), 0, st, x, y, argmax, N, H, W, C, Ho, Wo);
     return launch_status("maxpool_fwd_kernel");
 }
 extern "C" int dsrl_maxpool3x3s2_bwd(const uint8_t* argmax, const float* dy, float* dx, int N, int H, int W, int C, dsrl_stream_t stream) {
     DSRL_PROLOGUE(argmax && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool3x3s2_bwd")
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if (C % 4 == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)argmax % 4) == 0 && (long long)N * H * W * C < (1ll << 32)) {
+        hipLaunchKernelGGL(maxpool_bwd4_kernel, dim3(flat_grid((long long)N * H * W * (C / 4))), dim3(256), 0, st, argmax, dy, dx, N, H, W, C / 4, Ho, Wo);
+        return launch_status("maxpool_bwd4_kernel");
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(flat_grid((long long)N * H * W * C)), dim3(256), 0, st, argmax, dy, dx, N, H, W, C, Ho, Wo);
     return launch_status("maxpool_bwd_kernel");
 }
@@ -695,13 +862,25 @@ extern "C" int dsrl_convt2x2_bwd(const float* x, const float* w, const float* dy
     return DSRL_E_UNSUPPORTED;
 }
 
+static size_t pixel_shuffle_tile_bytes(int c, int r) { return (size_t)kPsTile * c * (r * r + 1) * sizeof(float); }
+static bool pixel_shuffle_tiled_ok(int N, int H, int W, int c, int r) {
+    return pixel_shuffle_tile_bytes(c, r) <= 48 * 1024 && (long long)N * H * ceil_div(W, kPsTile) < (1ll << 31) && (long long)W * r * c < (1ll << 31);
+}
 extern "C" int dsrl_pixel_shuffle_fwd(const float* x, float* y, int N, int H, int W, int c, int r, dsrl_stream_t stream) {
     DSRL_PROLOGUE(x && y && N > 0 && H > 0 && W > 0 && c > 0 && r > 0, "pixel_shuffle_fwd")
+    if (pixel_shuffle_tiled_ok(N, H, W, c, r)) {
+        hipLaunchKernelGGL(pixel_shuffle_tiled_kernel, dim3((unsigned)((long long)N * H * ceil_div(W, kPsTile))), dim3(256), pixel_shuffle_tile_bytes(c, r), st, x, y, N, H, W, c, r, 0);
+        return launch_status("pixel_shuffle_tiled_kernel");
+    }
     hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(flat_grid((long long)N * H * W * c * r * r)), dim3(256), 0, st, x, y, N, H, W, c, r, 0);
     return launch_status("pixel_shuffle_kernel");
 }
 extern "C" int dsrl_pixel_shuffle_bwd(const float* dy, float* dx, int N, int H, int W, int c, int r, dsrl_stream_t stream) {
     DSRL_PROLOGUE(dy && dx && N > 0 && H > 0 && W > 0 && c > 0 && r > 0, "pixel_shuffle_bwd")
+    if (pixel_shuffle_tiled_ok(N, H, W, c, r)) {
+        hipLaunchKernelGGL(pixel_shuffle_tiled_kernel, dim3((unsigned)((long long)N * H * ceil_div(W, kPsTile))), dim3(256), pixel_shuffle_tile_bytes(c, r), st, dy, dx, N, H, W, c, r, 1);
+        return launch_status("pixel_shuffle_tiled_kernel");
+    }
     hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(flat_grid((long long)N * H * W * c * r * r)), dim3(256), 0, st, dy, dx, N, H, W, c, r, 1);
     return launch_status("pixel_shuffle_kernel");
 }

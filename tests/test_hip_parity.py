@@ -216,6 +216,24 @@ def test_bilinear_golden(golden, name):
     check(host(x.grad), g[f'{name}.dx'], 1e-5)
 
 
+@pytest.mark.parametrize('shape,r', [((2, 192, 5, 40), 8), ((1, 12, 3, 70), 2), ((2, 27, 4, 33), 3), ((1, 2048, 2, 3), 32)])
+def test_pixel_shuffle_vs_oracle_ragged(shape, r):
+    # the LDS-tiled kernel: tiles of 32 pixels with a ragged last tile (40 = 32 + 8, 70, 33), several upscale factors; r = 32 exceeds the
+    # tile's LDS budget and takes the gather kernel. A permutation: exact.
+    rs = np.random.RandomState(r)
+    x = rs.standard_normal(shape).astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    y = HF.pixel_shuffle(xt, r)
+    yo = O.pixel_shuffle(x, r)
+    assert np.array_equal(host(y), yo)
+    dy = rs.standard_normal(yo.shape).astype(np.float32)
+    y.backward(dev(dy))
+    N, C, H, W = shape
+    c = C // (r * r)
+    dxo = dy.reshape(N, c, H, r, W, r).transpose(0, 1, 3, 5, 2, 4).reshape(N, C, H, W)
+    assert np.array_equal(host(xt.grad), dxo)
+
+
 def test_pixel_shuffle_golden(golden):
     g = golden('ops_micro')
     x = dev(g['pixel_shuffle.x']).requires_grad_(True)
