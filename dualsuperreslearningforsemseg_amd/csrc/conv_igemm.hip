@@ -685,31 +685,48 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
 
 // The same for every conv filter of the model in ONE launch: table[i] = {w, wt, K, Kp, RS, C, first tile, tiles along C} as int64;
 // blockIdx.x = global 32x32 tile index, located in the table by bisection on the first-tile column.
-__global__ void weight_transpose_batched_kernel(const long long* __restrict__ table, int n) {
-    __shared__ float tile[32][33];
+constexpr int kWtTilesPerBlock = 4;
+// A block transposes kWtTilesPerBlock consecutive 32x32 tiles (consecutive ids are neighbours along C: contiguous reads): one bisection over
+// the rows of the table per block instead of per 4 KB tile, four times the bytes in flight per block.
+__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const long long* __restrict__ table, int n, long long total_tiles) {
+    __shared__ float tile[kWtTilesPerBlock][32][33];
+    const long long b0 = (long long)blockIdx.x * kWtTilesPerBlock;
     int lo = 0, hi = n - 1;
-    const long long b = blockIdx.x;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (table[mid * 8 + 6] <= b) lo = mid; else hi = mid - 1;
+        if (table[mid * 8 + 6] <= b0) lo = mid; else hi = mid - 1;
     }
-    const long long* e = table + lo * 8;
-    const float* w = reinterpret_cast<const float*>(e[0]);
-    float* wt = reinterpret_cast<float*>(e[1]);
-    const int K = (int)e[2], Kp = (int)e[3], RS = (int)e[4], C = (int)e[5], ct = (int)e[7];
-    const int kt = (Kp + 31) / 32;
-    int t = (int)(b - e[6]);
-    const int tap = t / (ct * kt); t -= tap * ct * kt;
-    const int k0 = (t / ct) * 32, c0 = (t % ct) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int r = ty; r < 32; r += 8) {
-        const int k = k0 + r, c = c0 + tx;
-        tile[r][tx] = (k < K && c < C) ? w[((long long)k * RS + tap) * C + c] : 0.f;
+    float* dst[kWtTilesPerBlock]; int dC[kWtTilesPerBlock], dKp[kWtTilesPerBlock], dc0[kWtTilesPerBlock], dk0[kWtTilesPerBlock], dRS[kWtTilesPerBlock], dtap[kWtTilesPerBlock];
+#pragma unroll
+    for (int u = 0; u < kWtTilesPerBlock; ++u) {
+        const long long b = b0 + u;
+        dst[u] = nullptr;
+        if (b >= total_tiles) continue;
+        while (lo + 1 < n && table[(lo + 1) * 8 + 6] <= b) ++lo;            // the next tile may belong to the next filter
+        const long long* e = table + lo * 8;
+        const float* w = reinterpret_cast<const float*>(e[0]);
+        const int K = (int)e[2], Kp = (int)e[3], RS = (int)e[4], C = (int)e[5], ct = (int)e[7];
+        const int kt = (Kp + 31) / 32;
+        int t = (int)(b - e[6]);
+        const int tap = t / (ct * kt); t -= tap * ct * kt;
+        const int k0 = (t / ct) * 32, c0 = (t % ct) * 32;
+        dst[u] = reinterpret_cast<float*>(e[1]); dC[u] = C; dKp[u] = Kp; dc0[u] = c0; dk0[u] = k0; dRS[u] = RS; dtap[u] = tap;
+#pragma unroll
+        for (int r = ty; r < 32; r += 8) {
+            const int k = k0 + r, c = c0 + tx;
+            tile[u][r][tx] = (k < K && c < C) ? w[((long long)k * RS + tap) * C + c] : 0.f;
+        }
     }
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int c = c0 + r, k = k0 + tx;
-        if (c < C && k < Kp) wt[((long long)c * RS + tap) * Kp + k] = tile[tx][r];
+#pragma unroll
+    for (int u = 0; u < kWtTilesPerBlock; ++u) {
+        if (dst[u] == nullptr) continue;
+#pragma unroll
+        for (int r = ty; r < 32; r += 8) {
+            const int c = dc0[u] + r, k = dk0[u] + tx;
+            if (c < dC[u] && k < dKp[u]) dst[u][((long long)c * dRS[u] + dtap[u]) * dKp[u] + k] = tile[u][tx][r];      // k in [K,Kp): zero padding
+        }
     }
 }
 
@@ -1590,7 +1607,8 @@ extern "C" int dsrl_conv2d_transpose_filters_batched(const int64_t* table, int n
     DSRL_REQUIRE(table && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31), DSRL_E_BADARG, "conv2d_transpose_filters_batched: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
-    hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, (const long long*)table, n);
+    hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)ceil_div(total_tiles, (int64_t)kWtTilesPerBlock)), dim3(256), 0, st, (const long long*)table, n,
+                       (long long)total_tiles);
     return launch_status("weight_transpose_batched_kernel");
 }
 

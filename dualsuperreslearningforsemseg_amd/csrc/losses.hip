@@ -147,15 +147,16 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const float* __restrict__
             float* v = tile + threadIdx.x * C;
             float m = v[0];
             for (int c = 1; c < C; ++c) m = fmaxf(m, v[c]);
+            const float vt = v[min(tg == ignore_index ? 0 : tg, C - 1)];
             float s = 0.f;
-            for (int c = 0; c < C; ++c) s += expf(v[c] - m);
+            for (int c = 0; c < C; ++c) { const float e = expf(v[c] - m); s += e; v[c] = e; }       // the tile keeps exp(v - m): one expf per logit
             bad |= !(s == s);                   // any NaN logit poisons the sum (fmaxf alone would skip it)
             if (tg != ignore_index) {
-                loss += (double)(m + logf(s) - v[min(tg, C - 1)]);
+                loss += (double)(m + logf(s) - vt);
                 cnt += 1.0;
                 if (dl) {
                     const float inv = scale / s;
-                    for (int c = 0; c < C; ++c) v[c] = expf(v[c] - m) * inv - (c == tg ? scale : 0.f);
+                    for (int c = 0; c < C; ++c) v[c] = v[c] * inv - (c == tg ? scale : 0.f);
                 }
             } else if (dl) {
                 for (int c = 0; c < C; ++c) v[c] = 0.f;
