@@ -50,7 +50,20 @@ struct ConvArgs {
     // partial sums of g = dy * [y > 0] and g * xhat per (row block, channel) in bstats [2][parts][K] (null: off)
     const float* bn_x; const float* bn_y; const float* bn_mean; const float* bn_invstd; float* bstats;
     int bn_ldx, bn_ldy, bn_relu;
+    // split kernels, dgrad of a strided conv (par = stride > 1, else 0): the GEMM rows are ordered by parity class - M-tile t (pbm rows) holds
+    // rows (t / par^2) * pbm ... of class (ph, pw) = t % par^2, a class row j being pixel (n, hh*par + ph, wh*par + pw), (n, hh, wh) = j over the
+    // Hh x Wh grid of the class - so that all rows of a tile share the taps that divide evenly (a row-major tile multiplies zeros for the
+    // other par^2 - 1 of par^2 taps per row), and consecutive tiles cycle through the classes (their tap counts differ: 4, 2, 2, 1 of 9).
+    // Host side: Ho % par == Wo % par == 0, pixels per class % pbm == 0 (a tile never straddles classes), Wh % 32 == 0 (32 consecutive rows
+    // are 32 consecutive pixels of one image row of the class: the epilogue derives their offsets from the first one).
+    int par, Hh, Wh, pbm;
 };
+__device__ __forceinline__ int dgrad_pix(const ConvArgs& a, int m) {        // row of the parity-ordered GEMM -> pixel index (n*Ho + h)*Wo + w
+    const int t = m / a.pbm, p2 = a.par * a.par, c = t % p2, j = (t / p2) * a.pbm + (m - t * a.pbm);
+    const int hw = a.Hh * a.Wh, n = j / hw, r = j - n * hw, hh = r / a.Wh, wh = r - hh * a.Wh;
+    const int ph = c / a.par, pw = c - ph * a.par;
+    return (n * a.Ho + hh * a.par + ph) * a.Wo + wh * a.par + pw;
+}
 
 // Blocks are dealt round-robin over the 8 XCDs (private L2 each). Remap the linear block id so that every XCD works on a contiguous
 // range of tile ids (bijective for any count): tiles that share input rows then hit the same L2. Speed only, never correctness.
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
     for (int i = 0; i < A_IT; ++i) {
         const int m = m0 + r0 + 64 * i;
         a_ok[i] = m < a.M;
-        const int mm = a_ok[i] ? m : 0;
+        const int mm = a_ok[i] ? ((DGRAD && a.par) ? dgrad_pix(a, m) : m) : 0;
         const int n = mm / HoWo, rem = mm - n * HoWo;
         const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
         a_n[i] = n;
@@ -362,12 +375,16 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
             hf = (mf - nf * HoWo) / a.Wo; hl = (ml - nl * HoWo) / a.Wo;
             if (hf == hl) { wf = (mf - nf * HoWo) - hf * a.Wo; wl = (ml - nl * HoWo) - hl * a.Wo; }
         }
+        const int pcls = (DGRAD && a.par) ? (m0 / BM) % (a.par * a.par) : 0;  // parity class of this tile
+        const int ph = (DGRAD && a.par) ? pcls / a.par : 0, pw = (DGRAD && a.par) ? pcls - ph * a.par : 0;
+        if (DGRAD && a.par) { hf = 0; hl = a.Ho - 1; wf = 0; wl = a.Wo - 1; }     // the row range of a parity-ordered tile is not an interval: no bounds pruning
         for (int r = 0; r < a.R; ++r)
             for (int s = 0; s < a.S; ++s) {
                 bool act;
                 if (DGRAD) {
                     act = (hl + a.pad - r * a.dil >= 0) && (hf + a.pad - r * a.dil <= (a.H - 1) * a.stride) &&
                           (wl + a.pad - s * a.dil >= 0) && (wf + a.pad - s * a.dil <= (a.W - 1) * a.stride);
+                    if (a.par) act = act && ((ph + a.pad - r * a.dil) % a.par == 0) && ((pw + a.pad - s * a.dil) % a.par == 0);
                 } else {
                     act = (hl * a.stride - a.pad + r * a.dil >= 0) && (hf * a.stride - a.pad + r * a.dil <= a.H - 1) &&
                           (wl * a.stride - a.pad + s * a.dil >= 0) && (wf * a.stride - a.pad + s * a.dil <= a.W - 1);
@@ -564,13 +581,15 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
         const float bv = (a.bias != nullptr && kok) ? a.bias[k] : 0.f;
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
-            const int mb = m0 + (wm * MR + i) * 32 + rq;
+            const int mb32 = m0 + (wm * MR + i) * 32, mb = mb32 + rq;
+            // pixel of row m of this 32-row block: m itself, or (parity-ordered dgrad) 32 consecutive pixels of one class: stride par apart
+            const int pix0 = (DGRAD && a.par) ? dgrad_pix(a, min(mb32, a.M - 1)) : mb32, pst = (DGRAD && a.par) ? a.par : 1;
             if (a.accumulate && a.splits == 1) {        // y += result: all 16 old values of the tile are fetched before the first store
                 float old[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = mb + (e & 3) + 8 * (e >> 2);
-                    const unsigned off = (kok && m < a.M) ? ((unsigned)m * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
+                    const unsigned off = (kok && m < a.M) ? ((unsigned)(pix0 + (m - mb32) * pst) * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
                     old[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, (int)off, 0, 0));     // out-of-bounds offsets read 0
                 }
 #pragma unroll
@@ -579,7 +598,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = mb + (e & 3) + 8 * (e >> 2);
-                const unsigned off = (kok && m < a.M) ? ((unsigned)m * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
+                const unsigned off = (kok && m < a.M) ? ((unsigned)(pix0 + (m - mb32) * pst) * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e] + bv), yr, (int)off, 0, 0);
             }
         }
@@ -599,12 +618,15 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
                 float xv[16], yv[16];
+                const int mb32 = m0 + (wm * MR + i) * 32;
+                const int pix0 = a.par ? dgrad_pix(a, min(mb32, a.M - 1)) : mb32, pst = a.par ? a.par : 1;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {          // all loads of the tile first
-                    const int m = m0 + (wm * MR + i) * 32 + rq + (e & 3) + 8 * (e >> 2);
+                    const int m = mb32 + rq + (e & 3) + 8 * (e >> 2);
                     const bool ok = kok && m < a.M;
-                    xv[e] = ok ? a.bn_x[(long long)m * a.bn_ldx + k] : 0.f;
-                    yv[e] = (ok && a.bn_relu) ? a.bn_y[(long long)m * a.bn_ldy + k] : 1.f;
+                    const long long px = pix0 + (m - mb32) * pst;
+                    xv[e] = ok ? a.bn_x[px * a.bn_ldx + k] : 0.f;
+                    yv[e] = (ok && a.bn_relu) ? a.bn_y[px * a.bn_ldy + k] : 1.f;
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -1653,6 +1675,12 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
         return launch_status("splitk_reduce_kernel");
     }
     a.y = dx; a.ldy = lddx; a.bias = nullptr; a.accumulate = accumulate;
+    if (stride > 1 && conv_planes(PASS_DGRAD) && H % stride == 0 && W % stride == 0 && (W / stride) % 32 == 0 && env_int("DSRL_DGRAD_PARITY", 1)) {
+        // rows ordered by parity class (ConvArgs::par): a tile then only runs the taps that divide evenly for its class
+        int bm, bn_; cfg_dims(p.cfg, bm, bn_);
+        const long long Mc = (long long)N * (H / stride) * (W / stride);
+        if (Mc % bm == 0) { a.par = stride; a.Hh = H / stride; a.Wh = W / stride; a.pbm = bm; }
+    }
     if (bn) { a.bn_x = bn->x; a.bn_y = bn->y; a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bstats = bn->stats; a.bn_ldx = bn->ldx; a.bn_ldy = bn->ldy; a.bn_relu = bn->relu; }
     return launch_igemm<true>(a, p.cfg, st);
 }

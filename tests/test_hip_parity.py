@@ -108,9 +108,48 @@ def test_pointwise_strided_golden(golden):
     check(host(x.grad), g['conv_s8.dx'], 1e-5); check(host(w.grad), g['conv_s8.dw'], 1e-5)
 
 
+@pytest.mark.parametrize('shape', [(2, 128, 8, 64, 128, 3, 2, 1, 1), (2, 256, 8, 128, 512, 1, 2, 0, 1), (4, 64, 16, 64, 64, 3, 2, 1, 1)])
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_strided_dgrad_parity_order(shape, accumulate, monkeypatch):
+    """Data gradient of the stride-2 convs (layer2.0 / layer3.0 conv2 and downsample shapes at small N, H): with the GEMM rows ordered by
+    parity class (ConvArgs::par) a tile runs only the taps that divide evenly for its class. The multiply-adds it drops act on zeros, so the
+    gradient is BIT-identical to the row-major launch (DSRL_DGRAD_PARITY=0); the BatchNorm-backward partials of the epilogue
+    (dsrl_conv2d_dgrad_bnstats) are sums over other row blocks: equal in total up to summation order. Also against the fp64 oracle."""
+    N, C, H, W, K, R, stride, pad, dil = shape
+    rs = np.random.RandomState(sum(shape))
+    Ho, Wo = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1, (W + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    w = (rs.standard_normal((K, C, R, R)) / np.sqrt(C * R * R)).astype(np.float32)
+    dy = rs.standard_normal((N, K, Ho, Wo)).astype(np.float32)
+    bx = rs.standard_normal((N, C, H, W)).astype(np.float32); by = np.maximum(rs.standard_normal((N, C, H, W)), 0).astype(np.float32)
+    mean = rs.standard_normal(C).astype(np.float32); invstd = rs.uniform(0.5, 2.0, C).astype(np.float32)
+    old = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    wt, dyt = dev(w), dev(dy)
+    bxt, byt, mt, it = dev(bx), dev(by), dev(mean), dev(invstd)
+    shp = (N, H, W, C, K, R, R, stride, pad, dil)
+    res = {}
+    for par in ('1', '0'):
+        monkeypatch.setenv('DSRL_DGRAD_PARITY', par)
+        parts = int(HF.query('dsrl_conv2d_dgrad_stats_parts', *shp))
+        assert parts > 0
+        dx = dev(old).clone(memory_format=torch.channels_last) if accumulate else torch.empty((N, C, H, W), device=DEV).contiguous(memory_format=torch.channels_last)
+        bst = torch.zeros(2 * parts * C, device=DEV)
+        ws = torch.empty(int(HF.cquery('dsrl_conv2d_dgrad_workspace_bytes', *shp)) + 256, dtype=torch.uint8, device=DEV)
+        HF.call('dsrl_conv2d_dgrad_bnstats', dyt.data_ptr(), K, wt.data_ptr(), None, dx.data_ptr(), C, *shp, ws.data_ptr(), ws.numel(),
+                bxt.data_ptr(), C, byt.data_ptr(), C, mt.data_ptr(), it.data_ptr(), 1, bst.data_ptr(), parts, int(accumulate), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        res[par] = (host(dx), bst.view(2, parts, C).double().sum(1).cpu().numpy())
+    assert np.array_equal(res['1'][0], res['0'][0])
+    dxo = O.conv2d_bwd(np.zeros((N, C, H, W)), w.astype(np.float64), dy.astype(np.float64), stride, pad, dil)[0] + (old if accumulate else 0)
+    check(res['1'][0], dxo, 1e-5, 'dx')
+    g = dxo * (by > 0)
+    xh = (bx.astype(np.float64) - mean[None, :, None, None]) * invstd[None, :, None, None]
+    for par in ('1', '0'):
+        check(res[par][1][0], g.sum((0, 2, 3)), 1e-4, 'sum g'); check(res[par][1][1], (g * xh).sum((0, 2, 3)), 1e-4, 'sum g xhat')
+
+
 @pytest.mark.parametrize('shape', [(2, 2048, 16, 32, 256, 3, 1, 12, 12), (2, 304, 64, 128, 256, 3, 1, 1, 1), (1, 256, 64, 128, 19, 1, 1, 0, 1),
                                    (2, 304, 32, 64, 192, 3, 1, 1, 1), (2, 256, 32, 64, 48, 1, 1, 0, 1), (3, 64, 33, 47, 64, 3, 2, 1, 1),
-                                   (8, 2048, 1, 1, 256, 1, 1, 0, 1)])
+                                   (8, 2048, 1, 1, 256, 1, 1, 0, 1), (2, 128, 8, 64, 128, 3, 2, 1, 1), (2, 256, 8, 128, 512, 1, 2, 0, 1)])
 def test_conv_vs_oracle_real_shapes(shape):
     """The shapes the DSRL head really launches (ASPP dilated, cat_conv, cls_conv, SISR, shortcut, a strided backbone conv,
     the pooled ASPP branch) against the fp64 oracle, forward and both gradients."""
