@@ -1278,7 +1278,7 @@ static int valid_count(int n_in, int n_out, int stride, int pad, int off) {
 }
 
 // ---- launch timing (opt-in)
-struct ProfRec { hipEvent_t a, b; int family; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int family; double flops, bytes; char tag[64]; };
 static std::mutex g_prof_mu;
 static int g_prof_stride = 0;                    // 0 = off, n = bracket every n-th conv launch with events
 static std::atomic<unsigned> g_prof_seq{0};
@@ -1295,9 +1295,12 @@ struct ProfScope {
         const int stride = g_prof_stride;
         on = stride > 0 && (g_prof_seq.fetch_add(1) % (unsigned)stride) == 0;
         if (!on) return;
-        r.family = family; r.flops = flops; r.bytes = bytes;
+        r.family = family; r.flops = flops; r.bytes = bytes; r.tag[0] = 0;
         r.a = prof_event(); r.b = prof_event();
         hipEventRecord(r.a, s);
+    }
+    void shape(const char* what, int N, int H, int W, int C, int K, int R, int stride, int pad, int dil) {        // for DSRL_PROF_DUMP
+        if (on) snprintf(r.tag, sizeof(r.tag), "%s N%d %dx%d C%d K%d R%d s%d p%d d%d", what, N, H, W, C, K, R, stride, pad, dil);
     }
     ~ProfScope() {
         if (!on) return;
@@ -1574,6 +1577,7 @@ static int fwd_impl(const float* x, int ldx, const float* w, const float* bias, 
     DSRL_REQUIRE_31(xb, "conv2d_fwd(x)"); DSRL_REQUIRE_31(wb, "conv2d_fwd(w)"); DSRL_REQUIRE_31(yb, "conv2d_fwd(y)");
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
     ProfScope prof(prof_family(PASS_FWD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
+    prof.shape("fwd", N, H, W, C, K, R, stride, pad, dil);
     if (p.splits > 1) {
         a.y = (float*)ws; a.ldy = K; a.bias = nullptr;
         if (int e = launch_igemm<false>(a, p.cfg, st)) return e;
@@ -1666,6 +1670,7 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
         a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
     }
     ProfScope prof(prof_family(PASS_DGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
+    prof.shape("dgrad", N, H, W, C, K, R, stride, pad, dil);
     if (p.splits > 1) {
         a.y = slabs; a.ldy = C; a.bias = nullptr;
         if (int e = launch_igemm<true>(a, p.cfg, st)) return e;
@@ -1832,6 +1837,7 @@ extern "C" int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int l
     a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
     dim3 grid((unsigned)(a.kctiles * p.tl.n * psplits));
     ProfScope prof(prof_family(PASS_WGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
+    prof.shape("wgrad", N, H, W, C, K, R, stride, pad, dil);
     launch_wgrad(a, p.cfg, p.bm, p.bn, grid, st);
     if (int e = launch_status("conv_wgrad kernel")) return e;
     if (psplits > 1) {
@@ -2138,6 +2144,9 @@ extern "C" int dsrl_prof_read(int family, int64_t* launches, double* total_ms, d
         float t = 0.f;
         hipEventElapsedTime(&t, r.a, r.b);
         ms += t; fl += r.flops; ++n;
+        if (const char* dump = getenv("DSRL_PROF_DUMP")) {          // diagnosis (tools/per_launch.py): one line per bracketed launch
+            if (FILE* f = fopen(dump, "a")) { fprintf(f, "%d\t%.6f\t%.0f\t%.0f\t%s\n", r.family, (double)t, r.flops, r.bytes, r.tag); fclose(f); }
+        }
     }
     if (launches) *launches = n;
     if (total_ms) *total_ms = ms;
