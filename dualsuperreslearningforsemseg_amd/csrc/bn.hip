@@ -665,6 +665,7 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_bwd_kernel(const float
             xh[i] = make_float4((xv.x - mu[0]) * is[0], (xv.y - mu[1]) * is[1], (xv.z - mu[2]) * is[2], (xv.w - mu[3]) * is[3]);
             sg[0] += g[i].x; sgx[0] += g[i].x * xh[i].x; sg[1] += g[i].y; sgx[1] += g[i].y * xh[i].y;
             sg[2] += g[i].z; sgx[2] += g[i].z * xh[i].z; sg[3] += g[i].w; sgx[3] += g[i].w * xh[i].w;
+            if (dres) ST4(dres, p, lddr, q) = g[i];         // the residual branch's gradient does not depend on the sums: written under the read phase
         } else {
             g[i] = make_float4(0.f, 0.f, 0.f, 0.f); xh[i] = g[i];
         }
@@ -729,7 +730,6 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_bwd_kernel(const float
         if (p >= row1) continue;
         ST4(dx, p, lddx, q) = make_float4(gi[0] * (g[i].x - mb[0] - xh[i].x * mg[0]), gi[1] * (g[i].y - mb[1] - xh[i].y * mg[1]),
                                           gi[2] * (g[i].z - mb[2] - xh[i].z * mg[2]), gi[3] * (g[i].w - mb[3] - xh[i].w * mg[3]));
-        if (dres) ST4(dres, p, lddr, q) = g[i];
     }
 }
 
