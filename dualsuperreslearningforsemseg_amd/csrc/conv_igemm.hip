@@ -689,6 +689,62 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
 }
 
 // wt[c][tap][k] = w[k][tap][c]   (dgrad runs the forward kernel on the transposed filter)
+// The same reduce for a forward conv whose output feeds a BatchNorm (round 2): a block sums the slabs of 64 rows x 32 channels with float4
+// loads, stores y and leaves the (n, mean, M2) partial of its 64 rows per channel in stats[3][ceil(M/64)][K] - the layout the conv epilogue
+// writes - so that the BatchNorm of a split-K conv (layer4, ASPP) also runs from statistics instead of crossing a device-wide barrier.
+// K % 32 == 0, ldy % 4 == 0; Chan merges in a fixed order (row lanes by xor shuffles, the four waves through LDS).
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ slabs, int splits, long long slab, int M, int K,
+                                                                   const float* __restrict__ bias, float* __restrict__ y, int ldy, float* __restrict__ stats) {
+    __shared__ float shw[4][3][4][8];
+    const int groups = K / 32, grp = blockIdx.x % groups, rb = blockIdx.x / groups;
+    const int tid = threadIdx.x, l8 = tid & 7, rr = tid >> 3, wave = tid >> 6;
+    const int c0 = grp * 32 + 4 * l8, nparts = (M + 63) / 64;
+    const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float v[2][4]; bool ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = rb * 64 + rr + 32 * i;
+        ok[i] = m < M;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok[i]) {
+            const float* src = slabs + (long long)m * K + c0;
+            for (int zz = 0; zz < splits; ++zz) { const float4 t = *reinterpret_cast<const float4*>(src + zz * slab); acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+            acc.x += b4.x; acc.y += b4.y; acc.z += b4.z; acc.w += b4.w;
+            *reinterpret_cast<float4*>(y + (long long)m * ldy + c0) = acc;
+        }
+        v[i][0] = acc.x; v[i][1] = acc.y; v[i][2] = acc.z; v[i][3] = acc.w;
+    }
+    float n = (ok[0] ? 1.f : 0.f) + (ok[1] ? 1.f : 0.f), mean[4], m2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mean[j] = n > 0.f ? ((ok[0] ? v[0][j] : 0.f) + (ok[1] ? v[1][j] : 0.f)) / n : 0.f;
+        const float d0 = v[0][j] - mean[j], d1 = v[1][j] - mean[j];
+        m2[j] = (ok[0] ? d0 * d0 : 0.f) + (ok[1] ? d1 * d1 : 0.f);
+    }
+    auto merge = [](float& na, float& ma, float& qa, float nb, float mb, float qb) {
+        if (nb > 0.f) { const float nt = na + nb, d = mb - ma; ma += d * (nb / nt); qa += qb + d * d * (na * nb / nt); na = nt; }
+    };
+#pragma unroll
+    for (int sft = 8; sft < 64; sft <<= 1) {
+        const float nb = __shfl_xor(n, sft);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { float na = n; merge(na, mean[j], m2[j], nb, __shfl_xor(mean[j], sft), __shfl_xor(m2[j], sft)); }
+        n += nb;
+    }
+    if ((tid & 63) < 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { shw[wave][0][j][l8] = n; shw[wave][1][j][l8] = mean[j]; shw[wave][2][j][l8] = m2[j]; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int j = tid & 3, c8 = tid >> 2;
+        float na = shw[0][0][j][c8], ma = shw[0][1][j][c8], qa = shw[0][2][j][c8];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) merge(na, ma, qa, shw[w][0][j][c8], shw[w][1][j][c8], shw[w][2][j][c8]);
+        float* o = stats + (long long)rb * K + grp * 32 + tid;
+        o[0] = na; o[(long long)nparts * K] = ma; o[2ll * nparts * K] = qa;
+    }
+}
 __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int K, int Kp, int RS, int C) {
     __shared__ float tile[32][33];
     const int tap = blockIdx.z;
@@ -1544,7 +1600,9 @@ extern "C" size_t dsrl_conv2d_fwd_workspace_bytes(int N, int H, int W, int C, in
 
 // rows blocks of BatchNorm partials a forward launch of this shape writes in the current arithmetic mode (0 = it cannot: fp32 kernels,
 // split-K slabs, or more than 256 row blocks)
-static int fwd_stats_parts(const FwdPlan& p, int npl) {
+static int fwd_stats_parts(const FwdPlan& p, int npl, bool dgrad = false) {
+    if (npl && p.splits > 1 && !dgrad && env_int("DSRL_SPLITK_STATS", 1))      // forward split-K: the slab reduce leaves partials of 64 rows each
+        return ((p.ws / ((size_t)p.splits * p.M * sizeof(float))) % 32 == 0 && ceil_div(p.M, 64) <= 256) ? (int)ceil_div(p.M, 64) : 0;
     if (!npl || p.splits > 1) return 0;
     int bm, bn; cfg_dims(p.cfg, bm, bn);
     static const int kWGM[kNumCfg] = {2, 4, 4, 2, 2, 2, 4};          // waves along M per block tile, DSRL_CFG_SWITCH order
@@ -1582,6 +1640,15 @@ static int fwd_impl(const float* x, int ldx, const float* w, const float* bias, 
         a.y = (float*)ws; a.ldy = K; a.bias = nullptr;
         if (int e = launch_igemm<false>(a, p.cfg, st)) return e;
         const long long total = (long long)p.M * K;
+        if (stats != nullptr) {
+            DSRL_REQUIRE(fwd_stats_parts(p, conv_planes(PASS_FWD)) == stats_parts && stats_parts > 0 && ldy % 4 == 0 && ((uintptr_t)y % 16) == 0 &&
+                         (bias == nullptr || ((uintptr_t)bias % 16) == 0), DSRL_E_BADARG,
+                         "conv2d_fwd_stats: this split-K launch writes %d row blocks of partials (ldy a multiple of 4, y 16-byte aligned), the caller expects %d",
+                         fwd_stats_parts(p, conv_planes(PASS_FWD)), stats_parts);
+            hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((unsigned)(stats_parts * (K / 32))), dim3(256), 0, st,
+                               (const float*)ws, p.splits, a.slab, p.M, K, bias, y, ldy, stats);
+            return launch_status("splitk_reduce_stats_kernel");
+        }
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st,
                            (const float*)ws, p.splits, a.slab, p.M, K, bias, y, ldy);
         return launch_status("splitk_reduce_kernel");
@@ -1700,7 +1767,7 @@ extern "C" int dsrl_conv2d_dgrad_stats_parts(int N, int H, int W, int C, int K, 
     const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
     if (Ho <= 0 || Wo <= 0) return 0;
     const int npl = conv_planes(PASS_DGRAD);
-    return fwd_stats_parts(plan_fwd(N, Ho, Wo, pad4(K), C, R, S, H, W, npl), npl);
+    return fwd_stats_parts(plan_fwd(N, Ho, Wo, pad4(K), C, R, S, H, W, npl), npl, true);
 }
 extern "C" int dsrl_conv2d_dgrad_bnstats(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
                                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

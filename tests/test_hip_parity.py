@@ -401,11 +401,13 @@ def test_batchnorm_frozen_statistics_backward(C):
     check(host(bn.running_mean), rm, 0.0); check(host(bn.running_var), rv, 0.0)
 
 
-@pytest.mark.parametrize('shape', [(8, 256, 16, 32, 256, 3, 1, 1, 1), (3, 64, 33, 47, 96, 3, 2, 1, 1), (2, 128, 9, 13, 64, 1, 1, 0, 1), (8, 64, 64, 128, 64, 3, 1, 1, 1)])
+@pytest.mark.parametrize('shape', [(8, 256, 16, 32, 256, 3, 1, 1, 1), (3, 64, 33, 47, 96, 3, 2, 1, 1), (2, 128, 9, 13, 64, 1, 1, 0, 1), (8, 64, 64, 128, 64, 3, 1, 1, 1),
+                                   (8, 512, 16, 32, 512, 3, 1, 2, 2), (8, 2048, 16, 32, 256, 3, 1, 6, 6), (2, 1024, 9, 13, 512, 3, 1, 1, 1)])
 def test_conv_epilogue_bn_statistics(shape):
     """conv2d_bn_act: BatchNorm batch statistics from the conv epilogue (dsrl_conv2d_fwd_stats -> dsrl_bn_train_fwd_from_stats) against
     the separate conv + BN path and the oracle; ragged row counts (33x47 maps), channel tails of the last tile (96 = 64 + 32), a shape
-    with more than 256 row blocks (falls back by itself), residual + ReLU, and the backward pass through both."""
+    with more than 256 row blocks (falls back by itself), residual + ReLU, and the backward pass through both. The last three shapes are
+    split-K launches (layer4 conv2, a dilated ASPP branch, a ragged 9x13 map): their partials come from the slab reduce (splitk_reduce_stats_kernel)."""
     N, C, H, W, K, R, stride, pad, dil = shape
     rs = np.random.RandomState(sum(shape))
     x = rs.standard_normal((N, C, H, W)).astype(np.float32)
