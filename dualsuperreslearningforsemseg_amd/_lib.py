@@ -25,7 +25,7 @@ _conv_shape = [i32] * 10                      # N,H,W,C,K,R,S,stride,pad,dil
 
 class WgradProblem(C.Structure):              # include/dsrl_hip.h: dsrl_wgrad_problem
     _fields_ = [('x', C.c_void_p), ('dy', C.c_void_p), ('dw', C.c_void_p)] + [(n, C.c_int32) for n in
-                ('ldx', 'lddy', 'N', 'H', 'W', 'C', 'K', 'R', 'S', 'stride', 'pad', 'dil')]
+                ('ldx', 'lddy', 'N', 'H', 'W', 'C', 'K', 'R', 'S', 'stride', 'pad', 'dil')] + [('x_amax', C.c_void_p), ('dy_amax', C.c_void_p)]
 
 
 PROTOTYPES = {
@@ -50,6 +50,10 @@ PROTOTYPES = {
     'dsrl_conv2d_wgrad_group_workspace_bytes': (sz, [fp, i32]),
     'dsrl_conv2d_wgrad_group_plan': (i32, [fp, i32, fp, sz, fp, fp, sz]),
     'dsrl_conv2d_wgrad_group_launch': (i32, [fp, fp, stream_t]),
+    'dsrl_amax': (i32, [fp, i32, i64, i32, fp, stream_t]),
+    'dsrl_conv2d_fwd_amax': (i32, [fp, i32, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, stream_t]),
+    'dsrl_conv2d_dgrad_amax': (i32, [fp, i32, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, fp, i32, fp, fp, i32, fp, i32, i32, stream_t]),
+    'dsrl_conv2d_wgrad_amax': (i32, [fp, i32, fp, fp, i32, fp, fp] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv_precision': (i32, [i32]),
     'dsrl_conv2d_inbounds_macs': (i64, _conv_shape),
     'dsrl_conv2d_rowfold_fwd_workspace_bytes': (sz, [i32] * 9),

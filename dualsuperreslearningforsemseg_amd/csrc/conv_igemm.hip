@@ -23,12 +23,40 @@ static int env_int(const char* name, int dflt) { const char* v = getenv(name); r
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 static std::atomic<int> g_conv_precision{-1};     // dsrl_conv_precision(); -1 = DSRL_CONV_PRECISION, modes in conv_precision_mode()
 
 // Split-precision arithmetic ("bf16x3": NPL = 2 planes, "bf16x6": NPL = 3): an fp32 value is carried as NPL bf16 terms
 // x = t0 + t1 (+ t2), t0 = bf16(x), t1 = bf16(x - t0), t2 = bf16(x - t0 - t1), i.e. 16 (24) mantissa bits, and a product is the sum
 // of the bf16 MFMAs a_i * b_j with i + j < NPL (3 or 6 of them), small terms first, all accumulated in fp32
 // (conv_igemm_split_kernel, conv_wgrad_split_kernel).
+//
+// "f16x3" (F16 = true, NPL = 2, round 3): the two terms are fp16 instead of bf16, t0 = f16(x * 2^e), t1 = f16(x * 2^e - t0), i.e. 22 mantissa
+// bits in 3 MFMAs (v_mfma_f32_32x32x16_f16: a0*b1 + a1*b0 + a0*b0) - the accuracy of bf16x6 / fp32 MFMA at half the matrix work and
+// two thirds of the LDS bytes.  fp16 has 5 exponent bits, so every operand tensor carries a power-of-two scale: 2^e maps the tensor's
+// largest magnitude into [2^14, 2^15) (e from a device word holding max |x| as its bit pattern, written by the tensor's producer or by
+// amax_kernel), and the accumulators are multiplied by 2^-(ea + eb) in the epilogue - exact.  Elements more than 2^18 below the
+// tensor's maximum lose low-order bits gracefully (absolute error <= 2^-40 of the maximum: invisible in any sum an fp32 kernel forms).
+template <bool F16> struct Plane;
+template <> struct Plane<false> {
+    using v4 = bf16x4; using v8 = bf16x8;
+    static __device__ __forceinline__ v4 cvt(const float* r) { return v4{(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]}; }
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Plane<true> {
+    using v4 = f16x4; using v8 = f16x8;
+    static __device__ __forceinline__ v4 cvt(const float* r) { return v4{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]}; }
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+// e with max|x| * 2^e in [2^14, 2^15) from the bit pattern of max|x| (zero / subnormal maxima count as 2^-126; Inf / NaN maxima give a
+// finite e: such tensors turn into NaN in the split by themselves)
+__device__ __forceinline__ int amax_shift(const unsigned* p) {
+    const unsigned u = __builtin_amdgcn_readfirstlane(*p);
+    int ex = (int)((u >> 23) & 0xffu);
+    if (ex == 0) ex = 1;
+    return 14 - (ex - 127);
+}
 
 struct ConvArgs {
     const float* x; const float* w; const float* bias; float* y;
@@ -57,6 +85,7 @@ struct ConvArgs {
     // Host side: Ho % par == Wo % par == 0, pixels per class % pbm == 0 (a tile never straddles classes), Wh % 32 == 0 (32 consecutive rows
     // are 32 consecutive pixels of one image row of the class: the epilogue derives their offsets from the first one).
     int par, Hh, Wh, pbm;
+    const unsigned* amax_a; const unsigned* amax_b;     // f16x3: max |.| (bit patterns) of the input tensor x and of the filter w
 };
 __device__ __forceinline__ int dgrad_pix(const ConvArgs& a, int m) {        // row of the parity-ordered GEMM -> pixel index (n*Ho + h)*Wo + w
     const int t = m / a.pbm, p2 = a.par * a.par, c = t % p2, j = (t / p2) * a.pbm + (m - t * a.pbm);
@@ -320,8 +349,12 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
 //   * KG > 1 ("K groups", for grids of at most ~1.5 tiles per CU): the block has KG groups of 4 waves, group g runs the same pipeline
 //     on chunks g, g+KG, ... with its own two LDS stages, and the KG accumulator sets are summed through LDS in a fixed order at the
 //     end - the latency-hiding of split-K (more waves per SIMD) without slab traffic or a reduce launch.
-template <int MR, int NR, int WGM, int WGN, bool DGRAD, int NPL, int KG = 1>
+template <int MR, int NR, int WGM, int WGN, bool DGRAD, int NPL, int KG = 1, bool F16 = false>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_kernel(const ConvArgs a) {
+    static_assert(!F16 || NPL == 2, "f16x3 carries two fp16 terms per operand");
+    using PT = Plane<F16>;
+    using pl4 = typename PT::v4; using pl8 = typename PT::v8;
+    const int sh_a = F16 ? amax_shift(a.amax_a) : 0, sh_b = F16 ? amax_shift(a.amax_b) : 0;
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
     constexpr int A_IT = (BM + 63) / 64, B_IT = (BN + 63) / 64;      // 64 rows per staging pass (4 lanes per row)
     constexpr int NV = A_IT + B_IT;
@@ -472,12 +505,19 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
     float res[4] = {0.f, 0.f, 0.f, 0.f};
     auto cstep = [&](char* nb, float4 (*R)[2], int hf, int c) {        // plane c % NPL of staged value c / NPL
         const int v = c / NPL, pl = c % NPL;
-        if (pl == 0) { const float4 x = R[v][hf]; res[0] = x.x; res[1] = x.y; res[2] = x.z; res[3] = x.w; }
-        const bf16x4 t = {(__bf16)res[0], (__bf16)res[1], (__bf16)res[2], (__bf16)res[3]};
+        if (pl == 0) {
+            const float4 x = R[v][hf]; res[0] = x.x; res[1] = x.y; res[2] = x.z; res[3] = x.w;
+            if (F16) {
+                const int sh = v < A_IT ? sh_a : sh_b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) res[e] = __builtin_ldexpf(res[e], sh);
+            }
+        }
+        const pl4 t = PT::cvt(res);
         if (v < A_IT) {
-            *reinterpret_cast<bf16x4*>(nb + (pl * BM + r0 + 64 * v) * ROWB + w_swz) = t;
+            *reinterpret_cast<pl4*>(nb + (pl * BM + r0 + 64 * v) * ROWB + w_swz) = t;
         } else if (b_rows) {
-            *reinterpret_cast<bf16x4*>(nb + (NPL * BM + pl * BN + r0 + 64 * (v - A_IT)) * ROWB + w_swz) = t;
+            *reinterpret_cast<pl4*>(nb + (NPL * BM + pl * BN + r0 + 64 * (v - A_IT)) * ROWB + w_swz) = t;
         }
         if (pl + 1 < NPL) {
 #pragma unroll
@@ -488,17 +528,17 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
     constexpr int MPS = NMFMA / CSTEPS > 0 ? NMFMA / CSTEPS : 1;
     auto pipe = [&](const char* cur, char* nxt, float4 (*R)[2], int hf) {
         // every fragment read first (the compiler cannot prove the two stages disjoint: a read placed after a write would wait)
-        bf16x8 fa[MR][NPL], fb[NR][NPL];
+        pl8 fa[MR][NPL], fb[NR][NPL];
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl)
-                fa[i][pl] = *reinterpret_cast<const bf16x8*>(cur + (pl * BM + (wm * MR + i) * 32 + frag_row) * ROWB + r_swz);
+                fa[i][pl] = *reinterpret_cast<const pl8*>(cur + (pl * BM + (wm * MR + i) * 32 + frag_row) * ROWB + r_swz);
 #pragma unroll
         for (int j = 0; j < NR; ++j)
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl)
-                fb[j][pl] = *reinterpret_cast<const bf16x8*>(cur + (NPL * BM + pl * BN + (wn * NR + j) * 32 + frag_row) * ROWB + r_swz);
+                fb[j][pl] = *reinterpret_cast<const pl8*>(cur + (NPL * BM + pl * BN + (wn * NR + j) * 32 + frag_row) * ROWB + r_swz);
         __builtin_amdgcn_sched_barrier(0);
         int m = 0;
         // small terms first; consecutive MFMAs go to different accumulator tiles; a convert step after every MPS-th MFMA
@@ -510,7 +550,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
                 for (int i = 0; i < MR; ++i)
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa], fb[j][sum - pa], acc[i][j], 0, 0, 0);
+                        acc[i][j] = PT::mfma(fa[i][pa], fb[j][sum - pa], acc[i][j]);
                         if (m % MPS == 0 && m / MPS < CSTEPS) cstep(nxt, R, hf, m / MPS);
                         __builtin_amdgcn_sched_barrier(0);
                         ++m;
@@ -570,6 +610,15 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
                     }
     }
 
+    if (F16) {          // undo the two operand scales (exact: a power of two)
+        const int sh = -(sh_a + sh_b);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NR; ++jj)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][jj][e] = __builtin_ldexpf(acc[i][jj][e], sh);
+    }
     // ---- epilogue: D[row][col], col = lane&31 (out channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); bounds by the descriptor
     float* yout = a.y + (a.splits > 1 ? (long long)z * a.slab : 0ll);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)yout, 0, (int)a.y_bytes, 0x00020000);
@@ -764,25 +813,31 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
 // The same for every conv filter of the model in ONE launch: table[i] = {w, wt, K, Kp, RS, C, first tile, tiles along C} as int64;
 // blockIdx.x = global 32x32 tile index, located in the table by bisection on the first-tile column.
 constexpr int kWtTilesPerBlock = 4;
+constexpr int kWtRow = 10;      // int64 words per table row: {w, wt, K, Kp, RS, C, first tile, tiles along C, amax word (0: none), unused}
 // A block transposes kWtTilesPerBlock consecutive 32x32 tiles (consecutive ids are neighbours along C: contiguous reads): one bisection over
 // the rows of the table per block instead of per 4 KB tile, four times the bytes in flight per block.
 __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const long long* __restrict__ table, int n, long long total_tiles) {
     __shared__ float tile[kWtTilesPerBlock][32][33];
+    __shared__ unsigned smax[kWtTilesPerBlock];
+    if (threadIdx.x < kWtTilesPerBlock) smax[threadIdx.x] = 0u;
+    __syncthreads();
     const long long b0 = (long long)blockIdx.x * kWtTilesPerBlock;
     int lo = 0, hi = n - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (table[mid * 8 + 6] <= b0) lo = mid; else hi = mid - 1;
+        if (table[mid * kWtRow + 6] <= b0) lo = mid; else hi = mid - 1;
     }
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     float* dst[kWtTilesPerBlock]; int dC[kWtTilesPerBlock], dKp[kWtTilesPerBlock], dc0[kWtTilesPerBlock], dk0[kWtTilesPerBlock], dRS[kWtTilesPerBlock], dtap[kWtTilesPerBlock];
+    unsigned* dam[kWtTilesPerBlock];            // where the filter's max |w| goes (f16x3 operand scale), or null
 #pragma unroll
     for (int u = 0; u < kWtTilesPerBlock; ++u) {
         const long long b = b0 + u;
-        dst[u] = nullptr;
+        dst[u] = nullptr; dam[u] = nullptr;
         if (b >= total_tiles) continue;
-        while (lo + 1 < n && table[(lo + 1) * 8 + 6] <= b) ++lo;            // the next tile may belong to the next filter
-        const long long* e = table + lo * 8;
+        while (lo + 1 < n && table[(lo + 1) * kWtRow + 6] <= b) ++lo;            // the next tile may belong to the next filter
+        const long long* e = table + lo * kWtRow;
+        dam[u] = reinterpret_cast<unsigned*>(e[8]);
         const float* w = reinterpret_cast<const float*>(e[0]);
         const int K = (int)e[2], Kp = (int)e[3], RS = (int)e[4], C = (int)e[5], ct = (int)e[7];
         const int kt = (Kp + 31) / 32;
@@ -790,13 +845,30 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const lon
         const int tap = t / (ct * kt); t -= tap * ct * kt;
         const int k0 = (t / ct) * 32, c0 = (t % ct) * 32;
         dst[u] = reinterpret_cast<float*>(e[1]); dC[u] = C; dKp[u] = Kp; dc0[u] = c0; dk0[u] = k0; dRS[u] = RS; dtap[u] = tap;
+        unsigned mx = 0u;
 #pragma unroll
         for (int r = ty; r < 32; r += 8) {
             const int k = k0 + r, c = c0 + tx;
-            tile[u][r][tx] = (k < K && c < C) ? w[((long long)k * RS + tap) * C + c] : 0.f;
+            const float v = (k < K && c < C) ? w[((long long)k * RS + tap) * C + c] : 0.f;
+            tile[u][r][tx] = v;
+            mx = max(mx, __float_as_uint(v) & 0x7fffffffu);
+        }
+        if (dam[u] != nullptr) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+            if ((threadIdx.x & 63) == 0 && mx) atomicMax(&smax[u], mx);
         }
     }
     __syncthreads();
+    if (threadIdx.x == 0) {                 // one global atomic per (block, filter)
+        unsigned* cur = nullptr; unsigned m = 0u;
+#pragma unroll
+        for (int u = 0; u < kWtTilesPerBlock; ++u) {
+            if (dam[u] != cur) { if (cur != nullptr && m) atomicMax(cur, m); cur = dam[u]; m = 0u; }
+            m = max(m, smax[u]);
+        }
+        if (cur != nullptr && m) atomicMax(cur, m);
+    }
 #pragma unroll
     for (int u = 0; u < kWtTilesPerBlock; ++u) {
         if (dst[u] == nullptr) continue;
@@ -805,6 +877,37 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const lon
             const int c = dc0[u] + r, k = dk0[u] + tx;
             if (c < dC[u] && k < dKp[u]) dst[u][((long long)c * dRS[u] + dtap[u]) * dKp[u] + k] = tile[u][tx][r];      // k in [K,Kp): zero padding
         }
+    }
+}
+
+// max |x| of a pixel-major [P][ld] tensor with C channels as a bit pattern, atomically maxed into *out (the caller zeroes it): the operand
+// scale of the f16x3 kernels when the tensor's producer did not leave one.  NaN bit patterns compare above every number.
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int ld, long long P, int C, int vec, unsigned* __restrict__ out) {
+    __shared__ unsigned sm[4];
+    unsigned m = 0u;
+    const long long stride = (long long)gridDim.x * blockDim.x, t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const int C4 = C >> 2;
+        const long long n = P * C4;
+        for (long long e = t0; e < n; e += stride) {
+            const long long p = ld == C ? 0 : e / C4;
+            const float4 v = *reinterpret_cast<const float4*>(ld == C ? x + 4 * e : x + p * ld + 4 * (e - p * C4));
+            m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu, max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+        }
+    } else {
+        const long long n = P * C;
+        for (long long e = t0; e < n; e += stride) {
+            const long long p = e / C;
+            m = max(m, __float_as_uint(x[p * ld + (e - p * C)]) & 0x7fffffffu);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+        if (m) atomicMax(out, m);
     }
 }
 
@@ -828,6 +931,7 @@ struct WgradArgs {
     int nblocks;
     float* dw_final;
     int rblocks;
+    const unsigned* amax_dy; const unsigned* amax_x;        // f16x3: max |.| (bit patterns) of dy and of x
 };
 
 template <int MR, int NR, int WGM, int WGN>
@@ -968,8 +1072,12 @@ __device__ __forceinline__ int fast_div(int n, unsigned m, unsigned s) { return 
 // The pixel -> (n, ho, wo) decomposition of every staged x row uses magic-number division (two mul-hi instead of two divides).
 // KG > 1 (pixel groups): KG groups of 4 waves per block, group g takes the 32-pixel chunks g, g+KG, ... of the block's pixel range with
 // its own two LDS stages; the KG accumulator sets are summed through LDS in a fixed order - KG times fewer slabs to write and reduce.
-template <int MR, int NR, int WGM, int WGN, int NPL, int KG>
+template <int MR, int NR, int WGM, int WGN, int NPL, int KG, bool F16 = false>
 __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int bid) {
+    static_assert(!F16 || NPL == 2, "f16x3 carries two fp16 terms per operand");
+    using PT = Plane<F16>;
+    using pl4 = typename PT::v4; using pl8 = typename PT::v8;
+    const int sh_a = F16 ? amax_shift(a.amax_dy) : 0, sh_b = F16 ? amax_shift(a.amax_x) : 0;
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
     constexpr int A_V = BM / 4, B_V = BN / 4;                 // float4 per pixel row
     constexpr int A_RP = 256 / A_V, B_RP = 256 / B_V;          // pixel rows per staging pass
@@ -1084,12 +1192,17 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
         if (pl == 0) {
             const float4 x = v < A_H ? ra[hf * A_H + v] : rb[B_IT >= 2 ? hf * B_H + (v - A_H) : 0];
             res[0] = x.x; res[1] = x.y; res[2] = x.z; res[3] = x.w;
+            if (F16) {
+                const int sh = v < A_H ? sh_a : sh_b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) res[e] = __builtin_ldexpf(res[e], sh);
+            }
         }
-        const bf16x4 t = {(__bf16)res[0], (__bf16)res[1], (__bf16)res[2], (__bf16)res[3]};
+        const pl4 t = PT::cvt(res);
         if (v < A_H) {
-            *reinterpret_cast<bf16x4*>(nb_ + pl * PLA + wa_off + v * (A_RP * SA)) = t;
+            *reinterpret_cast<pl4*>(nb_ + pl * PLA + wa_off + v * (A_RP * SA)) = t;
         } else if (B_IT >= 2 || b_half == hf) {
-            *reinterpret_cast<bf16x4*>(nb_ + pl * PLB + wb_off + (v - A_H) * (B_RP * SB)) = t;
+            *reinterpret_cast<pl4*>(nb_ + pl * PLB + wb_off + (v - A_H) * (B_RP * SB)) = t;
         }
         if (pl + 1 < NPL) {
 #pragma unroll
@@ -1098,13 +1211,13 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
     };
     constexpr int NMFMA = MR * NR * (NPL * (NPL + 1) / 2), CSTEPS = (A_H + B_H) * NPL;
     constexpr int MPS = NMFMA / CSTEPS > 0 ? NMFMA / CSTEPS : 1;
-    auto tr8 = [&](const char* q, int stride) -> bf16x8 {
+    auto tr8 = [&](const char* q, int stride) -> pl8 {
         const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q));
         const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * stride));
-        return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(pl8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));         // the transposing read moves 16-bit words whatever they hold
     };
     auto pipe = [&](const char* cur, char* nxt, const float4* ra, const float4* rb, int hf) {
-        bf16x8 fa[MR][NPL], fb[NR][NPL];
+        pl8 fa[MR][NPL], fb[NR][NPL];
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -1123,7 +1236,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
                 for (int i = 0; i < MR; ++i)
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa], fb[j][sum - pa], acc[i][j], 0, 0, 0);
+                        acc[i][j] = PT::mfma(fa[i][pa], fb[j][sum - pa], acc[i][j]);
                         if (m % MPS == 0 && m / MPS < CSTEPS) cstep(nxt, ra, rb, hf, m / MPS);
                         __builtin_amdgcn_sched_barrier(0);
                         ++m;
@@ -1220,6 +1333,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
     float* out = a.dw + (a.psplits > 1 ? (long long)zsplit * a.slab : 0ll);
     const int RS = a.R * a.S;
     const int col = lane & 31, rq = (lane >> 5) * 4;
+    const int sh_out = -(sh_a + sh_b);          // f16x3: undo the two operand scales (exact)
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int c = c0 + (wn * NR + j) * 32 + col;
@@ -1230,21 +1344,21 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int k = kb + (e & 3) + 8 * (e >> 2);
-                if (k < a.K) out[((long long)k * RS + tap) * a.C + c] = acc[i][j][e];
+                if (k < a.K) out[((long long)k * RS + tap) * a.C + c] = F16 ? __builtin_ldexpf(acc[i][j][e], sh_out) : acc[i][j][e];
             }
         }
     }
 }
 
-template <int MR, int NR, int WGM, int WGN, int NPL, int KG = 1>
+template <int MR, int NR, int WGM, int WGN, int NPL, int KG = 1, bool F16 = false>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_wgrad_split_kernel(const WgradArgs a) {
-    wgrad_split_body<MR, NR, WGM, WGN, NPL, KG>(a, (int)blockIdx.x);
+    wgrad_split_body<MR, NR, WGM, WGN, NPL, KG, F16>(a, (int)blockIdx.x);
 }
 
 // Grouped launch: ONE grid covers the weight gradients of many convolutions that share a tile configuration.  `table` holds one
 // WgradArgs per problem, `starts` the first block of each (ascending, multiples of 8 so that a problem's local block ids keep their
 // XCD round-robin phase); a block finds its problem by bisection (wave-uniform scalar loads) and runs the ordinary kernel body on it.
-template <int MR, int NR, int WGM, int WGN, int NPL>
+template <int MR, int NR, int WGM, int WGN, int NPL, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_group_kernel(const WgradArgs* __restrict__ table, const int* __restrict__ starts, int nprob) {
     const int b = (int)blockIdx.x;
     int lo = 0, hi = nprob - 1;
@@ -1256,7 +1370,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_group_kernel(const WgradArg
     const WgradArgs& a = table[lo];
     const int local = b - starts[lo];
     if (local >= a.nblocks) return;             // padding block
-    wgrad_split_body<MR, NR, WGM, WGN, NPL, 1>(a, local);
+    wgrad_split_body<MR, NR, WGM, WGN, NPL, 1, F16>(a, local);
 }
 
 struct TapList { int taps[64]; int n; };
@@ -1426,26 +1540,52 @@ static int pick_splits(long long tiles, int nq) {
 //   1  bf16x3 everywhere   (16 mantissa bits per operand, ~5e-6 relative error per conv)
 //   2  bf16x6 everywhere   (24 mantissa bits per operand: fp32-equivalent, measured error vs fp64 equal to mode 0)
 //   3  forward bf16x6, dgrad / wgrad bf16x3 (logits keep fp32 accuracy, gradients carry ~5e-6)
-// Returns the number of bf16 planes per operand for the pass (0 = fp32 kernel).
+//   4  f16x3 everywhere    (two fp16 terms per operand + per-tensor power-of-two scales: 22 mantissa bits, fp32-equivalent, 3 MFMAs)
+// Returns the number of 16-bit planes per operand for the pass (0 = fp32 kernel); conv_f16(): are they fp16 (mode 4) or bf16.
 enum ConvPass { PASS_FWD, PASS_DGRAD, PASS_WGRAD };
 static int conv_precision_mode() {
     int prec = g_conv_precision.load();
     if (prec < 0) prec = env_int("DSRL_CONV_PRECISION", 2);
-    return prec < 0 ? 0 : (prec > 3 ? 3 : prec);
+    return prec < 0 ? 0 : (prec > 4 ? 4 : prec);
 }
+static bool conv_f16() { return conv_precision_mode() == 4; }
 static int conv_planes(ConvPass pass) {
     switch (conv_precision_mode()) {
         case 0: return 0;
         case 1: return 2;
         case 2: return 3;
+        case 4: return 2;
         default: return pass == PASS_FWD ? 3 : 2;
     }
 }
 
-// launch-timer family = 3 * arithmetic (0 fp32, 1 bf16x3, 2 bf16x6) + pass (0 forward, 1 wgrad, 2 dgrad)
+// launch-timer family = 3 * arithmetic (0 fp32, 1 bf16x3, 2 bf16x6, 3 f16x3) + pass (0 forward, 1 wgrad, 2 dgrad)
 static int prof_family(ConvPass pass) {
     const int npl = conv_planes(pass);
-    return 3 * (npl ? npl - 1 : 0) + (pass == PASS_FWD ? 0 : (pass == PASS_WGRAD ? 1 : 2));
+    return 3 * (conv_f16() ? 3 : (npl ? npl - 1 : 0)) + (pass == PASS_FWD ? 0 : (pass == PASS_WGRAD ? 1 : 2));
+}
+
+// f16x3 operand scales the caller did not provide: measured into two zeroed words at `scratch` (kAmaxScratch bytes at the end of the
+// call's workspace) by one amax launch per missing operand.
+constexpr size_t kAmaxScratch = 256;
+static int launch_amax(const float* x, int ld, long long P, int C, unsigned* out, hipStream_t st) {
+    const int vec = (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0) ? 1 : 0;
+    const long long n = vec ? P * (C / 4) : P * C;
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(ceil_div(n, 256 * 4), 2048));
+    hipLaunchKernelGGL(amax_kernel, dim3(grid), dim3(256), 0, st, x, ld, P, C, vec, out);
+    return launch_status("amax_kernel");
+}
+struct OperandAmax { const unsigned* a; const unsigned* b; };
+// a: [Pa][lda] with Ca channels, b: [Pb][ldb] with Cb channels
+static int resolve_amax(OperandAmax& am, const float* a, int lda, long long Pa, int Ca, const float* b, int ldb, long long Pb, int Cb,
+                        void* ws, size_t ws_bytes, size_t ws_used, hipStream_t st, const char* who) {
+    if (am.a != nullptr && am.b != nullptr) return DSRL_OK;
+    DSRL_REQUIRE(ws != nullptr && ws_bytes >= align_up(ws_used, 16) + kAmaxScratch, DSRL_E_WORKSPACE, "%s: the f16x3 arithmetic measures operand magnitudes the caller did not pass in %zu bytes behind the first %zu of the workspace (got %zu)", who, kAmaxScratch, ws_used, ws_bytes);
+    unsigned* scratch = (unsigned*)((char*)ws + align_up(ws_used, 16));
+    if (hipMemsetAsync(scratch, 0, 16, st) != hipSuccess) return launch_status("hipMemsetAsync(amax scratch)");
+    if (am.a == nullptr) { if (int e = launch_amax(a, lda, Pa, Ca, scratch, st)) return e; am.a = scratch; }
+    if (am.b == nullptr) { if (int e = launch_amax(b, ldb, Pb, Cb, scratch + 1, st)) return e; am.b = scratch + 1; }
+    return DSRL_OK;
 }
 
 template <bool DGRAD>
@@ -1456,7 +1596,9 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
     a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
     dim3 grid((unsigned)(a.mtiles * a.ntiles), 1u, (unsigned)a.splits);
     const int npl = conv_planes(DGRAD ? PASS_DGRAD : PASS_FWD);
+    const bool f16 = conv_f16();
     const long long nblocks = (long long)grid.x * grid.y * grid.z;
+    if (f16 && (a.amax_a == nullptr || a.amax_b == nullptr)) { set_error("conv_igemm_split_kernel<f16x3>: operand magnitudes missing"); return DSRL_E_BADARG; }
     if (npl) {
         const int kg = a.kg > 1 ? a.kg : 1;
         const size_t stages = (size_t)2 * (bm + bn) * npl * 32;      // two stages of 32-byte rows per K group: <= 60 KiB for every tile
@@ -1465,31 +1607,33 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
             // accumulator sets of the final reduction, whichever is larger (up to 96 KiB: opt-in attribute, set once per instantiation)
             grid = dim3((unsigned)(a.mtiles * a.ntiles), 1u, 1u);
             const size_t lds = std::max(stages * kg, (size_t)(kg - 1) * (bm / 32) * (bn / 32) / 4 * 16384);
-#define DSRL_LAUNCH_KG(a_, b_, c_, d_, NPL_, KG_)                                                                                     \
+#define DSRL_LAUNCH_KG(a_, b_, c_, d_, NPL_, KG_, F16_)                                                                               \
             {                                                                                                                          \
-                static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_>, \
+                static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_, F16_>, \
                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);            \
                 (void)attr;                                                                                                            \
-                hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_>), grid, dim3(256 * KG_), lds, st, a);      \
+                hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_, F16_>), grid, dim3(256 * KG_), lds, st, a); \
             }
+#define DSRL_KG_BY_ARITH(a_, b_, c_, d_, KG_) { if (f16) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, true) else if (npl == 2) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, false) else DSRL_LAUNCH_KG(a_, b_, c_, d_, 3, KG_, false) }
             if (cfg == T64x64) {
-                if (kg == 4) { if (npl == 2) DSRL_LAUNCH_KG(1, 1, 2, 2, 2, 4) else DSRL_LAUNCH_KG(1, 1, 2, 2, 3, 4) }
-                else { if (npl == 2) DSRL_LAUNCH_KG(1, 1, 2, 2, 2, 2) else DSRL_LAUNCH_KG(1, 1, 2, 2, 3, 2) }
+                if (kg == 4) DSRL_KG_BY_ARITH(1, 1, 2, 2, 4) else DSRL_KG_BY_ARITH(1, 1, 2, 2, 2)
             } else if (cfg == T128x64) {
-                if (npl == 2) DSRL_LAUNCH_KG(2, 1, 2, 2, 2, 2) else DSRL_LAUNCH_KG(2, 1, 2, 2, 3, 2)
+                DSRL_KG_BY_ARITH(2, 1, 2, 2, 2)
             } else {
-                if (npl == 2) DSRL_LAUNCH_KG(1, 2, 2, 2, 2, 2) else DSRL_LAUNCH_KG(1, 2, 2, 2, 3, 2)
+                DSRL_KG_BY_ARITH(1, 2, 2, 2, 2)
             }
+#undef DSRL_KG_BY_ARITH
 #undef DSRL_LAUNCH_KG
             return launch_status("conv_igemm_split_kernel<K groups>");
         }
         const size_t lds2 = stages;
 #define DSRL_LAUNCH_SPLIT(a_, b_, c_, d_)                                                                                    \
-        if (npl == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2>), grid, dim3(256), lds2, st, a); \
+        if (f16) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, true>), grid, dim3(256), lds2, st, a); \
+        else if (npl == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2>), grid, dim3(256), lds2, st, a); \
         else hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 3>), grid, dim3(256), lds2, st, a);
         DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_SPLIT)
 #undef DSRL_LAUNCH_SPLIT
-        return launch_status(npl == 2 ? "conv_igemm_split_kernel<bf16x3>" : "conv_igemm_split_kernel<bf16x6>");
+        return launch_status(f16 ? "conv_igemm_split_kernel<f16x3>" : (npl == 2 ? "conv_igemm_split_kernel<bf16x3>" : "conv_igemm_split_kernel<bf16x6>"));
     }
     const size_t lds1 = (size_t)(bm + bn) * LDS_LD * sizeof(float);
     const bool dbuf = env_int("DSRL_IGEMM_DBUF", 0) != 0;     // measured: no gain from the two-stage LDS variant; kept selectable
@@ -1578,6 +1722,7 @@ static FwdPlan plan_fwd(int N, int Hin, int Win, int Cin, int Kout, int R, int S
 static size_t plan_fwd_ws(int N, int Hin, int Win, int Cin, int Kout, int R, int S, int Ho, int Wo) {
     return std::max(plan_fwd(N, Hin, Win, Cin, Kout, R, S, Ho, Wo, 0).ws, plan_fwd(N, Hin, Win, Cin, Kout, R, S, Ho, Wo, 3).ws);
 }
+static size_t with_amax_scratch(size_t ws) { return align_up(ws, 16) + kAmaxScratch; }      // every conv workspace ends with the f16x3 scratch words
 
 }  // namespace dsrl
 
@@ -1595,7 +1740,7 @@ extern "C" int64_t dsrl_conv2d_inbounds_macs(int N, int H, int W, int C, int K, 
 extern "C" size_t dsrl_conv2d_fwd_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
     const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
     if (Ho <= 0 || Wo <= 0) return 0;
-    return plan_fwd_ws(N, H, W, C, K, R, S, Ho, Wo);
+    return with_amax_scratch(plan_fwd_ws(N, H, W, C, K, R, S, Ho, Wo));
 }
 
 // rows blocks of BatchNorm partials a forward launch of this shape writes in the current arithmetic mode (0 = it cannot: fp32 kernels,
@@ -1618,7 +1763,8 @@ extern "C" int dsrl_conv2d_fwd_stats_parts(int N, int H, int W, int C, int K, in
 
 static int fwd_impl(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                    void* ws, size_t ws_bytes, dsrl_stream_t stream, float* stats, int stats_parts) {
+                    void* ws, size_t ws_bytes, dsrl_stream_t stream, float* stats, int stats_parts,
+                    const unsigned* x_amax = nullptr, const unsigned* w_amax = nullptr) {
     if (int e = check_conv(x, w, y, N, H, W, C, K, R, S, stride, pad, dil)) return e;
     DSRL_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, DSRL_E_UNSUPPORTED,
                  "conv2d_fwd: C (%d) and ldx (%d) must be multiples of 4 and x,w 16-byte aligned", C, ldx);
@@ -1634,6 +1780,11 @@ static int fwd_impl(const float* x, int ldx, const float* w, const float* bias, 
     const long long xb = span_bytes((long long)N * H * W, ldx, C), wb = (long long)K * R * S * C * 4, yb = p.splits > 1 ? (long long)p.M * K * 4 : span_bytes(p.M, ldy, K);
     DSRL_REQUIRE_31(xb, "conv2d_fwd(x)"); DSRL_REQUIRE_31(wb, "conv2d_fwd(w)"); DSRL_REQUIRE_31(yb, "conv2d_fwd(y)");
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
+    if (conv_f16()) {
+        OperandAmax am{x_amax, w_amax};
+        if (int e = resolve_amax(am, x, ldx, (long long)N * H * W, C, w, C, (long long)K * R * S, C, ws, ws_bytes, p.ws, st, "conv2d_fwd")) return e;
+        a.amax_a = am.a; a.amax_b = am.b;
+    }
     ProfScope prof(prof_family(PASS_FWD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
     prof.shape("fwd", N, H, W, C, K, R, stride, pad, dil);
     if (p.splits > 1) {
@@ -1683,7 +1834,7 @@ static size_t dgrad_wt_bytes(int C, int K, int R, int S) { return align_up((size
 extern "C" size_t dsrl_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
     const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
     if (Ho <= 0 || Wo <= 0) return 0;
-    return dgrad_wt_bytes(C, K, R, S) + plan_fwd_ws(N, Ho, Wo, pad4(K), C, R, S, H, W);
+    return with_amax_scratch(dgrad_wt_bytes(C, K, R, S) + plan_fwd_ws(N, Ho, Wo, pad4(K), C, R, S, H, W));
 }
 
 extern "C" size_t dsrl_conv2d_transposed_filter_floats(int C, int K, int R, int S) { return (size_t)C * R * S * pad4(K); }
@@ -1708,7 +1859,8 @@ extern "C" int dsrl_conv2d_transpose_filters_batched(const int64_t* table, int n
 struct DgradBn { const float* x; const float* y; const float* mean; const float* invstd; float* stats; int ldx, ldy, relu; };
 static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                      void* ws, size_t ws_bytes, dsrl_stream_t stream, int accumulate, const DgradBn* bn = nullptr) {
+                      void* ws, size_t ws_bytes, dsrl_stream_t stream, int accumulate, const DgradBn* bn = nullptr,
+                      const unsigned* dy_amax = nullptr, const unsigned* w_amax = nullptr) {
     if (int e = check_conv(dy, w, dx, N, H, W, C, K, R, S, stride, pad, dil)) return e;
     const int Kp = pad4(K);     // K % 4 != 0 (cls_conv, 19 classes): dy must be padded to lddy >= Kp with finite pad values
     DSRL_REQUIRE(lddy % 4 == 0 && ((uintptr_t)dy % 16) == 0, DSRL_E_UNSUPPORTED,
@@ -1735,6 +1887,11 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
         const long long xb = span_bytes((long long)N * Ho * Wo, lddy, Kp), wb = (long long)C * R * S * Kp * 4, yb = p.splits > 1 ? (long long)p.M * C * 4 : span_bytes(p.M, lddx, C);
         DSRL_REQUIRE_31(xb, "conv2d_dgrad(dy)"); DSRL_REQUIRE_31(wb, "conv2d_dgrad(w)"); DSRL_REQUIRE_31(yb, "conv2d_dgrad(dx)");
         a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
+    }
+    if (conv_f16()) {
+        OperandAmax am{dy_amax, w_amax};
+        if (int e = resolve_amax(am, dy, lddy, (long long)N * Ho * Wo, Kp, w, C, (long long)K * R * S, C, ws, ws_bytes, wtb + p.ws, st, "conv2d_dgrad")) return e;
+        a.amax_a = am.a; a.amax_b = am.b;
     }
     ProfScope prof(prof_family(PASS_DGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
     prof.shape("dgrad", N, H, W, C, K, R, stride, pad, dil);
@@ -1797,6 +1954,7 @@ static void make_magic(int d, unsigned& m, unsigned& sh) {
 }
 static void launch_wgrad(const WgradArgs& a_in, TileCfg cfg, int bm, int bn, dim3 grid, hipStream_t st) {
     const int npl = conv_planes(PASS_WGRAD);
+    const bool f16 = conv_f16();
     if (npl) {
         WgradArgs a = a_in;
         make_magic(a.Ho * a.Wo, a.mHW, a.sHW);
@@ -1805,14 +1963,14 @@ static void launch_wgrad(const WgradArgs& a_in, TileCfg cfg, int bm, int bn, dim
         const int kg = a.kg > 1 ? a.kg : 1;
         if (kg > 1) {
             const size_t lds = std::max(stages * kg, (size_t)(kg - 1) * (bm / 32) * (bn / 32) / 4 * 16384);
-#define DSRL_LAUNCH_WKG(a_, b_, c_, d_, NPL_, KG_)                                                                                  \
+#define DSRL_LAUNCH_WKG(a_, b_, c_, d_, NPL_, KG_, F16_)                                                                            \
             {                                                                                                                        \
-                static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_split_kernel<a_, b_, c_, d_, NPL_, KG_>,  \
+                static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_split_kernel<a_, b_, c_, d_, NPL_, KG_, F16_>,  \
                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);          \
                 (void)attr;                                                                                                          \
-                hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, NPL_, KG_>), grid, dim3(256 * KG_), lds, st, a);         \
+                hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, NPL_, KG_, F16_>), grid, dim3(256 * KG_), lds, st, a);   \
             }
-#define DSRL_WKG_BY_NPL(a_, b_, c_, d_, KG_) { if (npl == 2) DSRL_LAUNCH_WKG(a_, b_, c_, d_, 2, KG_) else DSRL_LAUNCH_WKG(a_, b_, c_, d_, 3, KG_) }
+#define DSRL_WKG_BY_NPL(a_, b_, c_, d_, KG_) { if (f16) DSRL_LAUNCH_WKG(a_, b_, c_, d_, 2, KG_, true) else if (npl == 2) DSRL_LAUNCH_WKG(a_, b_, c_, d_, 2, KG_, false) else DSRL_LAUNCH_WKG(a_, b_, c_, d_, 3, KG_, false) }
             if (cfg == T64x64) { if (kg == 4) DSRL_WKG_BY_NPL(1, 1, 2, 2, 4) else DSRL_WKG_BY_NPL(1, 1, 2, 2, 2) }
             else if (cfg == T128x64) { if (kg == 4) DSRL_WKG_BY_NPL(2, 1, 2, 2, 4) else DSRL_WKG_BY_NPL(2, 1, 2, 2, 2) }
             else if (cfg == T64x128) { if (kg == 4) DSRL_WKG_BY_NPL(1, 2, 2, 2, 4) else DSRL_WKG_BY_NPL(1, 2, 2, 2, 2) }
@@ -1823,7 +1981,8 @@ static void launch_wgrad(const WgradArgs& a_in, TileCfg cfg, int bm, int bn, dim
         }
         const size_t lds = stages;
 #define DSRL_LAUNCH_WGRAD(a_, b_, c_, d_)                                                                           \
-        if (npl == 2) hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, 2>), grid, dim3(256), lds, st, a); \
+        if (f16) hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, 2, 1, true>), grid, dim3(256), lds, st, a); \
+        else if (npl == 2) hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, 2>), grid, dim3(256), lds, st, a); \
         else hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, 3>), grid, dim3(256), lds, st, a);
         DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_WGRAD)
 #undef DSRL_LAUNCH_WGRAD
@@ -1858,12 +2017,12 @@ static WgPlan plan_wgrad(int N, int H, int W, int C, int K, int R, int S, int st
 
 extern "C" size_t dsrl_conv2d_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
     if (out_size(H, R, stride, pad, dil) <= 0 || out_size(W, S, stride, pad, dil) <= 0) return 0;
-    return plan_wgrad(N, H, W, C, K, R, S, stride, pad, dil).ws;
+    return with_amax_scratch(plan_wgrad(N, H, W, C, K, R, S, stride, pad, dil).ws);
 }
 
-extern "C" int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
-                                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                                 void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+static int wgrad_impl(const float* x, int ldx, const float* dy, int lddy, float* dw,
+                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                      void* ws, size_t ws_bytes, dsrl_stream_t stream, const unsigned* x_amax, const unsigned* dy_amax) {
     if (int e = check_conv(x, dy, dw, N, H, W, C, K, R, S, stride, pad, dil)) return e;
     DSRL_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddy >= pad4(K) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0,
                  DSRL_E_UNSUPPORTED, "conv2d_wgrad: C (%d), ldx (%d), lddy (%d) must be multiples of 4 (lddy >= K rounded up to 4), pointers 16-byte aligned", C, ldx, lddy);
@@ -1887,6 +2046,11 @@ extern "C" int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int l
     }
     a.ntaps = p.tl.n;
     for (int i = 0; i < p.tl.n; ++i) a.taps[i] = p.tl.taps[i];
+    if (conv_f16()) {
+        OperandAmax am{dy_amax, x_amax};
+        if (int e = resolve_amax(am, dy, lddy, p.P, pad4(K), x, ldx, (long long)N * H * W, C, ws, ws_bytes, p.ws, st, "conv2d_wgrad")) return e;
+        a.amax_dy = am.a; a.amax_x = am.b;
+    }
     // pixel groups (split kernels): two groups of 4 waves share a block and half of the planned slabs remain.  Measured
     // (tools/wgrad_kg.py): 1x1 convs gain 5-20 %, 3x3 convs lose (each of their taps already has its own blocks), four groups always lose.
     int psplits = p.psplits, kg = 1;
@@ -1915,6 +2079,45 @@ extern "C" int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int l
     }
     return DSRL_OK;
 }
+extern "C" int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
+                                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                 void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    return wgrad_impl(x, ldx, dy, lddy, dw, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+// ---- the same three passes with the operand magnitudes of the f16x3 arithmetic handed in by the caller (device words holding max |.| as a
+//      bit pattern, e.g. left by the tensor's producer: dsrl_bn_*(..., y_amax), dsrl_conv2d_transpose_filters_batched; dsrl_amax measures one);
+//      a null word is measured by the call itself, the other arithmetics ignore them
+extern "C" int dsrl_amax(const float* x, int ld, int64_t P, int C, uint32_t* amax, dsrl_stream_t stream) {
+    DSRL_REQUIRE(x && amax && ld >= C && C > 0 && P > 0, DSRL_E_BADARG, "amax: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    return launch_amax(x, ld, P, C, amax, st);
+}
+extern "C" int dsrl_conv2d_fwd_amax(const float* x, int ldx, const uint32_t* x_amax, const float* w, const uint32_t* w_amax, const float* bias, float* y, int ldy,
+                                    int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                    void* ws, size_t ws_bytes, float* stats, int stats_parts, dsrl_stream_t stream) {
+    return fwd_impl(x, ldx, w, bias, y, ldy, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, stats, stats_parts, x_amax, w_amax);
+}
+extern "C" int dsrl_conv2d_dgrad_amax(const float* dy, int lddy, const uint32_t* dy_amax, const float* w, const float* wt_in, const uint32_t* w_amax, float* dx, int lddx,
+                                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                      void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y, int bn_ldy,
+                                      const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats, int stats_parts, int accumulate,
+                                      dsrl_stream_t stream) {
+    if (bstats == nullptr)
+        return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, accumulate ? 1 : 0, nullptr, dy_amax, w_amax);
+    DSRL_REQUIRE(bn_x && bn_mean && bn_invstd && (bn_y || !bn_relu) && bn_ldx >= C && (!bn_relu || bn_ldy >= C), DSRL_E_BADARG, "conv2d_dgrad_amax: bad BatchNorm arguments");
+    DSRL_REQUIRE(dsrl_conv2d_dgrad_stats_parts(N, H, W, C, K, R, S, stride, pad, dil) == stats_parts && stats_parts > 0, DSRL_E_BADARG,
+                 "conv2d_dgrad_amax: this launch writes %d row blocks of partials, the caller expects %d",
+                 dsrl_conv2d_dgrad_stats_parts(N, H, W, C, K, R, S, stride, pad, dil), stats_parts);
+    DgradBn bn{bn_x, bn_y, bn_mean, bn_invstd, bstats, bn_ldx, bn_ldy, bn_relu};
+    return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, accumulate ? 1 : 0, &bn, dy_amax, w_amax);
+}
+extern "C" int dsrl_conv2d_wgrad_amax(const float* x, int ldx, const uint32_t* x_amax, const float* dy, int lddy, const uint32_t* dy_amax, float* dw,
+                                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                      void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    return wgrad_impl(x, ldx, dy, lddy, dw, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, x_amax, dy_amax);
+}
 
 
 // ------------------------------------------------------------------------------------------------ grouped wgrad
@@ -1928,7 +2131,7 @@ constexpr unsigned kGroupMagic = 0x44535247u;       // "DSRG"
 constexpr int kGroupMaxProblems = 512, kGroupMaxLaunches = kNumCfg;
 struct GroupLaunch { int cfg, first, count, grid; double flops, bytes; };
 struct GroupHeader {
-    unsigned magic; int n, nlaunch, npl;
+    unsigned magic; int n, nlaunch, npl, f16;
     GroupLaunch launch[kGroupMaxLaunches];
     int rgrid;                      // blocks of the slab reduce (0: no problem is split)
     long long args_off, starts_off, rstarts_off, used_bytes;      // byte offsets inside the table
@@ -1975,6 +2178,9 @@ static int group_item(const dsrl_wgrad_problem& q, int npl, GroupItem& it) {
     a.rblocks = a.psplits > 1 ? (int)ceil_div((long long)K * a.ntaps * (C / 4), 1024) : 0;
     make_magic(a.Ho * a.Wo, a.mHW, a.sHW);
     make_magic(a.Wo, a.mW, a.sW);
+    DSRL_REQUIRE(!conv_f16() || (q.x_amax != nullptr && q.dy_amax != nullptr), DSRL_E_BADARG,
+                 "conv2d_wgrad_group: the f16x3 arithmetic needs x_amax / dy_amax of every problem (dsrl_amax measures a tensor)");
+    a.amax_x = q.x_amax; a.amax_dy = q.dy_amax;
     it.a = a; it.cfg = p.cfg; it.bm = p.bm; it.bn = p.bn;
     it.cost = (double)p.P / a.psplits * p.bm * p.bn;
     it.flops = 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil);
@@ -2021,7 +2227,7 @@ extern "C" int dsrl_conv2d_wgrad_group_plan(const dsrl_wgrad_problem* problems, 
     char* base = (char*)host_table;
     memset(base, 0, group_table_bytes(n));
     GroupHeader* h = (GroupHeader*)base;
-    h->magic = kGroupMagic; h->n = n; h->npl = npl; h->nlaunch = 0;
+    h->magic = kGroupMagic; h->n = n; h->npl = npl; h->nlaunch = 0; h->f16 = conv_f16() ? 1 : 0;
     h->args_off = (long long)align_up(sizeof(GroupHeader), 256);
     h->starts_off = h->args_off + (long long)align_up((size_t)n * sizeof(WgradArgs), 256);
     h->rstarts_off = h->starts_off + (long long)align_up((size_t)(n + 1) * sizeof(int), 256);
@@ -2074,9 +2280,10 @@ extern "C" int dsrl_conv2d_wgrad_group_launch(const void* host_table, const void
         const size_t lds = (size_t)2 * npl * 16 * ((bm * 2 + 64) + (bn * 2 + 64));
         const WgradArgs* t = dargs + L.first;
         const int* s = dstarts + L.first;
-        ProfScope prof(3 * (npl - 1) + 1, L.flops, L.bytes, st);
+        ProfScope prof(3 * (h->f16 ? 3 : npl - 1) + 1, L.flops, L.bytes, st);
 #define DSRL_LAUNCH_WGROUP(a_, b_, c_, d_)                                                                                         \
-        if (npl == 2) hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 2>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count); \
+        if (h->f16) hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 2, true>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count); \
+        else if (npl == 2) hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 2>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count); \
         else hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 3>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count);
         DSRL_CFG_SWITCH((TileCfg)L.cfg, DSRL_LAUNCH_WGROUP)
 #undef DSRL_LAUNCH_WGROUP
@@ -2100,7 +2307,7 @@ static int check_rowfold(const void* a, const void* b, const void* c, int ldx, i
 }
 extern "C" size_t dsrl_conv2d_rowfold_fwd_workspace_bytes(int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo) {
     (void)stride;
-    return plan_fwd_ws(N, H, W, Cfold, K, R, 1, Ho, Wo);
+    return with_amax_scratch(plan_fwd_ws(N, H, W, Cfold, K, R, 1, Ho, Wo));
 }
 extern "C" int dsrl_conv2d_rowfold_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                                        int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo, int64_t algorithmic_macs,
@@ -2118,6 +2325,11 @@ extern "C" int dsrl_conv2d_rowfold_fwd(const float* x, int ldx, const float* w, 
         const long long xb = (long long)N * H * W * ldx * 4, wb = (long long)K * R * Cfold * 4, yb = p.splits > 1 ? (long long)p.M * K * 4 : span_bytes(p.M, ldy, K);
         DSRL_REQUIRE_31(xb, "conv2d_rowfold_fwd(x)"); DSRL_REQUIRE_31(wb, "conv2d_rowfold_fwd(w)"); DSRL_REQUIRE_31(yb, "conv2d_rowfold_fwd(y)");
         a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
+    }
+    if (conv_f16()) {       // the image and the folded filter are measured by the call itself
+        OperandAmax am{nullptr, nullptr};
+        if (int e = resolve_amax(am, x, ldx, (long long)N * H * W, ldx, w, Cfold, (long long)K * R, Cfold, ws, ws_bytes, p.ws, st, "conv2d_rowfold_fwd")) return e;
+        a.amax_a = am.a; a.amax_b = am.b;
     }
     ProfScope prof(prof_family(PASS_FWD), 2.0 * (double)algorithmic_macs, 4.0 * ((double)N * H * W * ldx + (double)K * R * Cfold + (double)N * Ho * Wo * K), st);
     if (p.splits > 1) {
@@ -2148,7 +2360,7 @@ static WgPlan plan_wgrad_rowfold(int N, int Cf, int K, int R, int Ho, int Wo) {
 }  // namespace dsrl
 extern "C" size_t dsrl_conv2d_rowfold_wgrad_workspace_bytes(int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo) {
     (void)H; (void)W; (void)stride;
-    return plan_wgrad_rowfold(N, Cfold, K, R, Ho, Wo).ws;
+    return with_amax_scratch(plan_wgrad_rowfold(N, Cfold, K, R, Ho, Wo).ws);
 }
 extern "C" int dsrl_conv2d_rowfold_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
                                          int N, int H, int W, int Cfold, int K, int R, int stride, int Ho, int Wo, int64_t algorithmic_macs,
@@ -2173,6 +2385,11 @@ extern "C" int dsrl_conv2d_rowfold_wgrad(const float* x, int ldx, const float* d
     a.dw = p.psplits > 1 ? (float*)ws : dw;
     a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
     dim3 grid((unsigned)(a.kctiles * R * p.psplits));
+    if (conv_f16()) {
+        OperandAmax am{nullptr, nullptr};
+        if (int e = resolve_amax(am, dy, lddy, p.P, pad4(K), x, ldx, (long long)N * H * W, ldx, ws, ws_bytes, p.ws, st, "conv2d_rowfold_wgrad")) return e;
+        a.amax_dy = am.a; a.amax_x = am.b;
+    }
     ProfScope prof(prof_family(PASS_WGRAD), 2.0 * (double)algorithmic_macs, 4.0 * ((double)N * H * W * ldx + (double)K * R * Cfold + (double)N * Ho * Wo * K), st);
     launch_wgrad(a, p.cfg, p.bm, p.bn, grid, st);
     if (int e = launch_status("conv_wgrad kernel")) return e;
@@ -2187,7 +2404,7 @@ extern "C" int dsrl_conv2d_rowfold_wgrad(const float* x, int ldx, const float* d
 
 extern "C" int dsrl_conv_precision(int mode) {
     const int prev = g_conv_precision.load();
-    if (mode >= -1 && mode <= 3) g_conv_precision.store(mode);
+    if (mode >= -1 && mode <= 4) g_conv_precision.store(mode);
     return prev;
 }
 
@@ -2231,9 +2448,10 @@ extern "C" int dsrl_prof_read_bytes(int family, double* total_bytes) {
 }
 
 extern "C" const char* dsrl_prof_kernel_name(int family) {
-    static const char* names[9] = {
+    static const char* names[12] = {
         "conv_igemm_f32_kernel (forward)", "conv_wgrad_f32_kernel", "conv_igemm_f32_kernel (dgrad)",
         "conv_igemm_split_kernel<bf16x3> (forward)", "conv_wgrad_split_kernel<bf16x3>", "conv_igemm_split_kernel<bf16x3> (dgrad)",
-        "conv_igemm_split_kernel<bf16x6> (forward)", "conv_wgrad_split_kernel<bf16x6>", "conv_igemm_split_kernel<bf16x6> (dgrad)"};
-    return family >= 0 && family < 9 ? names[family] : "";
+        "conv_igemm_split_kernel<bf16x6> (forward)", "conv_wgrad_split_kernel<bf16x6>", "conv_igemm_split_kernel<bf16x6> (dgrad)",
+        "conv_igemm_split_kernel<f16x3> (forward)", "conv_wgrad_split_kernel<f16x3>", "conv_igemm_split_kernel<f16x3> (dgrad)"};
+    return family >= 0 && family < 12 ? names[family] : "";
 }

@@ -164,18 +164,23 @@ class FlatParams:
         if not entries:
             return
         self.wt_flat = torch.empty(floats, device=self.device, dtype=torch.float32)
+        # one magnitude word per filter (max |w| as a bit pattern), re-measured by the same launch: the filter-side operand scale of the
+        # f16x3 conv arithmetic (include/dsrl_hip.h: dsrl_amax)
+        self.w_amax = torch.zeros(len(entries), device=self.device, dtype=torch.int32)
         rows, tiles = [], 0
-        for w, K, Kp, RS, C, off in entries:
+        for i, (w, K, Kp, RS, C, off) in enumerate(entries):
             wt = self.wt_flat[off:off + C * RS * Kp]
             w._dsrl_wt = wt
+            w._dsrl_wamax = self.w_amax[i:i + 1]
             ct = (C + 31) // 32
-            rows.append([w.data_ptr(), wt.data_ptr(), K, Kp, RS, C, tiles, ct])
+            rows.append([w.data_ptr(), wt.data_ptr(), K, Kp, RS, C, tiles, ct, self.w_amax.data_ptr() + 4 * i, 0])
             tiles += RS * ct * ((Kp + 31) // 32)
         self._wt_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
         self._wt_rows, self._wt_tiles = len(rows), tiles
 
     def refresh_transposed_filters(self):
         if self._wt_table is not None and os.environ.get('DSRL_BATCHED_TRANSPOSE', '1') != '0':
+            self.w_amax.zero_()
             HF.call('dsrl_conv2d_transpose_filters_batched', self._wt_table.data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
             self.wt_valid = True
 
@@ -186,6 +191,8 @@ class FlatParams:
         self._works = []
         if self.device.type == 'cuda':
             HF.open_wgrad_queue()           # the convs of this step defer their weight gradients (functional.WgradQueue)
+            if HF.f16_mode():
+                HF.amax_begin_step(self.device)     # operand-magnitude slots of this step (functional.amax_slot)
 
     def finish_reduction(self):
         """Waits (stream-wise) for the chunk all-reduces launched during backward; chunks whose hooks did not all fire

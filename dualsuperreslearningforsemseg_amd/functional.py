@@ -38,26 +38,91 @@ overlap_wgrad = os.environ.get('DSRL_OVERLAP_WGRAD', '1') != '0'     # measured:
 pretranspose_filters = os.environ.get('DSRL_PRETRANSPOSE', '0') != '0'
 
 
-CONV_PRECISION_MODES = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'mixed': 3}
+CONV_PRECISION_MODES = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'mixed': 3, 'f16x3': 4}
+DEFAULT_CONV_PRECISION = 2
 
 
 def set_conv_precision(mode):
     """Arithmetic of the conv kernels (include/dsrl_hip.h: dsrl_conv_precision): 'fp32' (exact fp32 MFMA products), 'bf16x3',
-    'bf16x6' (fp32-equivalent; the default) or 'mixed' (forward bf16x6, backward bf16x3); None follows DSRL_CONV_PRECISION.
+    'bf16x6' (fp32-equivalent; the default), 'mixed' (forward bf16x6, backward bf16x3) or 'f16x3' (two fp16 terms of the per-tensor
+    scaled operands: fp32-equivalent at half the matrix work of bf16x6); None follows DSRL_CONV_PRECISION.
     Returns the previous setting as the library reported it (an int, -1 = environment)."""
     code = -1 if mode is None else (CONV_PRECISION_MODES[mode] if isinstance(mode, str) else int(mode))
-    if not -1 <= code <= 3:
+    if not -1 <= code <= 4:
         raise ValueError(f'conv precision mode {mode!r}')
+    _mode_cache.clear()
     return int(_lib.load().dsrl_conv_precision(code))
+
+
+_mode_cache = {}
+
+
+def _conv_precision_code():
+    code = _mode_cache.get('code')
+    if code is None:
+        prev = int(_lib.load().dsrl_conv_precision(-2))          # out-of-range argument: query only
+        code = prev if prev >= 0 else int(os.environ.get('DSRL_CONV_PRECISION', str(DEFAULT_CONV_PRECISION)))
+        code = _mode_cache['code'] = min(max(code, 0), 4)
+    return code
 
 
 def get_conv_precision():
     """Name of the mode the conv kernels currently run in."""
-    lib = _lib.load()
-    prev = int(lib.dsrl_conv_precision(-2))          # out-of-range argument: query only
-    code = prev if prev >= 0 else int(os.environ.get('DSRL_CONV_PRECISION', '2'))
-    code = min(max(code, 0), 3)
+    code = _conv_precision_code()
     return [k for k, v in CONV_PRECISION_MODES.items() if v == code][0]
+
+
+# ------------------------------------------------------------------------------------------------ operand magnitudes (f16x3 arithmetic)
+# The f16x3 conv kernels scale every operand tensor by a power of two taken from max |x| of the whole tensor (include/dsrl_hip.h:
+# dsrl_amax).  A magnitude is one uint32 device word ("slot"); a tensor that has one carries it as the attribute `_dsrl_amax`, left by
+# the kernel that wrote the tensor (BatchNorm apply / backward, the batched filter transpose) or by a dsrl_amax launch here, so that the
+# forward conv and the weight gradient (x) and the data and weight gradients (dy) share one measurement.  Slots come from an arena that
+# ddp.FlatParams.zero_grad() rewinds and zeroes at the start of every training step (one memset; static addresses under graph capture).
+_AMAX_SLOTS = 8192
+_amax_arena = {}            # device -> [int32 tensor, next free slot]
+
+
+def amax_begin_step(device):
+    """Rewinds the slot arena of `device` and zeroes it (stream-ordered): every slot handed out before belongs to a finished step."""
+    ar = _amax_arena.get(device)
+    if ar is None:
+        ar = _amax_arena[device] = [torch.zeros(_AMAX_SLOTS, dtype=torch.int32, device=device), 0]
+    else:
+        ar[0].zero_()
+        ar[1] = 0
+    return ar
+
+
+def amax_slot(device):
+    ar = _amax_arena.get(device)
+    if ar is None or ar[1] >= _AMAX_SLOTS:
+        # no step context (or an exhausted arena): a fresh zeroed arena; views keep the old one alive for the kernels that still read it
+        ar = _amax_arena[device] = [torch.zeros(_AMAX_SLOTS, dtype=torch.int32, device=device), 0]
+    i = ar[1]
+    ar[1] = i + 1
+    return ar[0][i:i + 1]
+
+
+def f16_mode():
+    return _conv_precision_code() == 4
+
+
+def amax_for(t, data=None, ld=None):
+    """The magnitude slot of pixel-major tensor `t` (N,C,H,W): the one it carries, or a fresh measurement that it then carries.
+    `data`/`ld`: the pixel-major copy of `t` the kernels read, if the caller already has it."""
+    slot = getattr(t, '_dsrl_amax', None)
+    if slot is not None:
+        return slot
+    if data is None:
+        data, ld = pm(t)
+    N, Cc, H, W = data.shape
+    slot = amax_slot(data.device)
+    call('dsrl_amax', data.data_ptr(), ld, N * H * W, Cc, slot.data_ptr(), _stream())
+    try:
+        t._dsrl_amax = slot
+    except Exception:           # noqa: BLE001
+        pass
+    return slot
 
 
 def set_bn_fused_max_blocks(n):
@@ -101,8 +166,8 @@ class WgradQueue:
     def __init__(self):
         self.items = []           # (x, ldx, dy, lddy, dw tensor, shp, on_written)
 
-    def add(self, x, ldx, dy, lddy, dw, shp, on_written=None):
-        self.items.append((x, ldx, dy, lddy, dw, shp, on_written))
+    def add(self, x, ldx, dy, lddy, dw, shp, on_written=None, x_amax=None, dy_amax=None):
+        self.items.append((x, ldx, dy, lddy, dw, shp, on_written, x_amax, dy_amax))
 
     def flush(self):
         items, self.items = self.items, []
@@ -110,9 +175,11 @@ class WgradQueue:
             return
         n = len(items)
         probs = (_lib.WgradProblem * n)()
-        for q, (x, ldx, dy, lddy, dw, shp, _) in zip(probs, items):
+        for q, (x, ldx, dy, lddy, dw, shp, _, xa, dya) in zip(probs, items):
             N, H, W, Cc, K, R, S, stride, pad, dil = shp
             q.x, q.dy, q.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+            q.x_amax = None if xa is None else xa.data_ptr()
+            q.dy_amax = None if dya is None else dya.data_ptr()
             q.ldx, q.lddy, q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.dil = ldx, lddy, N, H, W, Cc, K, R, S, stride, pad, dil
         import ctypes
         lib = _lib.load()
@@ -284,6 +351,14 @@ def _sink(param, like_shape=None):
     return param.grad
 
 
+def _weight_amax(w):
+    """Magnitude slot of a conv filter that ddp.FlatParams keeps (measured by the batched filter transpose of this step), or None."""
+    arena, slot = getattr(w, '_dsrl_arena', None), getattr(w, '_dsrl_wamax', None)
+    if slot is not None and arena is not None and arena.wt_valid:
+        return slot
+    return None
+
+
 def _is_krsc(w):
     """Is the (K,C,R,S) filter physically [K][R][S][C]?  (torch does not call plain-strided 1x1 filters channels_last although the
     two layouts coincide for them)"""
@@ -384,6 +459,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.set_materialize_grads(False)       # no zero tensor for the (non-differentiable) statistics output's gradient
         ctx.gslot = gslot
         ctx.in_link = in_link
+        x_in = x
         x, ldx = pm_vec4(x)
         w_param = w
         w = w_cl(w)
@@ -398,13 +474,16 @@ class _Conv2d(torch.autograd.Function):
         if bias is not None:
             _need_gpu(bias)
         stats = None
+        xa = wa = None
+        if f16_mode():              # operand magnitudes of the f16x3 arithmetic (the library measures what it is not given)
+            xa = amax_for(x_in, x, ldx)
+            wa = _weight_amax(w_param)
+        ctx.amax = (xa, wa)
         if stats_parts > 0:         # BatchNorm partials of y from the conv epilogue (include/dsrl_hip.h: dsrl_conv2d_fwd_stats)
             stats = torch.empty(3 * stats_parts * K, device=x.device, dtype=torch.float32)
-            call('dsrl_conv2d_fwd_stats', x.data_ptr(), ldx, w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), K,
-                 *shp, ws.data_ptr(), ws.numel(), stats.data_ptr(), int(stats_parts), _stream())
-        else:
-            call('dsrl_conv2d_fwd', x.data_ptr(), ldx, w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), K,
-                 *shp, ws.data_ptr(), ws.numel(), _stream())
+        call('dsrl_conv2d_fwd_amax', x.data_ptr(), ldx, None if xa is None else xa.data_ptr(), w.data_ptr(), None if wa is None else wa.data_ptr(),
+             None if bias is None else bias.data_ptr(), y.data_ptr(), K, *shp, ws.data_ptr(), ws.numel(),
+             None if stats is None else stats.data_ptr(), int(stats_parts), _stream())
         ctx.save_for_backward(x, w)
         ctx.shp = shp
         ctx.has_bias = bias is not None
@@ -433,28 +512,38 @@ class _Conv2d(torch.autograd.Function):
         x, w = ctx.saved_tensors
         shp = ctx.shp
         N, H, W, Cc, K, R, S, stride, pad, dil = shp
+        dy_in = dy
         dy, lddy = pm_vec4(dy)
         ldx = _ld_of(x)
         dx = dw = db = None
         st = _stream()
+        xa, wa = ctx.amax
+        dya = None
+        if f16_mode():
+            dya = amax_for(dy_in, dy, lddy)          # one measurement for the data and the weight gradient
+            if xa is None:
+                xa = amax_for(x, x, ldx)
+            if wa is not None and ctx.wparam is not None and not getattr(getattr(ctx.wparam, '_dsrl_arena', None), 'wt_valid', False):
+                wa = None                             # the filter changed since its magnitude was taken
+        p_ = lambda t_: None if t_ is None else t_.data_ptr()       # noqa: E731
         if ctx.needs_input_grad[1]:
             sink = _sink(ctx.wparam) if ctx.wparam is not None and _is_krsc(ctx.wparam) else None
             if sink is not None and wgrad_queue is not None:
                 # deferred: all weight gradients of this backward pass run as a few grouped grids when the pass is over
                 wp = ctx.wparam
-                wgrad_queue.add(x, ldx, dy, lddy, sink, shp, lambda wp=wp: wp._dsrl_arena.written(wp))
+                wgrad_queue.add(x, ldx, dy, lddy, sink, shp, lambda wp=wp: wp._dsrl_arena.written(wp), xa, dya)
             elif sink is not None and overlap_wgrad and ctx.needs_input_grad[0]:
                 cur, side = torch.cuda.current_stream(), side_stream(x.device)
                 side.wait_stream(cur)                                   # dy (and x) are ready on the compute stream
                 with torch.cuda.stream(side):
                     ws = _ws(cquery('dsrl_conv2d_wgrad_workspace_bytes', *shp), x)
-                    call('dsrl_conv2d_wgrad', x.data_ptr(), ldx, dy.data_ptr(), lddy, sink.data_ptr(), *shp, ws.data_ptr(), ws.numel(), side.cuda_stream)
+                    call('dsrl_conv2d_wgrad_amax', x.data_ptr(), ldx, p_(xa), dy.data_ptr(), lddy, p_(dya), sink.data_ptr(), *shp, ws.data_ptr(), ws.numel(), side.cuda_stream)
                 x.record_stream(side); dy.record_stream(side)
                 ctx.wparam._dsrl_arena.written(ctx.wparam, side)
             else:
                 dw = sink if sink is not None else torch.empty((K, Cc, R, S), device=x.device, dtype=torch.float32, memory_format=CL)
                 ws = _ws(cquery('dsrl_conv2d_wgrad_workspace_bytes', *shp), x)
-                call('dsrl_conv2d_wgrad', x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(), *shp, ws.data_ptr(), ws.numel(), st)
+                call('dsrl_conv2d_wgrad_amax', x.data_ptr(), ldx, p_(xa), dy.data_ptr(), lddy, p_(dya), dw.data_ptr(), *shp, ws.data_ptr(), ws.numel(), st)
                 if sink is not None:
                     ctx.wparam._dsrl_arena.written(ctx.wparam)
                     dw = None
@@ -486,13 +575,13 @@ class _Conv2d(torch.autograd.Function):
                 # x is y = relu(bn(.)) of a BatchNorm that feeds only this conv: leave its backward partial sums with the data gradient
                 bstats = torch.empty(2 * parts * Cc, device=x.device, dtype=torch.float32)
                 _, bld = pm(link.x)
-                call('dsrl_conv2d_dgrad_bnstats', dy.data_ptr(), lddy, w.data_ptr(), wt_ptr, dx.data_ptr(), Cc, *shp, ws.data_ptr(), ws.numel(),
+                call('dsrl_conv2d_dgrad_amax', dy.data_ptr(), lddy, p_(dya), w.data_ptr(), wt_ptr, p_(wa), dx.data_ptr(), Cc, *shp, ws.data_ptr(), ws.numel(),
                      link.x.data_ptr(), bld, x.data_ptr(), ldx, link.mean.data_ptr(), link.invstd.data_ptr(), int(link.relu),
                      bstats.data_ptr(), parts, int(acc), st)
                 link.stats, link.parts, link.dx_ptr = bstats, parts, dx.data_ptr()
             else:
-                call('dsrl_conv2d_dgrad_accumulate' if acc else 'dsrl_conv2d_dgrad', dy.data_ptr(), lddy, w.data_ptr(), wt_ptr, dx.data_ptr(), Cc, *shp,
-                     ws.data_ptr(), ws.numel(), st)
+                call('dsrl_conv2d_dgrad_amax', dy.data_ptr(), lddy, p_(dya), w.data_ptr(), wt_ptr, p_(wa), dx.data_ptr(), Cc, *shp,
+                     ws.data_ptr(), ws.numel(), None, 0, None, 0, None, None, 0, None, 0, int(acc), st)
             if acc:
                 dx = None                   # the contribution went into the buffer autograd already holds for this input
             elif slot is not None:

@@ -68,9 +68,11 @@ int dsrl_conv2d_fwd_stats(const float* x, int ldx, const float* w, const float* 
  * dsrl_conv2d_transpose_filter (e.g. built during the forward pass on another stream) or NULL to have it built here in `ws`. */
 size_t dsrl_conv2d_transposed_filter_floats(int C, int K, int R, int S);
 int dsrl_conv2d_transpose_filter(const float* w, float* wt, int C, int K, int R, int S, dsrl_stream_t stream);
-/* The same for n filters in one launch (once per training step instead of once per layer): table is a DEVICE array of n rows of eight
- * int64 {w pointer, wt pointer, K, Kp = K rounded up to 4, R*S, C, index of the row's first 32x32 tile, ceil(C/32)}, rows ordered by
- * first tile; total_tiles = sum over rows of R*S * ceil(C/32) * ceil(Kp/32). */
+/* The same for n filters in one launch (once per training step instead of once per layer): table is a DEVICE array of n rows of ten
+ * int64 {w pointer, wt pointer, K, Kp = K rounded up to 4, R*S, C, index of the row's first 32x32 tile, ceil(C/32), amax pointer, 0}, rows
+ * ordered by first tile; total_tiles = sum over rows of R*S * ceil(C/32) * ceil(Kp/32). A non-zero amax pointer names a uint32 device word
+ * (zeroed by the caller before the launch) into which the launch maxes the bit pattern of max |w| of that filter: the filter's operand
+ * magnitude for the "f16x3" arithmetic (dsrl_conv2d_*_amax below). */
 int dsrl_conv2d_transpose_filters_batched(const int64_t* table, int n, int64_t total_tiles, dsrl_stream_t stream);
 size_t dsrl_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, const float* wt /*nullable*/, float* dx, int lddx,
@@ -99,7 +101,7 @@ int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
 /* Grouped weight gradients: every dsrl_conv2d_wgrad of a backward pass as a few grids (one per tile configuration, blocks ordered
  * longest first) plus one slab reduce, instead of one launch + reduce per layer. The weight gradients of a pass depend on nothing
  * but (x, dy) of their layer and are read by the optimiser only, so the caller may collect the problems while backward runs and
- * launch them once at its end (ddp.FlatParams does). Split-precision arithmetics only (dsrl_conv_precision 1..3).
+ * launch them once at its end (ddp.FlatParams does). Split-precision arithmetics only (dsrl_conv_precision 1..4).
  *   1. ws  = dsrl_conv2d_wgrad_group_workspace_bytes(problems, n); table = dsrl_conv2d_wgrad_group_table_bytes(n)
  *   2. dsrl_conv2d_wgrad_group_plan(problems, n, host_table, table, dev_table, ws_ptr, ws)  - fills host_table (host memory) with
  *      device-side descriptors that hold absolute device pointers (x, dy, dw, slabs inside ws_ptr) and offsets valid for dev_table
@@ -109,18 +111,43 @@ int dsrl_conv2d_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
 typedef struct dsrl_wgrad_problem {
     const float* x; const float* dy; float* dw;
     int32_t ldx, lddy, N, H, W, C, K, R, S, stride, pad, dil;
+    const uint32_t* x_amax; const uint32_t* dy_amax;      /* "f16x3" arithmetic: operand magnitudes of x and dy (required there, else unused) */
 } dsrl_wgrad_problem;
 size_t dsrl_conv2d_wgrad_group_table_bytes(int n);
 size_t dsrl_conv2d_wgrad_group_workspace_bytes(const dsrl_wgrad_problem* problems, int n);
 int dsrl_conv2d_wgrad_group_plan(const dsrl_wgrad_problem* problems, int n, void* host_table, size_t table_bytes, const void* dev_table,
                                  void* ws, size_t ws_bytes);
 int dsrl_conv2d_wgrad_group_launch(const void* host_table, const void* dev_table, dsrl_stream_t stream);
+/* Operand magnitudes for the "f16x3" arithmetic (dsrl_conv_precision 4). That arithmetic carries every operand as two fp16 terms of
+ * x * 2^e, with e chosen per TENSOR so that the tensor's largest magnitude lands in [2^14, 2^15); it therefore needs max |x| of both
+ * operands of a launch, as a uint32 device word holding the bit pattern of max |x| ("amax word"). Producers can leave that word while
+ * they write the tensor (the y_amax / dx_amax arguments of the BatchNorm kernels, the batched filter transpose above); dsrl_amax measures
+ * any pixel-major tensor: it maxes into *amax atomically, the caller zeroes the word first (several calls may share a word).
+ * The *_amax entry points below are dsrl_conv2d_fwd(_stats) / _dgrad(_bnstats, _accumulate) / _wgrad with the two words passed in; a
+ * null word - and every call through the plain entry points - is measured by the call itself (one extra pass over that operand, in
+ * the last 256 bytes of the workspace, which the *_workspace_bytes queries include). The other arithmetics ignore the words.
+ * dsrl_conv2d_fwd_amax: stats may be null (no BatchNorm partials); dsrl_conv2d_dgrad_amax: bstats may be null (no BatchNorm sums; the
+ * bn_* arguments are then unused), accumulate as in dsrl_conv2d_dgrad_accumulate. */
+int dsrl_amax(const float* x, int ld, int64_t P, int C, uint32_t* amax, dsrl_stream_t stream);
+int dsrl_conv2d_fwd_amax(const float* x, int ldx, const uint32_t* x_amax, const float* w, const uint32_t* w_amax, const float* bias /*nullable*/,
+                         float* y, int ldy, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                         void* ws, size_t ws_bytes, float* stats /*nullable*/, int stats_parts, dsrl_stream_t stream);
+int dsrl_conv2d_dgrad_amax(const float* dy, int lddy, const uint32_t* dy_amax, const float* w, const float* wt /*nullable*/, const uint32_t* w_amax,
+                           float* dx, int lddx, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                           void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y, int bn_ldy,
+                           const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats /*nullable*/, int stats_parts, int accumulate,
+                           dsrl_stream_t stream);
+int dsrl_conv2d_wgrad_amax(const float* x, int ldx, const uint32_t* x_amax, const float* dy, int lddy, const uint32_t* dy_amax, float* dw,
+                           int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                           void* ws, size_t ws_bytes, dsrl_stream_t stream);
 /* Arithmetic of the implicit-GEMM conv kernels (forward, dgrad, wgrad, row-folded stem), process-wide. fp32 in, fp32 out and fp32
  * accumulation in every mode; the modes differ in how the products are formed on the matrix cores:
  *   0  v_mfma_f32_32x32x2_f32 (exact fp32 products)
  *   1  "bf16x3": operand = 2 bf16 terms (16 mantissa bits), 3 bf16 MFMAs per product; ~5e-6 relative error per conv
  *   2  "bf16x6": operand = 3 bf16 terms (24 mantissa bits), 6 bf16 MFMAs per product; error vs fp64 equal to mode 0 (default)
  *   3  "mixed": forward bf16x6, dgrad / wgrad bf16x3 (reduced-precision gradients, ~5e-6)
+ *   4  "f16x3": operand = 2 fp16 terms of the per-tensor scaled value (22 mantissa bits), 3 fp16 MFMAs per product; error vs fp64 equal
+ *      to modes 0 and 2 at half the matrix work of mode 2 (operand magnitudes: see dsrl_amax above)
  *  -1  follow the environment variable DSRL_CONV_PRECISION (unset = 2)
  * Any other value changes nothing (query). Returns the previous setting. */
 int dsrl_conv_precision(int mode);
