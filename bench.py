@@ -38,11 +38,13 @@ sys.path.insert(0, ROOT)
 # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak 157.3 TFLOP/s, dense bf16 2516.6 TFLOP/s, HBM 8 TB/s.  A split-precision
 # conv issues 3 (bf16x3) or 6 (bf16x6) bf16 MFMAs per algorithmic product, so its MFMA roof for ALGORITHMIC flops is the bf16 peak / 3 or / 6.
 BF16_MFMA_PEAK_TFLOPS = 2516.6
-MFMA_PEAK_TFLOPS = {0: 157.3, 1: BF16_MFMA_PEAK_TFLOPS / 3, 2: BF16_MFMA_PEAK_TFLOPS / 6}      # by arithmetic: fp32, bf16x3, bf16x6
-ARITH_NAME = {0: 'fp32', 1: 'bf16x3', 2: 'bf16x6'}
+MFMA_PEAK_TFLOPS = {0: 157.3, 1: BF16_MFMA_PEAK_TFLOPS / 3, 2: BF16_MFMA_PEAK_TFLOPS / 6, 3: BF16_MFMA_PEAK_TFLOPS / 3}      # by arithmetic: fp32, bf16x3, bf16x6, f16x3
+ARITH_NAME = {0: 'fp32', 1: 'bf16x3', 2: 'bf16x6', 3: 'f16x3'}
 HBM_PEAK_GBS = 8000.0
 ARITH_TEXT = {'fp32': 'exact-product fp32 MFMA', 'bf16x3': 'bf16x3 split, fp32 accumulate', 'bf16x6': 'bf16x6 split (fp32-equivalent), fp32 accumulate',
-              'mixed': 'forward bf16x6 (fp32-equivalent), dgrad/wgrad bf16x3 (reduced-precision gradients); fp32 storage and accumulation'}
+              'mixed': 'forward bf16x6 (fp32-equivalent), dgrad/wgrad bf16x3 (reduced-precision gradients); fp32 storage and accumulation',
+              'f16x3': 'f16x3 split (two fp16 terms of the per-tensor power-of-two scaled operands, 3 MFMAs per product; fp32-equivalent: error vs fp64 '
+                       'equal to exact-product fp32 MFMA), fp32 storage and accumulation'}
 
 
 def parse_args():
@@ -151,9 +153,9 @@ def decoder_stack_roofline(torch, HF, B, H, W, reps=10):
               ('cat_conv.0 3x3 304->256', 304, h4, w4, 256, 3, 1, 1), ('cat_conv.4 3x3 256->256', 256, h4, w4, 256, 3, 1, 1), ('cls_conv 1x1 256->19', 256, h4, w4, 19, 1, 0, 1),
               ('SISR 3x3 304->192', 304, h4, w4, 192, 3, 1, 1)]
     mode = HF.get_conv_precision()
-    arith = {'fp32': (0, 0, 0), 'bf16x3': (1, 1, 1), 'bf16x6': (2, 2, 2), 'mixed': (2, 1, 1)}[mode]       # forward, dgrad, wgrad
+    arith = {'fp32': (0, 0, 0), 'bf16x3': (1, 1, 1), 'bf16x6': (2, 2, 2), 'mixed': (2, 1, 1), 'f16x3': (3, 3, 3)}[mode]       # forward, dgrad, wgrad
     tot = {'forward': [0.0, 0.0], 'dgrad': [0.0, 0.0], 'wgrad_per_layer': [0.0, 0.0], 'wgrad': [0.0, 0.0]}
-    layers, keep = {}, []
+    layers, keep, keep_probs = {}, [], []
     dev = torch.device('cuda', torch.cuda.current_device())
     for name, C, h, w, K, R, pad, dil in shapes:
         x = torch.randn((B, C, h, w), device=dev).contiguous(memory_format=torch.channels_last)
@@ -170,19 +172,31 @@ def decoder_stack_roofline(torch, HF, B, H, W, reps=10):
         wsd = HF._ws(HF.cquery('dsrl_conv2d_dgrad_workspace_bytes', *shp), x)
         wsw = HF._ws(HF.cquery('dsrl_conv2d_wgrad_workspace_bytes', *shp), x)
         gf = 2.0 * HF.conv2d_inbounds_macs(*shp) / 1e9
-        t_f = _time_ms(lambda: _lib.call('dsrl_conv2d_fwd', x.data_ptr(), C, wt.data_ptr(), None, y.data_ptr(), K, *shp, wsf.data_ptr(), wsf.numel(), st), reps, torch)
-        t_d = _time_ms(lambda: _lib.call('dsrl_conv2d_dgrad', dy.data_ptr(), Kp, wt.data_ptr(), None, dx.data_ptr(), C, *shp, wsd.data_ptr(), wsd.numel(), st), reps, torch)
-        t_w = _time_ms(lambda: _lib.call('dsrl_conv2d_wgrad', x.data_ptr(), C, dy.data_ptr(), Kp, dw.data_ptr(), *shp, wsw.data_ptr(), wsw.numel(), st), reps, torch)
+        # operand magnitudes of the f16x3 arithmetic: in the step they are left by the producers of x / dy and by the per-step filter pass,
+        # so they are measured once here, outside the brackets (the other arithmetics ignore them)
+        xa = dya = wa = None
+        if mode == 'f16x3':
+            wslot = HF.amax_slot(dev)
+            HF.call('dsrl_amax', wt.data_ptr(), C * R * R, K, C * R * R, wslot.data_ptr(), st)
+            keep.append(wslot)
+            xa, dya, wa = HF.amax_for(x, x, C).data_ptr(), HF.amax_for(dy, dy, Kp).data_ptr(), wslot.data_ptr()
+        t_f = _time_ms(lambda: _lib.call('dsrl_conv2d_fwd_amax', x.data_ptr(), C, xa, wt.data_ptr(), wa, None, y.data_ptr(), K, *shp, wsf.data_ptr(), wsf.numel(), None, 0, st), reps, torch)
+        t_d = _time_ms(lambda: _lib.call('dsrl_conv2d_dgrad_amax', dy.data_ptr(), Kp, dya, wt.data_ptr(), None, wa, dx.data_ptr(), C, *shp, wsd.data_ptr(), wsd.numel(),
+                                         None, 0, None, 0, None, None, 0, None, 0, 0, st), reps, torch)
+        t_w = _time_ms(lambda: _lib.call('dsrl_conv2d_wgrad_amax', x.data_ptr(), C, xa, dy.data_ptr(), Kp, dya, dw.data_ptr(), *shp, wsw.data_ptr(), wsw.numel(), st), reps, torch)
         layers[name] = {'gflop': round(gf, 2), 'forward_tflops': round(gf / t_f, 1), 'dgrad_tflops': round(gf / t_d, 1), 'wgrad_per_layer_tflops': round(gf / t_w, 1)}
         for k, t in (('forward', t_f), ('dgrad', t_d), ('wgrad_per_layer', t_w)):
             tot[k][0] += gf; tot[k][1] += t
-        keep.append((x, dy, dw, Kp, shp))
+        keep_probs.append((x, dy, dw, Kp, shp))
     # the production path launches the weight gradients of a backward pass as grouped grids (dsrl_conv2d_wgrad_group_*): the whole stack at once
     if mode != 'fp32':
+        f16 = mode == 'f16x3'       # operand magnitudes: left by the producers in the step, measured once here
+        amax = [(HF.amax_for(x, x, shp[3]), HF.amax_for(dy, dy, Kp)) if f16 else (None, None) for x, dy, dw, Kp, shp in keep_probs]
+
         def grouped():
             q = HF.WgradQueue()
-            for x, dy, dw, Kp, shp in keep:
-                q.add(x, shp[3], dy, Kp, dw, shp)
+            for (x, dy, dw, Kp, shp), (xa, dya) in zip(keep_probs, amax):
+                q.add(x, shp[3], dy, Kp, dw, shp, None, xa, dya)
             q.flush()
         tot['wgrad'] = [tot['wgrad_per_layer'][0], _time_ms(grouped, reps, torch)]
     else:
@@ -350,7 +364,7 @@ def main():
     if not args.no_prof:
         gb = args.batch * world
         by_arith = {default_mode: round(gb * args.steps / elapsed, 1)}
-        for mode in ('bf16x6', 'mixed', 'fp32'):
+        for mode in ('f16x3', 'bf16x6', 'mixed', 'fp32'):
             if mode == default_mode or (mode == 'fp32' and world > 1):        # exact-product fp32 MFMA: single-GPU figure only
                 continue
             HF.set_conv_precision(mode)
@@ -360,7 +374,7 @@ def main():
 
     def read_prof(nsteps, stride=1):
         fams = []
-        for fam in range(9):                 # family = 3 * arithmetic + pass (include/dsrl_hip.h)
+        for fam in range(12):                # family = 3 * arithmetic + pass (include/dsrl_hip.h)
             n = ctypes.c_int64(0); ms = ctypes.c_double(0); fl = ctypes.c_double(0)
             _lib.check(lib.dsrl_prof_read(fam, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), 'dsrl_prof_read')
             by = ctypes.c_double(0)

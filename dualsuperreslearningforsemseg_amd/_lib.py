@@ -66,13 +66,13 @@ PROTOTYPES = {
     'dsrl_bn_workspace_bytes': (sz, [i64, i32]),
     'dsrl_bn_stats': (i32, [fp, i32, i64, i32, f32, f32, fp, fp, fp, fp, fp, sz, stream_t]),
     'dsrl_bn_invstd_from_var': (i32, [fp, i32, f32, fp, stream_t]),
-    'dsrl_bn_apply': (i32, [fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, stream_t]),
+    'dsrl_bn_apply': (i32, [fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, fp, stream_t]),
     'dsrl_bn_fused_max_blocks': (i32, [i32]),
     'dsrl_bn_fused_barrier_timeouts': (i32, [C.POINTER(i64)]),
-    'dsrl_bn_train_fwd_from_stats': (i32, [fp, i32, fp, i32, i64, i32, f32, f32, fp, fp, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, fp, i32, stream_t]),
-    'dsrl_bn_train_fwd': (i32, [fp, i32, fp, i32, i64, i32, f32, f32, fp, fp, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, fp, sz, stream_t]),
-    'dsrl_bn_bwd': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, f32, i32, fp, sz, stream_t]),
-    'dsrl_bn_bwd_from_stats': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, i32, fp, i32, stream_t]),
+    'dsrl_bn_train_fwd_from_stats': (i32, [fp, i32, fp, i32, i64, i32, f32, f32, fp, fp, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, fp, i32, fp, stream_t]),
+    'dsrl_bn_train_fwd': (i32, [fp, i32, fp, i32, i64, i32, f32, f32, fp, fp, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, fp, sz, fp, stream_t]),
+    'dsrl_bn_bwd': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, f32, i32, fp, sz, fp, stream_t]),
+    'dsrl_bn_bwd_from_stats': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, i32, fp, i32, fp, stream_t]),
     'dsrl_dropout_fwd': (i32, [fp, i32, fp, i32, i64, i32, f32, u64, u32, stream_t]),
     'dsrl_dropout_bwd': (i32, [fp, i32, fp, i32, i64, i32, f32, u64, u32, stream_t]),
     'dsrl_bilinear_ac_fwd': (i32, [fp, i32, fp, i32, i32, i32, i32, i32, i32, i32, stream_t]),

@@ -7,7 +7,7 @@ What differs by design:
   * the reference's 8 blocking device->host reads and 3 host-side NaN scans per iteration (train_or_resume.py:406-451) are
     folded into ONE readback of [CE, MSE, FA, Total, nan_flag] per iteration with the same abort-on-NaN behaviour;
   * apex is not used. `mixed_precision` (apex opt levels 'O0'..'O3' in the reference, train_or_resume.py:68-72, 441-444) selects the
-    arithmetic of the MFMA conv kernels instead: 'O0' = fp32-equivalent bf16x6, 'O1' = bf16x6 forward / bf16x3 gradients, 'O2'/'O3' =
+    arithmetic of the MFMA conv kernels instead: 'O0' = fp32-equivalent f16x3 (the default), 'O1' = bf16x6 forward / bf16x3 gradients, 'O2'/'O3' =
     bf16x3 everywhere (BASELINE config 5's reduced-precision MFMA path).  Storage and accumulation stay fp32 in every mode, so there
     is no loss scaling (nothing can underflow that fp32 training would keep) and `amp_state_dict` is None;
   * the input pipeline (torchvision Cityscapes + PIL transforms) is out of scope: `dataset` may carry a 'loader_factory'

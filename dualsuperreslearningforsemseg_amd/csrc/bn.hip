@@ -114,20 +114,25 @@ __global__ void invstd_from_var_kernel(const float* __restrict__ var, int C, flo
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long P, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const float* __restrict__ res, int ldr, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream) {
+                                                        const float* __restrict__ res, int ldr, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream,
+                                                        unsigned* __restrict__ y_amax) {
     const unsigned long long seed = seed_arg.dev ? *seed_arg.dev : seed_arg.value;     // device-resident key: replayable from a graph
     const ChanMap m = chan_map(C, blockIdx.y);
-    if (m.c < 0) return;
-    const float sc = gamma[m.c] * invstd[m.c];
-    const float sh = beta[m.c] - mean[m.c] * sc;
-    const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    for (long long p = (long long)blockIdx.x * m.G + m.slot; p < P; p += (long long)gridDim.x * m.G) {
-        float v = fmaf(x[p * ldx + m.c], sc, sh);
-        if (res) v += res[p * ldr + m.c];
-        if (relu) v = fmaxf(v, 0.f);
-        if (drop_p > 0.f) v = (philox_uniform((unsigned long long)p * C + m.c, seed, rng_stream) >= drop_p) ? v * keep_scale : 0.f;
-        y[p * ldy + m.c] = v;
+    unsigned am = 0u;
+    if (m.c >= 0) {
+        const float sc = gamma[m.c] * invstd[m.c];
+        const float sh = beta[m.c] - mean[m.c] * sc;
+        const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+        for (long long p = (long long)blockIdx.x * m.G + m.slot; p < P; p += (long long)gridDim.x * m.G) {
+            float v = fmaf(x[p * ldx + m.c], sc, sh);
+            if (res) v += res[p * ldr + m.c];
+            if (relu) v = fmaxf(v, 0.f);
+            if (drop_p > 0.f) v = (philox_uniform((unsigned long long)p * C + m.c, seed, rng_stream) >= drop_p) ? v * keep_scale : 0.f;
+            y[p * ldy + m.c] = v;
+            am = max(am, abs_bits(v));
+        }
     }
+    amax_publish(am, y_amax);
 }
 
 // ---------------------------------------------------------------------------------------------- backward
@@ -197,20 +202,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                             const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
                                                             float* __restrict__ dres, int lddr, long long P, int C,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                            const float* __restrict__ sums, int relu, float drop_p, int training) {
+                                                            const float* __restrict__ sums, int relu, float drop_p, int training,
+                                                            unsigned* __restrict__ dx_amax) {
     const ChanMap m = chan_map(C, blockIdx.y);
-    if (m.c < 0) return;
-    const float mu = mean[m.c], is = invstd[m.c], gi = gamma[m.c] * is;
-    const float inv_n = 1.f / (float)P;
-    const float mb = training ? sums[m.c] * inv_n : 0.f, mg = training ? sums[C + m.c] * inv_n : 0.f;
-    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    const bool need_y = relu || drop_p > 0.f;
-    for (long long p = (long long)blockIdx.x * m.G + m.slot; p < P; p += (long long)gridDim.x * m.G) {
-        const float g = masked_grad(dy[p * lddy + m.c], need_y ? y[p * ldy + m.c] : 1.f, relu, drop_p, ks);
-        const float xh = (x[p * ldx + m.c] - mu) * is;
-        dx[p * lddx + m.c] = gi * (g - mb - xh * mg);
-        if (dres) dres[p * lddr + m.c] = g;
+    unsigned am = 0u;
+    if (m.c >= 0) {
+        const float mu = mean[m.c], is = invstd[m.c], gi = gamma[m.c] * is;
+        const float inv_n = 1.f / (float)P;
+        const float mb = training ? sums[m.c] * inv_n : 0.f, mg = training ? sums[C + m.c] * inv_n : 0.f;
+        const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+        const bool need_y = relu || drop_p > 0.f;
+        for (long long p = (long long)blockIdx.x * m.G + m.slot; p < P; p += (long long)gridDim.x * m.G) {
+            const float g = masked_grad(dy[p * lddy + m.c], need_y ? y[p * ldy + m.c] : 1.f, relu, drop_p, ks);
+            const float xh = (x[p * ldx + m.c] - mu) * is;
+            const float d = gi * (g - mb - xh * mg);
+            dx[p * lddx + m.c] = d;
+            am = max(am, abs_bits(d));
+            if (dres) dres[p * lddr + m.c] = g;
+        }
     }
+    amax_publish(am, dx_amax);
 }
 
 // ---------------------------------------------------------------------------------------------- column sums
@@ -331,16 +342,19 @@ __global__ __launch_bounds__(256) void bn_partial4_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long P, int C,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const float* __restrict__ res, int ldr, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream) {
+                                                         const float* __restrict__ res, int ldr, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream,
+                                                         unsigned* __restrict__ y_amax) {
     const unsigned long long seed = seed_arg.dev ? *seed_arg.dev : seed_arg.value;     // device-resident key: replayable from a graph
     const ChanMap4 m = chan_map4(C, blockIdx.y);
-    if (m.q < 0) return;
-    float sc[4], sh[4];
+    unsigned am = 0u;
+    float sc[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m.q >= 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int c = 4 * m.q + j; sc[j] = gamma[c] * invstd[c]; sh[j] = beta[c] - mean[c] * sc[j]; }
+        for (int j = 0; j < 4; ++j) { const int c = 4 * m.q + j; sc[j] = gamma[c] * invstd[c]; sh[j] = beta[c] - mean[c] * sc[j]; }
+    }
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
 #pragma unroll 2
-    for (long long p = (long long)blockIdx.x * m.G + m.slot; p < P; p += (long long)gridDim.x * m.G) {
+    for (long long p = m.q >= 0 ? (long long)blockIdx.x * m.G + m.slot : P; p < P; p += (long long)gridDim.x * m.G) {
         const float4 xv = LD4(x, p, ldx, m.q);
         float v[4] = {fmaf(xv.x, sc[0], sh[0]), fmaf(xv.y, sc[1], sh[1]), fmaf(xv.z, sc[2], sh[2]), fmaf(xv.w, sc[3], sh[3])};
         if (res) { const float4 r = LD4(res, p, ldr, m.q); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
@@ -356,7 +370,9 @@ __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict_
             for (int j = 0; j < 4; ++j) v[j] = ((float)(r[j] >> 8) * 5.9604644775390625e-08f >= drop_p) ? v[j] * ks : 0.f;
         }
         ST4(y, p, ldy, m.q) = make_float4(v[0], v[1], v[2], v[3]);
+        am = abs_bits4(am, v[0], v[1], v[2], v[3]);
     }
+    amax_publish(am, y_amax);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
@@ -404,30 +420,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
                                                              const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
                                                              float* __restrict__ dres, int lddr, long long P, int C,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                             const float* __restrict__ sums, int relu, float drop_p, int training) {
+                                                             const float* __restrict__ sums, int relu, float drop_p, int training,
+                                                             unsigned* __restrict__ dx_amax) {
     const ChanMap4 m = chan_map4(C, blockIdx.y);
-    if (m.q < 0) return;
-    float mu[4], is[4], gi[4], mb[4], mg[4];
+    unsigned am = 0u;
+    float mu[4] = {}, is[4] = {}, gi[4] = {}, mb[4] = {}, mg[4] = {};
     const float inv_n = 1.f / (float)P;
+    if (m.q >= 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = 4 * m.q + j;
-        mu[j] = mean[c]; is[j] = invstd[c]; gi[j] = gamma[c] * is[j];
-        mb[j] = training ? sums[c] * inv_n : 0.f; mg[j] = training ? sums[C + c] * inv_n : 0.f;
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * m.q + j;
+            mu[j] = mean[c]; is[j] = invstd[c]; gi[j] = gamma[c] * is[j];
+            mb[j] = training ? sums[c] * inv_n : 0.f; mg[j] = training ? sums[C + c] * inv_n : 0.f;
+        }
     }
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     const bool need_y = relu || drop_p > 0.f;
 #pragma unroll 2
-    for (long long p = (long long)blockIdx.x * m.G + m.slot; p < P; p += (long long)gridDim.x * m.G) {
+    for (long long p = m.q >= 0 ? (long long)blockIdx.x * m.G + m.slot : P; p < P; p += (long long)gridDim.x * m.G) {
         const float4 dv = LD4(dy, p, lddy, m.q), xv = LD4(x, p, ldx, m.q);
         float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
         if (need_y) yv = LD4(y, p, ldy, m.q);
         const float g0 = masked_grad(dv.x, yv.x, relu, drop_p, ks), g1 = masked_grad(dv.y, yv.y, relu, drop_p, ks);
         const float g2 = masked_grad(dv.z, yv.z, relu, drop_p, ks), g3 = masked_grad(dv.w, yv.w, relu, drop_p, ks);
-        ST4(dx, p, lddx, m.q) = make_float4(gi[0] * (g0 - mb[0] - (xv.x - mu[0]) * is[0] * mg[0]), gi[1] * (g1 - mb[1] - (xv.y - mu[1]) * is[1] * mg[1]),
-                                            gi[2] * (g2 - mb[2] - (xv.z - mu[2]) * is[2] * mg[2]), gi[3] * (g3 - mb[3] - (xv.w - mu[3]) * is[3] * mg[3]));
+        const float4 d = make_float4(gi[0] * (g0 - mb[0] - (xv.x - mu[0]) * is[0] * mg[0]), gi[1] * (g1 - mb[1] - (xv.y - mu[1]) * is[1] * mg[1]),
+                                     gi[2] * (g2 - mb[2] - (xv.z - mu[2]) * is[2] * mg[2]), gi[3] * (g3 - mb[3] - (xv.w - mu[3]) * is[3] * mg[3]));
+        ST4(dx, p, lddx, m.q) = d;
+        am = abs_bits4(am, d.x, d.y, d.z, d.w);
         if (dres) ST4(dres, p, lddr, m.q) = make_float4(g0, g1, g2, g3);
     }
+    amax_publish(am, dx_amax);
 }
 
 
@@ -503,7 +525,7 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_fwd_kernel(const float
                                                             float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ rm, float* __restrict__ rv,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ res, int ldr, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream,
-                                                            float* part) {
+                                                            float* part, unsigned* __restrict__ y_amax) {
     const unsigned long long seed = seed_arg.dev ? *seed_arg.dev : seed_arg.value;     // device-resident key: replayable from a graph
     __shared__ float shw[kFusedNW][3][4][8];          // per wave: (n, mean, M2) x 4 channels x 8 float4 columns
     __shared__ double shm[kFusedNS][3][32];           // cross-slab merge: 8 slices x 3 sums x 32 channels
@@ -611,6 +633,7 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_fwd_kernel(const float
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int c = 4 * q + j; sc[j] = gamma[c] * fin[1][4 * l8 + j]; sf[j] = beta[c] - fin[0][4 * l8 + j] * sc[j]; }
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    unsigned am = 0u;
 #pragma unroll
     for (int i = 0; i < kFusedMaxPasses; ++i) {
         const int p = row0 + rr + kFusedRL * i;
@@ -629,7 +652,9 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_fwd_kernel(const float
             for (int j = 0; j < 4; ++j) v[j] = ((float)(r[j] >> 8) * 5.9604644775390625e-08f >= drop_p) ? v[j] * ks : 0.f;
         }
         ST4(y, p, ldy, q) = make_float4(v[0], v[1], v[2], v[3]);
+        am = abs_bits4(am, v[0], v[1], v[2], v[3]);
     }
+    amax_publish(am, y_amax);
 }
 
 __global__ __launch_bounds__(kFusedThreads) void bn_fused_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
@@ -637,7 +662,7 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_bwd_kernel(const float
                                                             float* __restrict__ dres, int lddr, int P, int C, int groups, int slabs, int rows_per_slab,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int relu, float drop_p, int training,
-                                                            float* part) {
+                                                            float* part, unsigned* __restrict__ dx_amax) {
     __shared__ float shw[kFusedNW][2][4][8];
     __shared__ double shm[kFusedNS][2][32];
     __shared__ float fin[2][32];               // sum g / n, sum g*xhat / n
@@ -724,13 +749,17 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_bwd_kernel(const float
     float gi[4], mb[4], mg[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { gi[j] = gamma[4 * q + j] * is[j]; mb[j] = fin[0][4 * l8 + j]; mg[j] = fin[1][4 * l8 + j]; }
+    unsigned am = 0u;
 #pragma unroll
     for (int i = 0; i < kFusedMaxPasses; ++i) {
         const int p = row0 + rr + kFusedRL * i;
         if (p >= row1) continue;
-        ST4(dx, p, lddx, q) = make_float4(gi[0] * (g[i].x - mb[0] - xh[i].x * mg[0]), gi[1] * (g[i].y - mb[1] - xh[i].y * mg[1]),
-                                          gi[2] * (g[i].z - mb[2] - xh[i].z * mg[2]), gi[3] * (g[i].w - mb[3] - xh[i].w * mg[3]));
+        const float4 d = make_float4(gi[0] * (g[i].x - mb[0] - xh[i].x * mg[0]), gi[1] * (g[i].y - mb[1] - xh[i].y * mg[1]),
+                                     gi[2] * (g[i].z - mb[2] - xh[i].z * mg[2]), gi[3] * (g[i].w - mb[3] - xh[i].w * mg[3]));
+        ST4(dx, p, lddx, q) = d;
+        am = abs_bits4(am, d.x, d.y, d.z, d.w);
     }
+    amax_publish(am, dx_amax);
 }
 
 
@@ -744,7 +773,7 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(const float* __rest
                                                               float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ rm, float* __restrict__ rv,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ res, int ldr, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream,
-                                                              const float* __restrict__ part, int nparts) {
+                                                              const float* __restrict__ part, int nparts, unsigned* __restrict__ y_amax) {
     const unsigned long long seed = seed_arg.dev ? *seed_arg.dev : seed_arg.value;     // device-resident key: replayable from a graph
     __shared__ double shm[8][3][32];
     __shared__ float fin[2][32];
@@ -797,6 +826,7 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(const float* __rest
     for (int j = 0; j < 4; ++j) { const int c = 4 * q + j; sc[j] = gamma[c] * fin[1][4 * l8 + j]; sf[j] = beta[c] - fin[0][4 * l8 + j] * sc[j]; }
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     const int row0 = slab * rows_per_slab, row1 = min(P, row0 + rows_per_slab);
+    unsigned am = 0u;
 #pragma unroll 4
     for (int p = row0 + rr; p < row1; p += 32) {
         const float4 xv = LD4(x, p, ldx, q);
@@ -814,7 +844,9 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(const float* __rest
             for (int j = 0; j < 4; ++j) v[j] = ((float)(r[j] >> 8) * 5.9604644775390625e-08f >= drop_p) ? v[j] * ks : 0.f;
         }
         ST4(y, p, ldy, q) = make_float4(v[0], v[1], v[2], v[3]);
+        am = abs_bits4(am, v[0], v[1], v[2], v[3]);
     }
+    amax_publish(am, y_amax);
 }
 
 
@@ -826,7 +858,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_apply_kernel(const float* __
                                                                   float* __restrict__ dres, int lddr, int P, int C, int groups, int rows_per_slab,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int relu, int training,
-                                                                  const float* __restrict__ part, int nparts) {
+                                                                  const float* __restrict__ part, int nparts, unsigned* __restrict__ dx_amax) {
     __shared__ double shm[8][2][32];
     __shared__ float fin[2][32];
     const int grp = blockIdx.x % groups, slab = blockIdx.x / groups;
@@ -871,6 +903,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_apply_kernel(const float* __
         mu[j] = mean[c]; is[j] = invstd[c]; gi[j] = gamma[c] * is[j]; mb[j] = fin[0][4 * l8 + j]; mg[j] = fin[1][4 * l8 + j];
     }
     const int row0 = slab * rows_per_slab, row1 = min(P, row0 + rows_per_slab);
+    unsigned am = 0u;
 #pragma unroll 2
     for (int p = row0 + rr; p < row1; p += 32) {
         const float4 dv = LD4(dy, p, lddy, q), xv = LD4(x, p, ldx, q);
@@ -878,10 +911,13 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_apply_kernel(const float* __
         if (relu) yv = LD4(y, p, ldy, q);
         const float g0 = masked_grad(dv.x, yv.x, relu, 0.f, 1.f), g1 = masked_grad(dv.y, yv.y, relu, 0.f, 1.f);
         const float g2 = masked_grad(dv.z, yv.z, relu, 0.f, 1.f), g3 = masked_grad(dv.w, yv.w, relu, 0.f, 1.f);
-        ST4(dx, p, lddx, q) = make_float4(gi[0] * (g0 - mb[0] - (xv.x - mu[0]) * is[0] * mg[0]), gi[1] * (g1 - mb[1] - (xv.y - mu[1]) * is[1] * mg[1]),
-                                          gi[2] * (g2 - mb[2] - (xv.z - mu[2]) * is[2] * mg[2]), gi[3] * (g3 - mb[3] - (xv.w - mu[3]) * is[3] * mg[3]));
+        const float4 d = make_float4(gi[0] * (g0 - mb[0] - (xv.x - mu[0]) * is[0] * mg[0]), gi[1] * (g1 - mb[1] - (xv.y - mu[1]) * is[1] * mg[1]),
+                                     gi[2] * (g2 - mb[2] - (xv.z - mu[2]) * is[2] * mg[2]), gi[3] * (g3 - mb[3] - (xv.w - mu[3]) * is[3] * mg[3]));
+        ST4(dx, p, lddx, q) = d;
+        am = abs_bits4(am, d.x, d.y, d.z, d.w);
         if (dres) ST4(dres, p, lddr, q) = make_float4(g0, g1, g2, g3);
     }
+    amax_publish(am, dx_amax);
 }
 
 // ---------------------------------------------------------------------------------------------- dense tensors, C % 4 != 0 ("flat" kernels)
@@ -995,11 +1031,12 @@ __global__ __launch_bounds__(kFlatThreads) void bn_bwd_partial_flat_kernel(const
 __global__ __launch_bounds__(kFlatThreads) void bn_apply_flat_kernel(const float* __restrict__ x, float* __restrict__ y, long long total4, int C, int T,
                                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                    const float* __restrict__ res, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream) {
+                                                                    const float* __restrict__ res, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream,
+                                                                    unsigned* __restrict__ y_amax) {
     const unsigned long long seed = seed_arg.dev ? *seed_arg.dev : seed_arg.value;
     const int t = threadIdx.x;
-    if (t >= T) return;
-    const long long f0 = (long long)blockIdx.x * T + t, stride = (long long)gridDim.x * T;      // 4 * stride % C == 0: the channels of a thread never change
+    unsigned am = 0u;
+    const long long f0 = t < T ? (long long)blockIdx.x * T + t : total4, stride = (long long)gridDim.x * T;      // 4 * stride % C == 0: the channels of a thread never change
     float sc[4], sf[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int c = (int)((4 * f0 + k) % C); sc[k] = gamma[c] * invstd[c]; sf[k] = beta[c] - mean[c] * sc[k]; }
@@ -1021,7 +1058,9 @@ __global__ __launch_bounds__(kFlatThreads) void bn_apply_flat_kernel(const float
             for (int k = 0; k < 4; ++k) v[k] = (philox_uniform((unsigned long long)(4 * f + k), seed, rng_stream) >= drop_p) ? v[k] * ks : 0.f;
         }
         y4[f] = make_float4(v[0], v[1], v[2], v[3]);
+        am = abs_bits4(am, v[0], v[1], v[2], v[3]);
     }
+    amax_publish(am, y_amax);
 }
 // column sums of a [P][C] tensor with C % 4 == 0: one float4 per thread and row (colsum_partial_kernel reads one float per lane)
 __global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __restrict__ x, int ld, long long P, int C, long long rows_per_block,
@@ -1161,20 +1200,20 @@ extern "C" int dsrl_bn_invstd_from_var(const float* running_var, int C, float ep
 
 extern "C" int dsrl_bn_apply(const float* x, int ldx, float* y, int ldy, int64_t P, int C, const float* mean, const float* invstd,
                              const float* gamma, const float* beta, const float* residual, int ldr, int relu, float drop_p,
-                             uint64_t seed, uint32_t rng_stream, dsrl_stream_t stream) {
+                             uint64_t seed, uint32_t rng_stream, uint32_t* y_amax, dsrl_stream_t stream) {
     DSRL_REQUIRE(x && y && mean && invstd && gamma && beta && P > 0 && C > 0 && ldx >= C && ldy >= C, DSRL_E_BADARG, "bn_apply: bad arguments");
     DSRL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, DSRL_E_BADARG, "bn_apply: dropout p=%f outside [0,1)", drop_p);
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
     if (vec4_ok(C, {ldx, ldy, residual ? ldr : 0}, {x, y, residual}))
         hipLaunchKernelGGL(bn_apply4_kernel, apply_grid4(P, C), dim3(256), 0, st, x, ldx, y, ldy, (long long)P, C, mean, invstd, gamma, beta, residual, ldr,
-                           relu, drop_p, seed_arg(seed), (unsigned)rng_stream);
+                           relu, drop_p, seed_arg(seed), (unsigned)rng_stream, y_amax);
     else if (const int T = flat_stride(C, P, {ldx, ldy, residual ? ldr : C}, {x, y, residual}))
         hipLaunchKernelGGL(bn_apply_flat_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, ceil_div(P * C / 4, (int64_t)T * 2)))), dim3(kFlatThreads), 0, st,
-                           x, y, (long long)(P * C / 4), C, T, mean, invstd, gamma, beta, residual, relu, drop_p, seed_arg(seed), (unsigned)rng_stream);
+                           x, y, (long long)(P * C / 4), C, T, mean, invstd, gamma, beta, residual, relu, drop_p, seed_arg(seed), (unsigned)rng_stream, y_amax);
     else
         hipLaunchKernelGGL(bn_apply_kernel, apply_grid(P, C), dim3(256), 0, st, x, ldx, y, ldy, (long long)P, C, mean, invstd, gamma, beta, residual, ldr,
-                           relu, drop_p, seed_arg(seed), (unsigned)rng_stream);
+                           relu, drop_p, seed_arg(seed), (unsigned)rng_stream, y_amax);
     return launch_status("bn_apply_kernel");
 }
 
@@ -1202,7 +1241,7 @@ extern "C" int dsrl_bn_fused_barrier_timeouts(int64_t* count) {
 
 extern "C" int dsrl_bn_train_fwd(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,
                                  float* running_mean, float* running_var, const float* gamma, const float* beta, const float* residual, int ldr,
-                                 int relu, float drop_p, uint64_t seed, uint32_t rng_stream, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+                                 int relu, float drop_p, uint64_t seed, uint32_t rng_stream, void* ws, size_t ws_bytes, uint32_t* y_amax, dsrl_stream_t stream) {
     DSRL_REQUIRE(x && y && mean && invstd && gamma && beta && ws && P > 0 && C > 0 && ldx >= C && ldy >= C, DSRL_E_BADARG, "bn_train_fwd: bad arguments");
     DSRL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, DSRL_E_BADARG, "bn_train_fwd: dropout p=%f outside [0,1)", drop_p);
     DSRL_REQUIRE(ws_bytes >= dsrl_bn_workspace_bytes(P, C), DSRL_E_WORKSPACE, "bn_train_fwd: workspace too small");
@@ -1212,16 +1251,17 @@ extern "C" int dsrl_bn_train_fwd(const float* x, int ldx, float* y, int ldy, int
         hipStream_t st = (hipStream_t)stream;
         hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3(f.blocks), dim3(kFusedThreads), 0, st, x, ldx, y, ldy, (int)P, C, f.groups, f.slabs, f.rows_per_slab, eps, momentum,
                            mean, invstd, running_mean, running_var, gamma, beta, residual, ldr, relu, drop_p, seed_arg(seed), (unsigned)rng_stream,
-                           (float*)ws);
+                           (float*)ws, y_amax);
         return launch_status("bn_fused_fwd_kernel");
     }
     if (int e = dsrl_bn_stats(x, ldx, P, C, eps, momentum, mean, invstd, running_mean, running_var, ws, ws_bytes, stream)) return e;
-    return dsrl_bn_apply(x, ldx, y, ldy, P, C, mean, invstd, gamma, beta, residual, ldr, relu, drop_p, seed, rng_stream, stream);
+    return dsrl_bn_apply(x, ldx, y, ldy, P, C, mean, invstd, gamma, beta, residual, ldr, relu, drop_p, seed, rng_stream, y_amax, stream);
 }
 
 extern "C" int dsrl_bn_train_fwd_from_stats(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,
                                             float* running_mean, float* running_var, const float* gamma, const float* beta, const float* residual, int ldr,
-                                            int relu, float drop_p, uint64_t seed, uint32_t rng_stream, const float* stats, int stats_parts, dsrl_stream_t stream) {
+                                            int relu, float drop_p, uint64_t seed, uint32_t rng_stream, const float* stats, int stats_parts, uint32_t* y_amax,
+                                            dsrl_stream_t stream) {
     DSRL_REQUIRE(x && y && mean && invstd && gamma && beta && stats && P > 0 && P < (1ll << 31) && C > 0 && ldx >= C && ldy >= C, DSRL_E_BADARG, "bn_train_fwd_from_stats: bad arguments");
     DSRL_REQUIRE(stats_parts > 0 && stats_parts <= 256, DSRL_E_BADARG, "bn_train_fwd_from_stats: %d row blocks of partials (1..256)", stats_parts);
     DSRL_REQUIRE(C % 32 == 0 && vec4_ok(C, {ldx, ldy, residual ? ldr : 0}, {x, y, residual}), DSRL_E_UNSUPPORTED,
@@ -1234,13 +1274,13 @@ extern "C" int dsrl_bn_train_fwd_from_stats(const float* x, int ldx, float* y, i
     const int rows_per_slab = (int)ceil_div(P, (int64_t)slabs);
     slabs = (int)ceil_div(P, (int64_t)rows_per_slab);
     hipLaunchKernelGGL(bn_stats_apply_kernel, dim3((unsigned)(groups * slabs)), dim3(256), 0, st, x, ldx, y, ldy, (int)P, C, groups, rows_per_slab, eps, momentum,
-                       mean, invstd, running_mean, running_var, gamma, beta, residual, ldr, relu, drop_p, seed_arg(seed), (unsigned)rng_stream, stats, stats_parts);
+                       mean, invstd, running_mean, running_var, gamma, beta, residual, ldr, relu, drop_p, seed_arg(seed), (unsigned)rng_stream, stats, stats_parts, y_amax);
     return launch_status("bn_stats_apply_kernel");
 }
 
 extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
                            float* dresidual, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
-                           float* dgamma, float* dbeta, int relu, float drop_p, int training, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+                           float* dgamma, float* dbeta, int relu, float drop_p, int training, void* ws, size_t ws_bytes, uint32_t* dx_amax, dsrl_stream_t stream) {
     DSRL_REQUIRE(x && dy && dx && mean && invstd && gamma && ws && P > 0 && C > 0, DSRL_E_BADARG, "bn_bwd: bad arguments");
     DSRL_REQUIRE(y || !(relu || drop_p > 0.f), DSRL_E_BADARG, "bn_bwd: forward output needed for the relu/dropout mask");
     DSRL_REQUIRE(ws_bytes >= dsrl_bn_workspace_bytes(P, C), DSRL_E_WORKSPACE, "bn_bwd: workspace too small");
@@ -1250,7 +1290,7 @@ extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, con
     const FusedPlan f = fused_plan(P, C);
     if (f.ok && v4 && fused_stream_ok(st)) {
         hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3(f.blocks), dim3(kFusedThreads), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (int)P, C,
-                           f.groups, f.slabs, f.rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, drop_p, training, (float*)ws);
+                           f.groups, f.slabs, f.rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, drop_p, training, (float*)ws, dx_amax);
         return launch_status("bn_fused_bwd_kernel");
     }
     const int nbx = row_blocks(P);
@@ -1271,16 +1311,17 @@ extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, con
     if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
     if (v4)
         hipLaunchKernelGGL(bn_bwd_apply4_kernel, apply_grid4(P, C), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (long long)P, C,
-                           mean, invstd, gamma, (const float*)sums, relu, drop_p, training);
+                           mean, invstd, gamma, (const float*)sums, relu, drop_p, training, dx_amax);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel, apply_grid(P, C), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (long long)P, C,
-                           mean, invstd, gamma, (const float*)sums, relu, drop_p, training);
+                           mean, invstd, gamma, (const float*)sums, relu, drop_p, training, dx_amax);
     return launch_status("bn_bwd_apply_kernel");
 }
 
 extern "C" int dsrl_bn_bwd_from_stats(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
                                       float* dresidual, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
-                                      float* dgamma, float* dbeta, int relu, int training, const float* stats, int stats_parts, dsrl_stream_t stream) {
+                                      float* dgamma, float* dbeta, int relu, int training, const float* stats, int stats_parts, uint32_t* dx_amax,
+                                      dsrl_stream_t stream) {
     DSRL_REQUIRE(x && dy && dx && mean && invstd && gamma && stats && P > 0 && P < (1ll << 31) && C > 0, DSRL_E_BADARG, "bn_bwd_from_stats: bad arguments");
     DSRL_REQUIRE(y || !relu, DSRL_E_BADARG, "bn_bwd_from_stats: forward output needed for the relu mask");
     DSRL_REQUIRE(stats_parts > 0 && stats_parts <= 256, DSRL_E_BADARG, "bn_bwd_from_stats: %d row blocks of partials (1..256)", stats_parts);
@@ -1293,7 +1334,7 @@ extern "C" int dsrl_bn_bwd_from_stats(const float* x, int ldx, const float* y, i
     const int rows_per_slab = (int)ceil_div(P, (int64_t)slabs);
     slabs = (int)ceil_div(P, (int64_t)rows_per_slab);
     hipLaunchKernelGGL(bn_bwd_stats_apply_kernel, dim3((unsigned)(groups * slabs)), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (int)P, C,
-                       groups, rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, training, stats, stats_parts);
+                       groups, rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, training, stats, stats_parts, dx_amax);
     return launch_status("bn_bwd_stats_apply_kernel");
 }
 

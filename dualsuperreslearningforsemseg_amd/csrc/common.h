@@ -66,6 +66,41 @@ __device__ inline double wave_sum_d(double v) {
     return v;
 }
 
+// ---------------------------------------------------------------- operand magnitudes (f16x3 conv arithmetic, dsrl_amax)
+// A kernel that writes a tensor a conv will read can leave max |x| of what it wrote (as a bit pattern; NaN patterns sort above every number)
+// in a device record: per thread a running maximum over its stores, then amax_publish - one fire-and-forget atomic per block.
+// A record ("amax record", kAmaxWords uint32) holds kAmaxShards partial maxima, one per 64-byte line: the ~1000 blocks of a streaming
+// kernel finish together, and their atomics on ONE word would be served one after the other (~12 ns each: measured +9 us on a 7 us
+// BatchNorm launch); spread over 16 lines they cost nothing visible.  The reader takes the maximum of the shards (amax_read).
+// Every thread of the block must reach amax_publish (it synchronises); `out` may be null.
+constexpr int kAmaxShards = 16, kAmaxShardStride = 16, kAmaxWords = kAmaxShards * kAmaxShardStride;     // 1 KiB per record
+__device__ inline unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ inline unsigned* amax_shard(unsigned* rec) { return rec + (((blockIdx.x + 5u * blockIdx.y) & (kAmaxShards - 1)) * kAmaxShardStride); }
+// maximum over the shards of a record, wave-uniform (every lane of the wave must be active)
+__device__ inline unsigned amax_read(const unsigned* rec) {
+    const int lane = threadIdx.x & 63;
+    unsigned m = lane < kAmaxShards ? rec[lane * kAmaxShardStride] : 0u;
+#pragma unroll
+    for (int o = kAmaxShards / 2; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    return __builtin_amdgcn_readfirstlane(m);
+}
+__device__ inline unsigned abs_bits4(unsigned m, float a, float b, float c, float d) {
+    return max(max(m, abs_bits(a)), max(max(abs_bits(b), abs_bits(c)), abs_bits(d)));
+}
+__device__ inline void amax_publish(unsigned m, unsigned* out) {
+    if (out == nullptr) return;
+    __shared__ unsigned sm_amax;
+    if (threadIdx.x == 0) sm_amax = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&sm_amax, m);
+    __syncthreads();
+    if (threadIdx.x == 0 && sm_amax) __hip_atomic_fetch_max(amax_shard(out), sm_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the same measurement as a launch of its own (conv_igemm.hip)
+int launch_amax(const float* x, int ld, long long P, int C, unsigned* out, hipStream_t st);
+
 // Per-channel thread mapping for pixel-major [P][ld] tensors with C channels (channel group of <= 256):
 // G = 256 / cg pixels are processed side by side, thread t < G*cg owns channel (t % cg) of pixel slot (t / cg).
 struct ChanMap {

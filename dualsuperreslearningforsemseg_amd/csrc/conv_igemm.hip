@@ -42,17 +42,32 @@ template <bool F16> struct Plane;
 template <> struct Plane<false> {
     using v4 = bf16x4; using v8 = bf16x8;
     static __device__ __forceinline__ v4 cvt(const float* r) { return v4{(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]}; }
+    static __device__ __forceinline__ void residual(float* r, v4 t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] -= (float)t[e];
+    }
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
+// fp16 split of one staged float4 in 8 vector instructions behind the scaling: two v_cvt_pk_f16_f32 per term and the residual r - t as ONE
+// v_fma_mix_f32 per element (t * -1.0 + r, t read as the low / high fp16 half of its packed word: exact, like the subtraction it replaces;
+// hipcc unpacks t with four v_cvt_f32_f16 and re-converts r twice when the same is written with casts).
+__device__ __forceinline__ float f16_resid_lo(unsigned t, float r) { float d; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(t), "v"(r)); return d; }
+__device__ __forceinline__ float f16_resid_hi(unsigned t, float r) { float d; asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(t), "v"(r)); return d; }
 template <> struct Plane<true> {
     using v4 = f16x4; using v8 = f16x8;
-    static __device__ __forceinline__ v4 cvt(const float* r) { return v4{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]}; }
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+    static __device__ __forceinline__ v4 cvt(const float* r) { return __builtin_convertvector((f32x4{r[0], r[1], r[2], r[3]}), v4); }
+    static __device__ __forceinline__ void residual(float* r, v4 t) {
+        const u32x2 u = __builtin_bit_cast(u32x2, t);
+        r[0] = f16_resid_lo(u.x, r[0]); r[1] = f16_resid_hi(u.x, r[1]); r[2] = f16_resid_lo(u.y, r[2]); r[3] = f16_resid_hi(u.y, r[3]);
+    }
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 // e with max|x| * 2^e in [2^14, 2^15) from the bit pattern of max|x| (zero / subnormal maxima count as 2^-126; Inf / NaN maxima give a
 // finite e: such tensors turn into NaN in the split by themselves)
 __device__ __forceinline__ int amax_shift(const unsigned* p) {
-    const unsigned u = __builtin_amdgcn_readfirstlane(*p);
+    const unsigned u = amax_read(p);
     int ex = (int)((u >> 23) & 0xffu);
     if (ex == 0) ex = 1;
     return 14 - (ex - 127);
@@ -519,10 +534,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
         } else if (b_rows) {
             *reinterpret_cast<pl4*>(nb + (NPL * BM + pl * BN + r0 + 64 * (v - A_IT)) * ROWB + w_swz) = t;
         }
-        if (pl + 1 < NPL) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) res[e] -= (float)t[e];
-        }
+        if (pl + 1 < NPL) PT::residual(res, t);
     };
     constexpr int NMFMA = MR * NR * (NPL * (NPL + 1) / 2), CSTEPS = NV * NPL;
     constexpr int MPS = NMFMA / CSTEPS > 0 ? NMFMA / CSTEPS : 1;
@@ -860,14 +872,14 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const lon
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {                 // one global atomic per (block, filter)
+    if (threadIdx.x == 0) {                 // one global atomic per (block, filter), into the block's shard of the filter's record
         unsigned* cur = nullptr; unsigned m = 0u;
 #pragma unroll
         for (int u = 0; u < kWtTilesPerBlock; ++u) {
-            if (dam[u] != cur) { if (cur != nullptr && m) atomicMax(cur, m); cur = dam[u]; m = 0u; }
+            if (dam[u] != cur) { if (cur != nullptr && m) atomicMax(amax_shard(cur), m); cur = dam[u]; m = 0u; }
             m = max(m, smax[u]);
         }
-        if (cur != nullptr && m) atomicMax(cur, m);
+        if (cur != nullptr && m) atomicMax(amax_shard(cur), m);
     }
 #pragma unroll
     for (int u = 0; u < kWtTilesPerBlock; ++u) {
@@ -880,8 +892,8 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const lon
     }
 }
 
-// max |x| of a pixel-major [P][ld] tensor with C channels as a bit pattern, atomically maxed into *out (the caller zeroes it): the operand
-// scale of the f16x3 kernels when the tensor's producer did not leave one.  NaN bit patterns compare above every number.
+// max |x| of a pixel-major [P][ld] tensor with C channels as a bit pattern, atomically maxed into the amax record `out` (the caller zeroes
+// it; common.h): the operand scale of the f16x3 kernels when the tensor's producer did not leave one.  NaN bit patterns compare above every number.
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int ld, long long P, int C, int vec, unsigned* __restrict__ out) {
     __shared__ unsigned sm[4];
     unsigned m = 0u;
@@ -907,7 +919,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     __syncthreads();
     if (threadIdx.x == 0) {
         m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
-        if (m) atomicMax(out, m);
+        if (m) atomicMax(amax_shard(out), m);
     }
 }
 
@@ -1204,10 +1216,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
         } else if (B_IT >= 2 || b_half == hf) {
             *reinterpret_cast<pl4*>(nb_ + pl * PLB + wb_off + (v - A_H) * (B_RP * SB)) = t;
         }
-        if (pl + 1 < NPL) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) res[e] -= (float)t[e];
-        }
+        if (pl + 1 < NPL) PT::residual(res, t);
     };
     constexpr int NMFMA = MR * NR * (NPL * (NPL + 1) / 2), CSTEPS = (A_H + B_H) * NPL;
     constexpr int MPS = NMFMA / CSTEPS > 0 ? NMFMA / CSTEPS : 1;
@@ -1535,7 +1544,7 @@ static int pick_splits(long long tiles, int nq) {
     return (int)std::max<long long>(1, std::min<long long>(nq / 24, cap));
 }
 
-// Conv arithmetic, per pass.  Mode (dsrl_conv_precision(), else DSRL_CONV_PRECISION, else the default 2 = fp32-equivalent):
+// Conv arithmetic, per pass.  Mode (dsrl_conv_precision(), else DSRL_CONV_PRECISION, else the default 4 = f16x3, fp32-equivalent):
 //   0  fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32, exact products)
 //   1  bf16x3 everywhere   (16 mantissa bits per operand, ~5e-6 relative error per conv)
 //   2  bf16x6 everywhere   (24 mantissa bits per operand: fp32-equivalent, measured error vs fp64 equal to mode 0)
@@ -1545,7 +1554,7 @@ static int pick_splits(long long tiles, int nq) {
 enum ConvPass { PASS_FWD, PASS_DGRAD, PASS_WGRAD };
 static int conv_precision_mode() {
     int prec = g_conv_precision.load();
-    if (prec < 0) prec = env_int("DSRL_CONV_PRECISION", 2);
+    if (prec < 0) prec = env_int("DSRL_CONV_PRECISION", 4);
     return prec < 0 ? 0 : (prec > 4 ? 4 : prec);
 }
 static bool conv_f16() { return conv_precision_mode() == 4; }
@@ -1567,8 +1576,8 @@ static int prof_family(ConvPass pass) {
 
 // f16x3 operand scales the caller did not provide: measured into two zeroed words at `scratch` (kAmaxScratch bytes at the end of the
 // call's workspace) by one amax launch per missing operand.
-constexpr size_t kAmaxScratch = 256;
-static int launch_amax(const float* x, int ld, long long P, int C, unsigned* out, hipStream_t st) {
+constexpr size_t kAmaxScratch = 2 * kAmaxWords * sizeof(unsigned);      // two records
+int launch_amax(const float* x, int ld, long long P, int C, unsigned* out, hipStream_t st) {
     const int vec = (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0) ? 1 : 0;
     const long long n = vec ? P * (C / 4) : P * C;
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(ceil_div(n, 256 * 4), 2048));
@@ -1580,11 +1589,11 @@ struct OperandAmax { const unsigned* a; const unsigned* b; };
 static int resolve_amax(OperandAmax& am, const float* a, int lda, long long Pa, int Ca, const float* b, int ldb, long long Pb, int Cb,
                         void* ws, size_t ws_bytes, size_t ws_used, hipStream_t st, const char* who) {
     if (am.a != nullptr && am.b != nullptr) return DSRL_OK;
-    DSRL_REQUIRE(ws != nullptr && ws_bytes >= align_up(ws_used, 16) + kAmaxScratch, DSRL_E_WORKSPACE, "%s: the f16x3 arithmetic measures operand magnitudes the caller did not pass in %zu bytes behind the first %zu of the workspace (got %zu)", who, kAmaxScratch, ws_used, ws_bytes);
-    unsigned* scratch = (unsigned*)((char*)ws + align_up(ws_used, 16));
-    if (hipMemsetAsync(scratch, 0, 16, st) != hipSuccess) return launch_status("hipMemsetAsync(amax scratch)");
+    DSRL_REQUIRE(ws != nullptr && ws_bytes >= align_up(ws_used, 64) + kAmaxScratch, DSRL_E_WORKSPACE, "%s: the f16x3 arithmetic measures operand magnitudes the caller did not pass in %zu bytes behind the first %zu of the workspace (got %zu)", who, kAmaxScratch, ws_used, ws_bytes);
+    unsigned* scratch = (unsigned*)((char*)ws + align_up(ws_used, 64));
+    if (hipMemsetAsync(scratch, 0, kAmaxScratch, st) != hipSuccess) return launch_status("hipMemsetAsync(amax scratch)");
     if (am.a == nullptr) { if (int e = launch_amax(a, lda, Pa, Ca, scratch, st)) return e; am.a = scratch; }
-    if (am.b == nullptr) { if (int e = launch_amax(b, ldb, Pb, Cb, scratch + 1, st)) return e; am.b = scratch + 1; }
+    if (am.b == nullptr) { if (int e = launch_amax(b, ldb, Pb, Cb, scratch + kAmaxWords, st)) return e; am.b = scratch + kAmaxWords; }
     return DSRL_OK;
 }
 
@@ -1722,7 +1731,7 @@ static FwdPlan plan_fwd(int N, int Hin, int Win, int Cin, int Kout, int R, int S
 static size_t plan_fwd_ws(int N, int Hin, int Win, int Cin, int Kout, int R, int S, int Ho, int Wo) {
     return std::max(plan_fwd(N, Hin, Win, Cin, Kout, R, S, Ho, Wo, 0).ws, plan_fwd(N, Hin, Win, Cin, Kout, R, S, Ho, Wo, 3).ws);
 }
-static size_t with_amax_scratch(size_t ws) { return align_up(ws, 16) + kAmaxScratch; }      // every conv workspace ends with the f16x3 scratch words
+static size_t with_amax_scratch(size_t ws) { return align_up(ws, 64) + kAmaxScratch; }      // every conv workspace ends with the f16x3 scratch words
 
 }  // namespace dsrl
 

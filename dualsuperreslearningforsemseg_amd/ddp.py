@@ -166,14 +166,14 @@ class FlatParams:
         self.wt_flat = torch.empty(floats, device=self.device, dtype=torch.float32)
         # one magnitude word per filter (max |w| as a bit pattern), re-measured by the same launch: the filter-side operand scale of the
         # f16x3 conv arithmetic (include/dsrl_hip.h: dsrl_amax)
-        self.w_amax = torch.zeros(len(entries), device=self.device, dtype=torch.int32)
+        self.w_amax = torch.zeros(len(entries) * HF.AMAX_WORDS, device=self.device, dtype=torch.int32)      # one amax record per filter
         rows, tiles = [], 0
         for i, (w, K, Kp, RS, C, off) in enumerate(entries):
             wt = self.wt_flat[off:off + C * RS * Kp]
             w._dsrl_wt = wt
-            w._dsrl_wamax = self.w_amax[i:i + 1]
+            w._dsrl_wamax = self.w_amax[i * HF.AMAX_WORDS:(i + 1) * HF.AMAX_WORDS]
             ct = (C + 31) // 32
-            rows.append([w.data_ptr(), wt.data_ptr(), K, Kp, RS, C, tiles, ct, self.w_amax.data_ptr() + 4 * i, 0])
+            rows.append([w.data_ptr(), wt.data_ptr(), K, Kp, RS, C, tiles, ct, self.w_amax.data_ptr() + 4 * HF.AMAX_WORDS * i, 0])
             tiles += RS * ct * ((Kp + 31) // 32)
         self._wt_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
         self._wt_rows, self._wt_tiles = len(rows), tiles

@@ -39,13 +39,13 @@ pretranspose_filters = os.environ.get('DSRL_PRETRANSPOSE', '0') != '0'
 
 
 CONV_PRECISION_MODES = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'mixed': 3, 'f16x3': 4}
-DEFAULT_CONV_PRECISION = 2
+DEFAULT_CONV_PRECISION = 4
 
 
 def set_conv_precision(mode):
     """Arithmetic of the conv kernels (include/dsrl_hip.h: dsrl_conv_precision): 'fp32' (exact fp32 MFMA products), 'bf16x3',
-    'bf16x6' (fp32-equivalent; the default), 'mixed' (forward bf16x6, backward bf16x3) or 'f16x3' (two fp16 terms of the per-tensor
-    scaled operands: fp32-equivalent at half the matrix work of bf16x6); None follows DSRL_CONV_PRECISION.
+    'bf16x6' (fp32-equivalent), 'mixed' (forward bf16x6, backward bf16x3) or 'f16x3' (two fp16 terms of the per-tensor scaled
+    operands: fp32-equivalent at half the matrix work of bf16x6; the default since round 3); None follows DSRL_CONV_PRECISION.
     Returns the previous setting as the library reported it (an int, -1 = environment)."""
     code = -1 if mode is None else (CONV_PRECISION_MODES[mode] if isinstance(mode, str) else int(mode))
     if not -1 <= code <= 4:
@@ -74,11 +74,11 @@ def get_conv_precision():
 
 # ------------------------------------------------------------------------------------------------ operand magnitudes (f16x3 arithmetic)
 # The f16x3 conv kernels scale every operand tensor by a power of two taken from max |x| of the whole tensor (include/dsrl_hip.h:
-# dsrl_amax).  A magnitude is one uint32 device word ("slot"); a tensor that has one carries it as the attribute `_dsrl_amax`, left by
+# dsrl_amax).  A magnitude is one amax record of 256 uint32 device words ("slot"); a tensor that has one carries it as the attribute `_dsrl_amax`, left by
 # the kernel that wrote the tensor (BatchNorm apply / backward, the batched filter transpose) or by a dsrl_amax launch here, so that the
 # forward conv and the weight gradient (x) and the data and weight gradients (dy) share one measurement.  Slots come from an arena that
 # ddp.FlatParams.zero_grad() rewinds and zeroes at the start of every training step (one memset; static addresses under graph capture).
-_AMAX_SLOTS = 8192
+_AMAX_SLOTS, AMAX_WORDS = 2048, 256          # records per arena (a stage-3 step uses ~700); include/dsrl_hip.h: DSRL_AMAX_WORDS
 _amax_arena = {}            # device -> [int32 tensor, next free slot]
 
 
@@ -86,7 +86,7 @@ def amax_begin_step(device):
     """Rewinds the slot arena of `device` and zeroes it (stream-ordered): every slot handed out before belongs to a finished step."""
     ar = _amax_arena.get(device)
     if ar is None:
-        ar = _amax_arena[device] = [torch.zeros(_AMAX_SLOTS, dtype=torch.int32, device=device), 0]
+        ar = _amax_arena[device] = [torch.zeros(_AMAX_SLOTS * AMAX_WORDS, dtype=torch.int32, device=device), 0]
     else:
         ar[0].zero_()
         ar[1] = 0
@@ -97,10 +97,10 @@ def amax_slot(device):
     ar = _amax_arena.get(device)
     if ar is None or ar[1] >= _AMAX_SLOTS:
         # no step context (or an exhausted arena): a fresh zeroed arena; views keep the old one alive for the kernels that still read it
-        ar = _amax_arena[device] = [torch.zeros(_AMAX_SLOTS, dtype=torch.int32, device=device), 0]
+        ar = _amax_arena[device] = [torch.zeros(_AMAX_SLOTS * AMAX_WORDS, dtype=torch.int32, device=device), 0]
     i = ar[1]
     ar[1] = i + 1
-    return ar[0][i:i + 1]
+    return ar[0][i * AMAX_WORDS:(i + 1) * AMAX_WORDS]
 
 
 def f16_mode():
@@ -449,7 +449,11 @@ class _Fork(torch.autograd.Function):
 
 
 def fork(x):
-    return _Fork.apply(x)
+    y = _Fork.apply(x)
+    a = getattr(x, '_dsrl_amax', None)
+    if a is not None:
+        y._dsrl_amax = a            # the alias holds the same values: it keeps the magnitude word of the tensor it aliases
+    return y
 
 
 # ------------------------------------------------------------------------------------------------ conv2d
@@ -669,6 +673,9 @@ class _BNAct(torch.autograd.Function):
         P = N * H * W
         st = _stream()
         y = new_cl((N, Cc, H, W), x)
+        # f16x3 conv arithmetic: the kernel leaves max |y| while it writes y (functional.amax_for finds it on the tensor)
+        ya = amax_slot(x.device) if f16_mode() else None
+        ya_ptr = None if ya is None else ya.data_ptr()
         res_ptr, ldr = None, 0
         if residual is not None:
             residual, ldr = pm(residual)
@@ -683,18 +690,20 @@ class _BNAct(torch.autograd.Function):
                 call('dsrl_bn_train_fwd_from_stats', x.data_ptr(), ldx, y.data_ptr(), Cc, P, Cc, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
                      None if running_mean is None else running_mean.data_ptr(), None if running_var is None else running_var.data_ptr(),
                      gamma.data_ptr(), beta.data_ptr(), res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream),
-                     stats.data_ptr(), int(stats_parts), st)
+                     stats.data_ptr(), int(stats_parts), ya_ptr, st)
             else:
                 call('dsrl_bn_train_fwd', x.data_ptr(), ldx, y.data_ptr(), Cc, P, Cc, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
                      None if running_mean is None else running_mean.data_ptr(), None if running_var is None else running_var.data_ptr(),
                      gamma.data_ptr(), beta.data_ptr(), res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream),
-                     ws.data_ptr(), ws.numel(), st)
+                     ws.data_ptr(), ws.numel(), ya_ptr, st)
         else:
             mean = running_mean
             invstd = torch.empty(Cc, device=x.device, dtype=torch.float32)
             call('dsrl_bn_invstd_from_var', running_var.data_ptr(), Cc, float(eps), invstd.data_ptr(), st)
             call('dsrl_bn_apply', x.data_ptr(), ldx, y.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                 res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream), st)
+                 res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream), ya_ptr, st)
+        if ya is not None:
+            y._dsrl_amax = ya
         ctx.save_for_backward(x, y, mean, invstd, gamma)
         if out_link is not None and drop_p == 0.0 and Cc % 32 == 0 and ldx == Cc:
             out_link.x, out_link.mean, out_link.invstd, out_link.relu, out_link.valid = x, mean, invstd, bool(relu), True
@@ -719,17 +728,21 @@ class _BNAct(torch.autograd.Function):
             sb = _sink(ctx.gb[1]) if sg is not None else None
         dgamma = sg if sg is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
         dbeta = sb if sb is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
+        dxa = amax_slot(x.device) if f16_mode() else None       # max |dx|, left by the kernel: dx is the dy operand of the conv in front of this BN
+        dxa_ptr = None if dxa is None else dxa.data_ptr()
         link = ctx.out_link
         if link is not None and link.stats is not None and link.dx_ptr == dy.data_ptr() and lddy == Cc and drop_p == 0.0:
             # the gradient we received is the buffer the consuming conv's dgrad wrote, and it left our two per-channel sums with it
             call('dsrl_bn_bwd_from_stats', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,
                  None if dres is None else dres.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                 dgamma.data_ptr(), dbeta.data_ptr(), int(relu), int(training), link.stats.data_ptr(), int(link.parts), _stream())
+                 dgamma.data_ptr(), dbeta.data_ptr(), int(relu), int(training), link.stats.data_ptr(), int(link.parts), dxa_ptr, _stream())
         else:
             ws = _ws(cquery('dsrl_bn_workspace_bytes', P, Cc), x)
             call('dsrl_bn_bwd', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,
                  None if dres is None else dres.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                 dgamma.data_ptr(), dbeta.data_ptr(), int(relu), drop_p, int(training), ws.data_ptr(), ws.numel(), _stream())
+                 dgamma.data_ptr(), dbeta.data_ptr(), int(relu), drop_p, int(training), ws.data_ptr(), ws.numel(), dxa_ptr, _stream())
+        if dxa is not None:
+            dx._dsrl_amax = dxa
         if sg is not None:
             ctx.gb[0]._dsrl_arena.written(ctx.gb[0]); dgamma = None
         if sb is not None:

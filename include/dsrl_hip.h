@@ -48,7 +48,7 @@ int dsrl_device_check(int* cu_count);
 
 /* ------------------------------------------------------------------------------------------------
  * conv2d: implicit GEMM on the matrix cores; fp32 in / out / accumulate, products formed as dsrl_conv_precision selects
- * (default: "bf16x6" split-precision bf16 MFMAs = fp32-equivalent in every pass; mode 0: v_mfma_f32_32x32x2_f32).
+ * (default: "f16x3" split-precision fp16 MFMAs = fp32-equivalent in every pass; mode 0: v_mfma_f32_32x32x2_f32).
  * replaces nn.Conv2d forward/backward at ASPP.py:10-15,19; DSRL.py:19-23,34-38,42-46,50,78-83 and the
  * ResNet101.py convolutions; x (N,H,W,C) -> y (N,Ho,Wo,K).
  * ---------------------------------------------------------------------------------------------- */
@@ -70,9 +70,9 @@ size_t dsrl_conv2d_transposed_filter_floats(int C, int K, int R, int S);
 int dsrl_conv2d_transpose_filter(const float* w, float* wt, int C, int K, int R, int S, dsrl_stream_t stream);
 /* The same for n filters in one launch (once per training step instead of once per layer): table is a DEVICE array of n rows of ten
  * int64 {w pointer, wt pointer, K, Kp = K rounded up to 4, R*S, C, index of the row's first 32x32 tile, ceil(C/32), amax pointer, 0}, rows
- * ordered by first tile; total_tiles = sum over rows of R*S * ceil(C/32) * ceil(Kp/32). A non-zero amax pointer names a uint32 device word
- * (zeroed by the caller before the launch) into which the launch maxes the bit pattern of max |w| of that filter: the filter's operand
- * magnitude for the "f16x3" arithmetic (dsrl_conv2d_*_amax below). */
+ * ordered by first tile; total_tiles = sum over rows of R*S * ceil(C/32) * ceil(Kp/32). A non-zero amax pointer names an amax record
+ * (DSRL_AMAX_WORDS uint32, zeroed by the caller before the launch) into which the launch maxes the bit pattern of max |w| of that filter:
+ * the filter's operand magnitude for the "f16x3" arithmetic (dsrl_amax, dsrl_conv2d_*_amax below). */
 int dsrl_conv2d_transpose_filters_batched(const int64_t* table, int n, int64_t total_tiles, dsrl_stream_t stream);
 size_t dsrl_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, const float* wt /*nullable*/, float* dx, int lddx,
@@ -120,14 +120,17 @@ int dsrl_conv2d_wgrad_group_plan(const dsrl_wgrad_problem* problems, int n, void
 int dsrl_conv2d_wgrad_group_launch(const void* host_table, const void* dev_table, dsrl_stream_t stream);
 /* Operand magnitudes for the "f16x3" arithmetic (dsrl_conv_precision 4). That arithmetic carries every operand as two fp16 terms of
  * x * 2^e, with e chosen per TENSOR so that the tensor's largest magnitude lands in [2^14, 2^15); it therefore needs max |x| of both
- * operands of a launch, as a uint32 device word holding the bit pattern of max |x| ("amax word"). Producers can leave that word while
- * they write the tensor (the y_amax / dx_amax arguments of the BatchNorm kernels, the batched filter transpose above); dsrl_amax measures
- * any pixel-major tensor: it maxes into *amax atomically, the caller zeroes the word first (several calls may share a word).
- * The *_amax entry points below are dsrl_conv2d_fwd(_stats) / _dgrad(_bnstats, _accumulate) / _wgrad with the two words passed in; a
- * null word - and every call through the plain entry points - is measured by the call itself (one extra pass over that operand, in
- * the last 256 bytes of the workspace, which the *_workspace_bytes queries include). The other arithmetics ignore the words.
+ * operands of a launch, as an "amax record": DSRL_AMAX_WORDS uint32 device words (1 KiB, 64-byte aligned) of which every 16th holds the
+ * bit pattern of a partial maximum of |x| (the writers' atomics are spread over 16 cache lines; the maximum of the record is max |x|).
+ * Producers can leave the record while they write the tensor (the y_amax / dx_amax arguments of the BatchNorm kernels, the batched filter
+ * transpose above); dsrl_amax measures any pixel-major tensor: it maxes into the record atomically, the caller zeroes the record first
+ * (several calls may share a record).
+ * The *_amax entry points below are dsrl_conv2d_fwd(_stats) / _dgrad(_bnstats, _accumulate) / _wgrad with the two records passed in; a
+ * null record - and every call through the plain entry points - is measured by the call itself (one extra pass over that operand, in
+ * the last 2 KiB of the workspace, which the *_workspace_bytes queries include). The other arithmetics ignore the records.
  * dsrl_conv2d_fwd_amax: stats may be null (no BatchNorm partials); dsrl_conv2d_dgrad_amax: bstats may be null (no BatchNorm sums; the
  * bn_* arguments are then unused), accumulate as in dsrl_conv2d_dgrad_accumulate. */
+#define DSRL_AMAX_WORDS 256
 int dsrl_amax(const float* x, int ld, int64_t P, int C, uint32_t* amax, dsrl_stream_t stream);
 int dsrl_conv2d_fwd_amax(const float* x, int ldx, const uint32_t* x_amax, const float* w, const uint32_t* w_amax, const float* bias /*nullable*/,
                          float* y, int ldy, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
@@ -144,11 +147,11 @@ int dsrl_conv2d_wgrad_amax(const float* x, int ldx, const uint32_t* x_amax, cons
  * accumulation in every mode; the modes differ in how the products are formed on the matrix cores:
  *   0  v_mfma_f32_32x32x2_f32 (exact fp32 products)
  *   1  "bf16x3": operand = 2 bf16 terms (16 mantissa bits), 3 bf16 MFMAs per product; ~5e-6 relative error per conv
- *   2  "bf16x6": operand = 3 bf16 terms (24 mantissa bits), 6 bf16 MFMAs per product; error vs fp64 equal to mode 0 (default)
+ *   2  "bf16x6": operand = 3 bf16 terms (24 mantissa bits), 6 bf16 MFMAs per product; error vs fp64 equal to mode 0
  *   3  "mixed": forward bf16x6, dgrad / wgrad bf16x3 (reduced-precision gradients, ~5e-6)
  *   4  "f16x3": operand = 2 fp16 terms of the per-tensor scaled value (22 mantissa bits), 3 fp16 MFMAs per product; error vs fp64 equal
- *      to modes 0 and 2 at half the matrix work of mode 2 (operand magnitudes: see dsrl_amax above)
- *  -1  follow the environment variable DSRL_CONV_PRECISION (unset = 2)
+ *      to modes 0 and 2 at half the matrix work of mode 2 (operand magnitudes: see dsrl_amax above); the default
+ *  -1  follow the environment variable DSRL_CONV_PRECISION (unset = 4)
  * Any other value changes nothing (query). Returns the previous setting. */
 int dsrl_conv_precision(int mode);
 /* in-bounds multiply-accumulates of one forward conv (zero-padding taps excluded): the roofline numerator */
@@ -188,17 +191,20 @@ int dsrl_bn_stats(const float* x, int ldx, int64_t P, int C, float eps, float mo
                   void* ws, size_t ws_bytes, dsrl_stream_t stream);
 /* invstd[c] = 1/sqrt(running_var[c] + eps) (eval mode / frozen BN, train_or_resume.py:379-382) */
 int dsrl_bn_invstd_from_var(const float* running_var, int C, float eps, float* invstd, dsrl_stream_t stream);
-/* y = dropout(relu((x-mean)*invstd*gamma + beta + residual)); flags: bit0 relu; dropout when p > 0 */
+/* y = dropout(relu((x-mean)*invstd*gamma + beta + residual)); flags: bit0 relu; dropout when p > 0.
+ * y_amax / dx_amax (here and in the four functions below; nullable): an amax record (dsrl_amax), zeroed by the caller, into which the
+ * launch maxes the bit pattern of max |.| of the tensor it writes - the operand magnitude of the "f16x3" conv arithmetic, taken while
+ * the tensor is written instead of by a pass of its own. */
 int dsrl_bn_apply(const float* x, int ldx, float* y, int ldy, int64_t P, int C,
                   const float* mean, const float* invstd, const float* gamma, const float* beta,
                   const float* residual /*nullable*/, int ldr, int relu, float drop_p, uint64_t seed, uint32_t rng_stream,
-                  dsrl_stream_t stream);
+                  uint32_t* y_amax /*nullable*/, dsrl_stream_t stream);
 /* dsrl_bn_train_fwd with the batch statistics taken from the partials a preceding dsrl_conv2d_fwd_stats left behind (C a multiple of 32):
  * one streaming kernel, no statistics pass over x, no device-wide barrier. Same outputs as dsrl_bn_train_fwd. */
 int dsrl_bn_train_fwd_from_stats(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,
                                  float* running_mean /*nullable*/, float* running_var /*nullable*/, const float* gamma, const float* beta,
                                  const float* residual /*nullable*/, int ldr, int relu, float drop_p, uint64_t seed, uint32_t rng_stream,
-                                 const float* stats, int stats_parts, dsrl_stream_t stream);
+                                 const float* stats, int stats_parts, uint32_t* y_amax /*nullable*/, dsrl_stream_t stream);
 /* The fused small-tensor BN kernels (dsrl_bn_train_fwd / dsrl_bn_bwd) cross a device-wide barrier: all blocks of a launch (128, or
  * 256 for tensors of 4.2-8.4 M elements; one 512-thread block per CU) must become resident together, so they assume that the process
  * has the GPU to itself apart from its own streams. dsrl_bn_fused_max_blocks: 0 = never use them, 128 = the 128-block variant only (what
@@ -214,20 +220,20 @@ int dsrl_bn_fused_barrier_timeouts(int64_t* count);
 int dsrl_bn_train_fwd(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,
                       float* running_mean /*nullable*/, float* running_var /*nullable*/, const float* gamma, const float* beta,
                       const float* residual /*nullable*/, int ldr, int relu, float drop_p, uint64_t seed, uint32_t rng_stream,
-                      void* ws, size_t ws_bytes, dsrl_stream_t stream);
+                      void* ws, size_t ws_bytes, uint32_t* y_amax /*nullable*/, dsrl_stream_t stream);
 /* backward of dsrl_bn_apply. y is the forward output (mask = y > 0 covers relu and dropout).
  * training != 0: batch-statistics gradient; == 0: statistics are constants. dresidual nullable. */
 int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy,
                 float* dx, int lddx, float* dresidual /*nullable*/, int lddr, int64_t P, int C,
                 const float* mean, const float* invstd, const float* gamma,
                 float* dgamma, float* dbeta, int relu, float drop_p, int training,
-                void* ws, size_t ws_bytes, dsrl_stream_t stream);
+                void* ws, size_t ws_bytes, uint32_t* dx_amax /*nullable*/, dsrl_stream_t stream);
 /* dsrl_bn_bwd (without dropout) with the two per-channel sums taken from the partials of dsrl_conv2d_dgrad_bnstats: one streaming kernel,
  * no reduction pass, no device-wide barrier (C a multiple of 32). */
 int dsrl_bn_bwd_from_stats(const float* x, int ldx, const float* y /*nullable*/, int ldy, const float* dy, int lddy, float* dx, int lddx,
                            float* dresidual /*nullable*/, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
                            float* dgamma /*nullable*/, float* dbeta /*nullable*/, int relu, int training, const float* stats, int stats_parts,
-                           dsrl_stream_t stream);
+                           uint32_t* dx_amax /*nullable*/, dsrl_stream_t stream);
 
 /* Device-resident dropout key. By default every dropout-bearing launch (dsrl_bn_apply, dsrl_bn_train_fwd*, dsrl_dropout_*) bakes its
  * `seed` argument into the launch. After dsrl_rng_bind_device_key(ptr) the kernels of the CURRENT device ignore that argument and read

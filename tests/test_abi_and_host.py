@@ -33,7 +33,7 @@ def test_library_exports_every_header_symbol():
     assert loaded.dsrl_conv2d_inbounds_macs(1, 16, 32, 2048, 256, 3, 3, 1, 18, 18) == 503316480        # d18 -> 503.3 M
     assert loaded.dsrl_conv2d_inbounds_macs(1, 16, 32, 2048, 256, 3, 3, 1, 6, 6) == 1585446912
     assert loaded.dsrl_conv2d_inbounds_macs(1, 64, 128, 304, 256, 3, 3, 1, 1, 1) == 190 * 382 * 304 * 256  # 5,648.5 M
-    assert loaded.dsrl_conv2d_fwd_workspace_bytes(8, 64, 128, 304, 256, 3, 3, 1, 1, 1) == 256      # no split-K slabs: only the f16x3 magnitude scratch
+    assert loaded.dsrl_conv2d_fwd_workspace_bytes(8, 64, 128, 304, 256, 3, 3, 1, 1, 1) == 2048     # no split-K slabs: only the two amax records of the f16x3 arithmetic
     assert loaded.dsrl_conv2d_fwd_workspace_bytes(8, 16, 32, 2048, 256, 3, 3, 1, 6, 6) > 0            # split-K slabs
 
 
@@ -132,7 +132,7 @@ def test_conv_precision_api_roundtrip():
     from dualsuperreslearningforsemseg_amd import functional as HF
     HF.set_conv_precision(None)
     default = HF.get_conv_precision()
-    assert default == {'0': 'fp32', '1': 'bf16x3', '2': 'bf16x6', '3': 'mixed', '4': 'f16x3'}[os.environ.get('DSRL_CONV_PRECISION', '2')]
+    assert default == {'0': 'fp32', '1': 'bf16x3', '2': 'bf16x6', '3': 'mixed', '4': 'f16x3'}[os.environ.get('DSRL_CONV_PRECISION', '4')]
     for mode in ('fp32', 'bf16x3', 'bf16x6', 'mixed', 'f16x3'):
         HF.set_conv_precision(mode)
         assert HF.get_conv_precision() == mode
