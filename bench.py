@@ -174,14 +174,13 @@ def decoder_stack_roofline(torch, HF, B, H, W, reps=10):
         gf = 2.0 * HF.conv2d_inbounds_macs(*shp) / 1e9
         # operand magnitudes of the f16x3 arithmetic: in the step they are left by the producers of x / dy and by the per-step filter pass,
         # so they are measured once here, outside the brackets (the other arithmetics ignore them)
-        xa = dya = wa = None
+        xa = dya = wa = wsp = wtsp = None
         if mode == 'f16x3':
-            wslot = HF.amax_slot(dev)
-            HF.call('dsrl_amax', wt.data_ptr(), C * R * R, K, C * R * R, wslot.data_ptr(), st)
-            keep.append(wslot)
-            xa, dya, wa = HF.amax_for(x, x, C).data_ptr(), HF.amax_for(dy, dy, Kp).data_ptr(), wslot.data_ptr()
-        t_f = _time_ms(lambda: _lib.call('dsrl_conv2d_fwd_amax', x.data_ptr(), C, xa, wt.data_ptr(), wa, None, y.data_ptr(), K, *shp, wsf.data_ptr(), wsf.numel(), None, 0, st), reps, torch)
-        t_d = _time_ms(lambda: _lib.call('dsrl_conv2d_dgrad_amax', dy.data_ptr(), Kp, dya, wt.data_ptr(), None, wa, dx.data_ptr(), C, *shp, wsd.data_ptr(), wsd.numel(),
+            wslot, wsp, wtsp, wtr = HF.split_filter(wt)         # the per-step filter pass of ddp.FlatParams, for this one filter
+            keep.append((wslot, wsp, wtsp, wtr))
+            xa, dya, wa, wsp, wtsp = HF.amax_for(x, x, C).data_ptr(), HF.amax_for(dy, dy, Kp).data_ptr(), wslot.data_ptr(), wsp.data_ptr(), wtsp.data_ptr()
+        t_f = _time_ms(lambda: _lib.call('dsrl_conv2d_fwd_amax', x.data_ptr(), C, xa, wt.data_ptr(), wa, wsp, None, y.data_ptr(), K, *shp, wsf.data_ptr(), wsf.numel(), None, 0, st), reps, torch)
+        t_d = _time_ms(lambda: _lib.call('dsrl_conv2d_dgrad_amax', dy.data_ptr(), Kp, dya, wt.data_ptr(), None, wa, wtsp, dx.data_ptr(), C, *shp, wsd.data_ptr(), wsd.numel(),
                                          None, 0, None, 0, None, None, 0, None, 0, 0, st), reps, torch)
         t_w = _time_ms(lambda: _lib.call('dsrl_conv2d_wgrad_amax', x.data_ptr(), C, xa, dy.data_ptr(), Kp, dya, dw.data_ptr(), *shp, wsw.data_ptr(), wsw.numel(), st), reps, torch)
         layers[name] = {'gflop': round(gf, 2), 'forward_tflops': round(gf / t_f, 1), 'dgrad_tflops': round(gf / t_d, 1), 'wgrad_per_layer_tflops': round(gf / t_w, 1)}

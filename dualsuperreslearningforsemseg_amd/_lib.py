@@ -51,8 +51,9 @@ PROTOTYPES = {
     'dsrl_conv2d_wgrad_group_plan': (i32, [fp, i32, fp, sz, fp, fp, sz]),
     'dsrl_conv2d_wgrad_group_launch': (i32, [fp, fp, stream_t]),
     'dsrl_amax': (i32, [fp, i32, i64, i32, fp, stream_t]),
-    'dsrl_conv2d_fwd_amax': (i32, [fp, i32, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, stream_t]),
-    'dsrl_conv2d_dgrad_amax': (i32, [fp, i32, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, fp, i32, fp, fp, i32, fp, i32, i32, stream_t]),
+    'dsrl_conv2d_fwd_amax': (i32, [fp, i32, fp, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, stream_t]),
+    'dsrl_conv2d_dgrad_amax': (i32, [fp, i32, fp, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, fp, i32, fp, fp, i32, fp, i32, i32, stream_t]),
+    'dsrl_conv2d_split_filters_batched': (i32, [fp, i32, i64, stream_t]),
     'dsrl_conv2d_wgrad_amax': (i32, [fp, i32, fp, fp, i32, fp, fp] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv_precision': (i32, [i32]),
     'dsrl_conv2d_inbounds_macs': (i64, _conv_shape),
@@ -64,6 +65,7 @@ PROTOTYPES = {
     'dsrl_colsum_workspace_bytes': (sz, [i64, i32]),
     'dsrl_colsum': (i32, [fp, i32, i64, i32, fp, fp, sz, stream_t]),
     'dsrl_bn_workspace_bytes': (sz, [i64, i32]),
+    'dsrl_bn_stats_floats': (sz, [i32, i32, i32]),
     'dsrl_bn_stats': (i32, [fp, i32, i64, i32, f32, f32, fp, fp, fp, fp, fp, sz, stream_t]),
     'dsrl_bn_invstd_from_var': (i32, [fp, i32, f32, fp, stream_t]),
     'dsrl_bn_apply': (i32, [fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, fp, stream_t]),

@@ -850,6 +850,57 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(const float* __rest
 }
 
 
+// More than 256 row blocks of partials (the M = 65536 layers: layer1, the decoder convs): kStatsReduced groups of consecutive row blocks are
+// merged first, one (32-channel group, reduced row) per block, with the formulas and the fixed order of the merges above; the apply
+// kernels then read kStatsReduced partials.  The reduced rows live behind the partials in the same buffer (dsrl_bn_stats_floats).
+constexpr int kStatsReduced = 32;
+// in [3][nparts][C] (n, mean, M2) -> out [3][kStatsReduced][C]
+__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
+    __shared__ double shm[8][3][32];
+    __shared__ float ref[32];
+    const int grp = blockIdx.x, rrow = blockIdx.y, tid = threadIdx.x, ch = tid & 31, k = tid >> 5;
+    const int per = (nparts + kStatsReduced - 1) / kStatsReduced, p0 = rrow * per, p1 = min(nparts, p0 + per);
+    const float* pn = part + grp * 32 + ch;
+    const float* pm_ = pn + (long long)nparts * C;
+    const float* pq = pn + 2ll * nparts * C;
+    const float mref = p0 < p1 ? pm_[(long long)p0 * C] : 0.f;
+    double N = 0, S = 0, T = 0;
+    for (int sl = p0 + k; sl < p1; sl += 8) {
+        const double nb = (double)pn[(long long)sl * C], d = (double)pm_[(long long)sl * C] - (double)mref;
+        N += nb; S += nb * d; T += (double)pq[(long long)sl * C] + nb * d * d;
+    }
+    shm[k][0][ch] = N; shm[k][1][ch] = S; shm[k][2][ch] = T;
+    if (k == 0) ref[ch] = mref;
+    __syncthreads();
+    if (tid < 32) {
+        N = S = T = 0;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) { N += shm[kk][0][tid]; S += shm[kk][1][tid]; T += shm[kk][2][tid]; }
+        const double mu = N > 0 ? (double)ref[tid] + S / N : 0.0, Q = N > 0 ? fmax(T - S * S / N, 0.0) : 0.0;
+        float* o = out + (long long)rrow * C + grp * 32 + tid;
+        o[0] = (float)N; o[(long long)kStatsReduced * C] = (float)mu; o[2ll * kStatsReduced * C] = (float)Q;
+    }
+}
+// in [2][nparts][C] (sum g, sum g * xhat) -> out [2][kStatsReduced][C]
+__global__ __launch_bounds__(256) void bn_bwd_stats_reduce_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
+    __shared__ double shm[8][2][32];
+    const int grp = blockIdx.x, rrow = blockIdx.y, tid = threadIdx.x, ch = tid & 31, k = tid >> 5;
+    const int per = (nparts + kStatsReduced - 1) / kStatsReduced, p0 = rrow * per, p1 = min(nparts, p0 + per);
+    const float* pa = part + grp * 32 + ch;
+    const float* pb = pa + (long long)nparts * C;
+    double a = 0, b = 0;
+    for (int sl = p0 + k; sl < p1; sl += 8) { a += (double)pa[(long long)sl * C]; b += (double)pb[(long long)sl * C]; }
+    shm[k][0][ch] = a; shm[k][1][ch] = b;
+    __syncthreads();
+    if (tid < 32) {
+        a = b = 0;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) { a += shm[kk][0][tid]; b += shm[kk][1][tid]; }
+        float* o = out + (long long)rrow * C + grp * 32 + tid;
+        o[0] = (float)a; o[(long long)kStatsReduced * C] = (float)b;
+    }
+}
+
 // BN backward from dgrad-epilogue partials: the conv whose data gradient IS this BatchNorm's output gradient already left
 // sum(g) and sum(g * xhat) per (row block, channel) (conv_igemm_split_kernel, DGRAD epilogue); merge them for the block's 32
 // channels (fp64, fixed order) and stream x, y, dy -> dx once.  No reduction pass, no device-wide barrier.
@@ -1169,6 +1220,11 @@ static bool fused_stream_ok(hipStream_t st) {
 }  // namespace dsrl
 
 extern "C" size_t dsrl_colsum_workspace_bytes(int64_t P, int C) { return (size_t)row_blocks(P) * C * sizeof(float); }
+// floats of a partials buffer of `rows` sums (3: forward statistics, 2: backward sums) x `parts` row blocks x C channels, with the room the
+// BatchNorm kernels need behind it to reduce more than 256 row blocks
+extern "C" size_t dsrl_bn_stats_floats(int rows, int parts, int C) {
+    return (size_t)rows * (size_t)(parts + (parts > 256 ? kStatsReduced : 0)) * (size_t)C;
+}
 
 extern "C" int dsrl_bn_stats(const float* x, int ldx, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,
                              float* running_mean, float* running_var, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
@@ -1260,16 +1316,22 @@ extern "C" int dsrl_bn_train_fwd(const float* x, int ldx, float* y, int ldy, int
 
 extern "C" int dsrl_bn_train_fwd_from_stats(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,
                                             float* running_mean, float* running_var, const float* gamma, const float* beta, const float* residual, int ldr,
-                                            int relu, float drop_p, uint64_t seed, uint32_t rng_stream, const float* stats, int stats_parts, uint32_t* y_amax,
+                                            int relu, float drop_p, uint64_t seed, uint32_t rng_stream, float* stats, int stats_parts, uint32_t* y_amax,
                                             dsrl_stream_t stream) {
     DSRL_REQUIRE(x && y && mean && invstd && gamma && beta && stats && P > 0 && P < (1ll << 31) && C > 0 && ldx >= C && ldy >= C, DSRL_E_BADARG, "bn_train_fwd_from_stats: bad arguments");
-    DSRL_REQUIRE(stats_parts > 0 && stats_parts <= 256, DSRL_E_BADARG, "bn_train_fwd_from_stats: %d row blocks of partials (1..256)", stats_parts);
+    DSRL_REQUIRE(stats_parts > 0 && stats_parts <= 4096, DSRL_E_BADARG, "bn_train_fwd_from_stats: %d row blocks of partials (1..4096)", stats_parts);
     DSRL_REQUIRE(C % 32 == 0 && vec4_ok(C, {ldx, ldy, residual ? ldr : 0}, {x, y, residual}), DSRL_E_UNSUPPORTED,
                  "bn_train_fwd_from_stats: C (%d) must be a multiple of 32, strides multiples of 4, pointers 16-byte aligned", C);
     DSRL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, DSRL_E_BADARG, "bn_train_fwd_from_stats: dropout p=%f outside [0,1)", drop_p);
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
     const int groups = C / 32;
+    if (stats_parts > 256) {            // reduced rows behind the partials (dsrl_bn_stats_floats)
+        float* red = stats + 3ll * stats_parts * C;
+        hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((unsigned)groups, kStatsReduced), dim3(256), 0, st, (const float*)stats, stats_parts, C, red);
+        if (int e = launch_status("bn_stats_reduce_kernel")) return e;
+        stats = red; stats_parts = kStatsReduced;
+    }
     int slabs = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(P, 32), ceil_div(4 * 256, groups)));     // ~4 blocks per CU, >= 32 rows each
     const int rows_per_slab = (int)ceil_div(P, (int64_t)slabs);
     slabs = (int)ceil_div(P, (int64_t)rows_per_slab);
@@ -1320,16 +1382,22 @@ extern "C" int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, con
 
 extern "C" int dsrl_bn_bwd_from_stats(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
                                       float* dresidual, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
-                                      float* dgamma, float* dbeta, int relu, int training, const float* stats, int stats_parts, uint32_t* dx_amax,
+                                      float* dgamma, float* dbeta, int relu, int training, float* stats, int stats_parts, uint32_t* dx_amax,
                                       dsrl_stream_t stream) {
     DSRL_REQUIRE(x && dy && dx && mean && invstd && gamma && stats && P > 0 && P < (1ll << 31) && C > 0, DSRL_E_BADARG, "bn_bwd_from_stats: bad arguments");
     DSRL_REQUIRE(y || !relu, DSRL_E_BADARG, "bn_bwd_from_stats: forward output needed for the relu mask");
-    DSRL_REQUIRE(stats_parts > 0 && stats_parts <= 256, DSRL_E_BADARG, "bn_bwd_from_stats: %d row blocks of partials (1..256)", stats_parts);
+    DSRL_REQUIRE(stats_parts > 0 && stats_parts <= 4096, DSRL_E_BADARG, "bn_bwd_from_stats: %d row blocks of partials (1..4096)", stats_parts);
     DSRL_REQUIRE(C % 32 == 0 && vec4_ok(C, {ldx, y ? ldy : 0, lddy, lddx, dresidual ? lddr : 0}, {x, y, dy, dx, dresidual}), DSRL_E_UNSUPPORTED,
                  "bn_bwd_from_stats: C (%d) must be a multiple of 32, strides multiples of 4, pointers 16-byte aligned", C);
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
     const int groups = C / 32;
+    if (stats_parts > 256) {
+        float* red = stats + 2ll * stats_parts * C;
+        hipLaunchKernelGGL(bn_bwd_stats_reduce_kernel, dim3((unsigned)groups, kStatsReduced), dim3(256), 0, st, (const float*)stats, stats_parts, C, red);
+        if (int e = launch_status("bn_bwd_stats_reduce_kernel")) return e;
+        stats = red; stats_parts = kStatsReduced;
+    }
     int slabs = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(P, 32), ceil_div(4 * 256, groups)));
     const int rows_per_slab = (int)ceil_div(P, (int64_t)slabs);
     slabs = (int)ceil_div(P, (int64_t)rows_per_slab);

@@ -100,7 +100,8 @@ struct ConvArgs {
     // Host side: Ho % par == Wo % par == 0, pixels per class % pbm == 0 (a tile never straddles classes), Wh % 32 == 0 (32 consecutive rows
     // are 32 consecutive pixels of one image row of the class: the epilogue derives their offsets from the first one).
     int par, Hh, Wh, pbm;
-    const unsigned* amax_a; const unsigned* amax_b;     // f16x3: max |.| (bit patterns) of the input tensor x and of the filter w
+    const unsigned* amax_a; const unsigned* amax_b;     // f16x3: amax records of the input tensor x and of the filter w
+    int w_split;                                        // f16x3: `w` is the pre-split filter (kernel ARITH = 2)
 };
 __device__ __forceinline__ int dgrad_pix(const ConvArgs& a, int m) {        // row of the parity-ordered GEMM -> pixel index (n*Ho + h)*Wo + w
     const int t = m / a.pbm, p2 = a.par * a.par, c = t % p2, j = (t / p2) * a.pbm + (m - t * a.pbm);
@@ -364,8 +365,13 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
 //   * KG > 1 ("K groups", for grids of at most ~1.5 tiles per CU): the block has KG groups of 4 waves, group g runs the same pipeline
 //     on chunks g, g+KG, ... with its own two LDS stages, and the KG accumulator sets are summed through LDS in a fixed order at the
 //     end - the latency-hiding of split-K (more waves per SIMD) without slab traffic or a reduce launch.
-template <int MR, int NR, int WGM, int WGN, bool DGRAD, int NPL, int KG = 1, bool F16 = false>
+// ARITH: 0 = bf16 terms; 1 = f16x3, both operands split here; 2 = f16x3 with the filter operand already split (ConvArgs::w then points at the
+// filter in "plane" form - per 4 consecutive channels 4 fp16 first terms followed by the 4 second terms, 16 bytes for 16 bytes of fp32, same
+// indexing - written once per training step by weight_split_batched_kernel with the scale of a.amax_b): its staged float4 are stored to
+// LDS as they come, which removes half of the split work of a chunk - work that every one of the M / BM row tiles used to repeat.
+template <int MR, int NR, int WGM, int WGN, bool DGRAD, int NPL, int KG = 1, int ARITH = 0>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_kernel(const ConvArgs a) {
+    constexpr bool F16 = ARITH != 0, PREB = ARITH == 2;
     static_assert(!F16 || NPL == 2, "f16x3 carries two fp16 terms per operand");
     using PT = Plane<F16>;
     using pl4 = typename PT::v4; using pl8 = typename PT::v8;
@@ -520,6 +526,15 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
     float res[4] = {0.f, 0.f, 0.f, 0.f};
     auto cstep = [&](char* nb, float4 (*R)[2], int hf, int c) {        // plane c % NPL of staged value c / NPL
         const int v = c / NPL, pl = c % NPL;
+        if (PREB && v >= A_IT) {                // filter rows arrive split: first terms in .x .y, second terms in .z .w
+            if (pl == 0 && b_rows) {
+                const float4 x = R[v][hf];
+                char* q = nb + (NPL * BM + r0 + 64 * (v - A_IT)) * ROWB + w_swz;
+                *reinterpret_cast<uint2*>(q) = make_uint2(__float_as_uint(x.x), __float_as_uint(x.y));
+                *reinterpret_cast<uint2*>(q + BN * ROWB) = make_uint2(__float_as_uint(x.z), __float_as_uint(x.w));
+            }
+            return;
+        }
         if (pl == 0) {
             const float4 x = R[v][hf]; res[0] = x.x; res[1] = x.y; res[2] = x.z; res[3] = x.w;
             if (F16) {
@@ -920,6 +935,60 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     if (threadIdx.x == 0) {
         m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
         if (m) atomicMax(amax_shard(out), m);
+    }
+}
+
+// Filters in "plane" form for the f16x3 kernels (ARITH = 2), all filters of the model in one launch, once per training step behind
+// weight_transpose_batched_kernel (which leaves every filter's amax record): for each 32 x 32 (k, c) tile of a tap, w_split [K][RS][C] and
+// wt_split [C][RS][Kp] receive, per 4 consecutive elements of the contiguous dimension, the 4 first terms f16(v * 2^e) followed by the 4
+// second terms f16(v * 2^e - first) - 16 bytes where the fp32 filter has 16 bytes, so both are indexed exactly like w and wt.
+// Table rows as for the transpose, kWtRow int64: {w, wt_split, K, Kp, RS, C, first tile, tiles along C, amax record, w_split}.
+__device__ __forceinline__ uint4 split4_f16(float a, float b, float c, float d, int sh) {
+    float r[4] = {__builtin_ldexpf(a, sh), __builtin_ldexpf(b, sh), __builtin_ldexpf(c, sh), __builtin_ldexpf(d, sh)};
+    const f16x4 t = Plane<true>::cvt(r);
+    Plane<true>::residual(r, t);
+    const f16x4 u = Plane<true>::cvt(r);
+    const uint2 hi = __builtin_bit_cast(uint2, t), lo = __builtin_bit_cast(uint2, u);
+    return make_uint4(hi.x, hi.y, lo.x, lo.y);
+}
+__global__ __launch_bounds__(256) void weight_split_batched_kernel(const long long* __restrict__ table, int n, long long total_tiles) {
+    __shared__ float tile[32][33];
+    const long long b0 = (long long)blockIdx.x * kWtTilesPerBlock;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * kWtRow + 6] <= b0) lo = mid; else hi = mid - 1;
+    }
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, row = threadIdx.x >> 3, g4 = (threadIdx.x & 7) * 4;
+    for (int u = 0; u < kWtTilesPerBlock; ++u) {
+        const long long b = b0 + u;
+        if (b >= total_tiles) break;
+        while (lo + 1 < n && table[(lo + 1) * kWtRow + 6] <= b) ++lo;
+        const long long* e = table + lo * kWtRow;
+        const float* w = reinterpret_cast<const float*>(e[0]);
+        uint4* wts = reinterpret_cast<uint4*>(e[1]);
+        uint4* wsp = reinterpret_cast<uint4*>(e[9]);
+        const int K = (int)e[2], Kp = (int)e[3], RS = (int)e[4], C = (int)e[5], ct = (int)e[7];
+        const int kt = (Kp + 31) / 32;
+        int t = (int)(b - e[6]);
+        const int tap = t / (ct * kt); t -= tap * ct * kt;
+        const int k0 = (t / ct) * 32, c0 = (t % ct) * 32;
+        const int sh = amax_shift(reinterpret_cast<const unsigned*>(e[8]));
+        __syncthreads();                        // the previous tile has been read out
+#pragma unroll
+        for (int r = ty; r < 32; r += 8) {
+            const int k = k0 + r, c = c0 + tx;
+            tile[r][tx] = (k < K && c < C) ? w[((long long)k * RS + tap) * C + c] : 0.f;
+        }
+        __syncthreads();
+        {   // w_split: row = out channel, 4 consecutive input channels per thread
+            const int k = k0 + row, c = c0 + g4;
+            if (wsp != nullptr && k < K && c < C) wsp[(((long long)k * RS + tap) * C + c) >> 2] = split4_f16(tile[row][g4], tile[row][g4 + 1], tile[row][g4 + 2], tile[row][g4 + 3], sh);
+        }
+        {   // wt_split: row = input channel, 4 consecutive out channels per thread (k in [K, Kp): zero padding)
+            const int c = c0 + row, k = k0 + g4;
+            if (wts != nullptr && c < C && k < Kp) wts[(((long long)c * RS + tap) * Kp + k) >> 2] = split4_f16(tile[g4][row], tile[g4 + 1][row], tile[g4 + 2][row], tile[g4 + 3][row], sh);
+        }
     }
 }
 
@@ -1623,7 +1692,7 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
                 (void)attr;                                                                                                            \
                 hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_, F16_>), grid, dim3(256 * KG_), lds, st, a); \
             }
-#define DSRL_KG_BY_ARITH(a_, b_, c_, d_, KG_) { if (f16) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, true) else if (npl == 2) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, false) else DSRL_LAUNCH_KG(a_, b_, c_, d_, 3, KG_, false) }
+#define DSRL_KG_BY_ARITH(a_, b_, c_, d_, KG_) { if (f16 && a.w_split) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 2) else if (f16) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 1) else if (npl == 2) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 0) else DSRL_LAUNCH_KG(a_, b_, c_, d_, 3, KG_, 0) }
             if (cfg == T64x64) {
                 if (kg == 4) DSRL_KG_BY_ARITH(1, 1, 2, 2, 4) else DSRL_KG_BY_ARITH(1, 1, 2, 2, 2)
             } else if (cfg == T128x64) {
@@ -1637,7 +1706,8 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
         }
         const size_t lds2 = stages;
 #define DSRL_LAUNCH_SPLIT(a_, b_, c_, d_)                                                                                    \
-        if (f16) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, true>), grid, dim3(256), lds2, st, a); \
+        if (f16 && a.w_split) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2>), grid, dim3(256), lds2, st, a); \
+        else if (f16) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 1>), grid, dim3(256), lds2, st, a); \
         else if (npl == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2>), grid, dim3(256), lds2, st, a); \
         else hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 3>), grid, dim3(256), lds2, st, a);
         DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_SPLIT)
@@ -1754,6 +1824,7 @@ extern "C" size_t dsrl_conv2d_fwd_workspace_bytes(int N, int H, int W, int C, in
 
 // rows blocks of BatchNorm partials a forward launch of this shape writes in the current arithmetic mode (0 = it cannot: fp32 kernels,
 // split-K slabs, or more than 256 row blocks)
+constexpr int kMaxStatsParts = 4096;
 static int fwd_stats_parts(const FwdPlan& p, int npl, bool dgrad = false) {
     if (npl && p.splits > 1 && !dgrad && env_int("DSRL_SPLITK_STATS", 1))      // forward split-K: the slab reduce leaves partials of 64 rows each
         return ((p.ws / ((size_t)p.splits * p.M * sizeof(float))) % 32 == 0 && ceil_div(p.M, 64) <= 256) ? (int)ceil_div(p.M, 64) : 0;
@@ -1761,7 +1832,7 @@ static int fwd_stats_parts(const FwdPlan& p, int npl, bool dgrad = false) {
     int bm, bn; cfg_dims(p.cfg, bm, bn);
     static const int kWGM[kNumCfg] = {2, 4, 4, 2, 2, 2, 4};          // waves along M per block tile, DSRL_CFG_SWITCH order
     const long long parts = ceil_div(p.M, bm) * kWGM[p.cfg];
-    return parts <= 256 ? (int)parts : 0;
+    return parts <= kMaxStatsParts ? (int)parts : 0;       // more than 256: the BatchNorm kernels reduce them to 32 first (bn.hip: stats_reduce)
 }
 extern "C" int dsrl_conv2d_fwd_stats_parts(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
     const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
@@ -1773,7 +1844,7 @@ extern "C" int dsrl_conv2d_fwd_stats_parts(int N, int H, int W, int C, int K, in
 static int fwd_impl(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                     void* ws, size_t ws_bytes, dsrl_stream_t stream, float* stats, int stats_parts,
-                    const unsigned* x_amax = nullptr, const unsigned* w_amax = nullptr) {
+                    const unsigned* x_amax = nullptr, const unsigned* w_amax = nullptr, const void* w_split = nullptr) {
     if (int e = check_conv(x, w, y, N, H, W, C, K, R, S, stride, pad, dil)) return e;
     DSRL_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, DSRL_E_UNSUPPORTED,
                  "conv2d_fwd: C (%d) and ldx (%d) must be multiples of 4 and x,w 16-byte aligned", C, ldx);
@@ -1793,6 +1864,10 @@ static int fwd_impl(const float* x, int ldx, const float* w, const float* bias, 
         OperandAmax am{x_amax, w_amax};
         if (int e = resolve_amax(am, x, ldx, (long long)N * H * W, C, w, C, (long long)K * R * S, C, ws, ws_bytes, p.ws, st, "conv2d_fwd")) return e;
         a.amax_a = am.a; a.amax_b = am.b;
+        if (w_split != nullptr && w_amax != nullptr && env_int("DSRL_PRESPLIT", 1)) {      // the split form carries the scale of ITS record
+            DSRL_REQUIRE(((uintptr_t)w_split % 16) == 0, DSRL_E_BADARG, "conv2d_fwd: unaligned pre-split filter");
+            a.w = (const float*)w_split; a.w_split = 1;
+        }
     }
     ProfScope prof(prof_family(PASS_FWD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
     prof.shape("fwd", N, H, W, C, K, R, stride, pad, dil);
@@ -1856,6 +1931,15 @@ extern "C" int dsrl_conv2d_transpose_filter(const float* w, float* wt, int C, in
     return launch_status("weight_transpose_kernel");
 }
 
+extern "C" int dsrl_conv2d_split_filters_batched(const int64_t* table, int n, int64_t total_tiles, dsrl_stream_t stream) {
+    DSRL_REQUIRE(table && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31), DSRL_E_BADARG, "conv2d_split_filters_batched: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(weight_split_batched_kernel, dim3((unsigned)ceil_div(total_tiles, (int64_t)kWtTilesPerBlock)), dim3(256), 0, st, (const long long*)table, n,
+                       (long long)total_tiles);
+    return launch_status("weight_split_batched_kernel");
+}
+
 extern "C" int dsrl_conv2d_transpose_filters_batched(const int64_t* table, int n, int64_t total_tiles, dsrl_stream_t stream) {
     DSRL_REQUIRE(table && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31), DSRL_E_BADARG, "conv2d_transpose_filters_batched: bad arguments");
     hipStream_t st = (hipStream_t)stream;
@@ -1869,7 +1953,7 @@ struct DgradBn { const float* x; const float* y; const float* mean; const float*
 static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                       void* ws, size_t ws_bytes, dsrl_stream_t stream, int accumulate, const DgradBn* bn = nullptr,
-                      const unsigned* dy_amax = nullptr, const unsigned* w_amax = nullptr) {
+                      const unsigned* dy_amax = nullptr, const unsigned* w_amax = nullptr, const void* wt_split = nullptr) {
     if (int e = check_conv(dy, w, dx, N, H, W, C, K, R, S, stride, pad, dil)) return e;
     const int Kp = pad4(K);     // K % 4 != 0 (cls_conv, 19 classes): dy must be padded to lddy >= Kp with finite pad values
     DSRL_REQUIRE(lddy % 4 == 0 && ((uintptr_t)dy % 16) == 0, DSRL_E_UNSUPPORTED,
@@ -1883,6 +1967,8 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
     DSRL_REQUIRE(ws && ws_bytes >= wtb + p.ws, DSRL_E_WORKSPACE, "conv2d_dgrad: workspace %zu < %zu", ws_bytes, wtb + p.ws);
     const float* wt = wt_in;
     float* slabs = (float*)((char*)ws + wtb);
+    const bool use_split = conv_f16() && wt_split != nullptr && w_amax != nullptr && env_int("DSRL_PRESPLIT", 1);
+    if (wt == nullptr && use_split) wt = (const float*)wt_split;         // replaced below; no fp32 transpose is built for it
     if (wt == nullptr) {
         hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)ceil_div(C, 32), (unsigned)ceil_div(Kp, 32), (unsigned)(R * S)), dim3(256), 0, st,
                            w, (float*)ws, K, Kp, R * S, C);
@@ -1901,6 +1987,10 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
         OperandAmax am{dy_amax, w_amax};
         if (int e = resolve_amax(am, dy, lddy, (long long)N * Ho * Wo, Kp, w, C, (long long)K * R * S, C, ws, ws_bytes, wtb + p.ws, st, "conv2d_dgrad")) return e;
         a.amax_a = am.a; a.amax_b = am.b;
+        if (wt_split != nullptr && w_amax != nullptr && env_int("DSRL_PRESPLIT", 1)) {
+            DSRL_REQUIRE(((uintptr_t)wt_split % 16) == 0, DSRL_E_BADARG, "conv2d_dgrad: unaligned pre-split filter");
+            a.w = (const float*)wt_split; a.w_split = 1;
+        }
     }
     ProfScope prof(prof_family(PASS_DGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
     prof.shape("dgrad", N, H, W, C, K, R, stride, pad, dil);
@@ -2103,24 +2193,25 @@ extern "C" int dsrl_amax(const float* x, int ld, int64_t P, int C, uint32_t* ama
     if (int e = bind_stream_device(st)) return e;
     return launch_amax(x, ld, P, C, amax, st);
 }
-extern "C" int dsrl_conv2d_fwd_amax(const float* x, int ldx, const uint32_t* x_amax, const float* w, const uint32_t* w_amax, const float* bias, float* y, int ldy,
-                                    int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+extern "C" int dsrl_conv2d_fwd_amax(const float* x, int ldx, const uint32_t* x_amax, const float* w, const uint32_t* w_amax, const void* w_split, const float* bias,
+                                    float* y, int ldy, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                                     void* ws, size_t ws_bytes, float* stats, int stats_parts, dsrl_stream_t stream) {
-    return fwd_impl(x, ldx, w, bias, y, ldy, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, stats, stats_parts, x_amax, w_amax);
+    return fwd_impl(x, ldx, w, bias, y, ldy, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, stats, stats_parts, x_amax, w_amax, w_split);
 }
-extern "C" int dsrl_conv2d_dgrad_amax(const float* dy, int lddy, const uint32_t* dy_amax, const float* w, const float* wt_in, const uint32_t* w_amax, float* dx, int lddx,
+extern "C" int dsrl_conv2d_dgrad_amax(const float* dy, int lddy, const uint32_t* dy_amax, const float* w, const float* wt_in, const uint32_t* w_amax, const void* wt_split,
+                                      float* dx, int lddx,
                                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                                       void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y, int bn_ldy,
                                       const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats, int stats_parts, int accumulate,
                                       dsrl_stream_t stream) {
     if (bstats == nullptr)
-        return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, accumulate ? 1 : 0, nullptr, dy_amax, w_amax);
+        return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, accumulate ? 1 : 0, nullptr, dy_amax, w_amax, wt_split);
     DSRL_REQUIRE(bn_x && bn_mean && bn_invstd && (bn_y || !bn_relu) && bn_ldx >= C && (!bn_relu || bn_ldy >= C), DSRL_E_BADARG, "conv2d_dgrad_amax: bad BatchNorm arguments");
     DSRL_REQUIRE(dsrl_conv2d_dgrad_stats_parts(N, H, W, C, K, R, S, stride, pad, dil) == stats_parts && stats_parts > 0, DSRL_E_BADARG,
                  "conv2d_dgrad_amax: this launch writes %d row blocks of partials, the caller expects %d",
                  dsrl_conv2d_dgrad_stats_parts(N, H, W, C, K, R, S, stride, pad, dil), stats_parts);
     DgradBn bn{bn_x, bn_y, bn_mean, bn_invstd, bstats, bn_ldx, bn_ldy, bn_relu};
-    return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, accumulate ? 1 : 0, &bn, dy_amax, w_amax);
+    return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, accumulate ? 1 : 0, &bn, dy_amax, w_amax, wt_split);
 }
 extern "C" int dsrl_conv2d_wgrad_amax(const float* x, int ldx, const uint32_t* x_amax, const float* dy, int lddy, const uint32_t* dy_amax, float* dw,
                                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

@@ -146,7 +146,7 @@ class FlatParams:
         """One arena with the [C][R][S][K padded to 4] transpose of every conv filter the dgrad kernel reads, refreshed by ONE
         launch per training step (dsrl_conv2d_transpose_filters_batched) instead of one launch inside every dgrad call."""
         from .nn_modules import HipConv2d
-        self.wt_valid, self._wt_table, self._wt_tiles = False, None, 0
+        self.wt_valid, self.wt_fp32_valid, self.split_valid, self._wt_table, self._wt_tiles = False, False, False, None, 0
         if self.device.type != 'cuda':
             return
         mine = {id(p) for p in self.params}
@@ -177,12 +177,39 @@ class FlatParams:
             tiles += RS * ct * ((Kp + 31) // 32)
         self._wt_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
         self._wt_rows, self._wt_tiles = len(rows), tiles
+        # f16x3 arithmetic: every filter also in pre-split ("plane") form, forward layout and transposed (dsrl_conv2d_split_filters_batched);
+        # the arenas are allocated on first use
+        self._split_entries, self._split_table = entries, None
+
+    def _build_split_filters(self):
+        floats_w = sum(_align(w.numel()) for w, *_ in self._split_entries)
+        self.wsplit_flat = torch.empty(floats_w, device=self.device, dtype=torch.float32)
+        self.wtsplit_flat = torch.empty(self.wt_flat.numel(), device=self.device, dtype=torch.float32)
+        rows, off_w = [], 0
+        base = self._wt_table.cpu()
+        for i, (w, K, Kp, RS, C, off) in enumerate(self._split_entries):
+            wsp = self.wsplit_flat[off_w:off_w + w.numel()]
+            wtsp = self.wtsplit_flat[off:off + C * RS * Kp]
+            off_w += _align(w.numel())
+            w._dsrl_wsplit, w._dsrl_wtsplit = wsp, wtsp
+            r = base[i].tolist()
+            rows.append([r[0], wtsp.data_ptr(), K, Kp, RS, C, r[6], r[7], r[8], wsp.data_ptr()])
+        self._split_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        amax_only = base.clone()
+        amax_only[:, 1] = 0                     # no transposed fp32 copy
+        self._amax_only_table = amax_only.to(self.device)
 
     def refresh_transposed_filters(self):
         if self._wt_table is not None and os.environ.get('DSRL_BATCHED_TRANSPOSE', '1') != '0':
             self.w_amax.zero_()
-            HF.call('dsrl_conv2d_transpose_filters_batched', self._wt_table.data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
-            self.wt_valid = True
+            presplit = HF.f16_mode() and os.environ.get('DSRL_PRESPLIT', '1') != '0'
+            if presplit and self._split_table is None:
+                self._build_split_filters()
+            # with pre-split filters nothing reads the fp32 transposes: the first launch then only measures (amax records), the second writes both split forms
+            HF.call('dsrl_conv2d_transpose_filters_batched', (self._amax_only_table if presplit else self._wt_table).data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
+            if presplit:
+                HF.call('dsrl_conv2d_split_filters_batched', self._split_table.data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
+            self.wt_valid, self.wt_fp32_valid, self.split_valid = True, not presplit, presplit
 
     def zero_grad(self):
         self.g_flat.zero_()
@@ -239,7 +266,7 @@ class FlatParams:
             HF.sgd_step_dev_(self.p_flat, self.g_flat, self.m_flat, hyper)
         else:
             HF.sgd_step_(self.p_flat, self.g_flat, self.m_flat, lr, momentum, weight_decay, 1.0 / self.world)
-        self.wt_valid = False               # the filters changed: the transposed copies are stale until the next refresh
+        self.wt_valid = self.wt_fp32_valid = self.split_valid = False       # the filters changed: transposed / split copies and amax records are stale until the next refresh
 
     def _trainable_in_model_order(self):
         return [p for p in self.model.parameters() if p.requires_grad]

@@ -359,6 +359,29 @@ def _weight_amax(w):
     return None
 
 
+def _weight_split(w, attr):
+    """The pre-split form of a conv filter that ddp.FlatParams wrote in this step (attr: '_dsrl_wsplit' forward layout, '_dsrl_wtsplit' transposed), or None."""
+    arena = getattr(w, '_dsrl_arena', None)
+    return getattr(w, attr, None) if (arena is not None and arena.split_valid) else None
+
+
+def split_filter(w):
+    """(amax record, w_split, wt_split) of one [K][R][S][C] filter for the f16x3 kernels: what ddp.FlatParams prepares for every filter of a
+    model once per step (dsrl_conv2d_transpose_filters_batched + dsrl_conv2d_split_filters_batched), here for a single tensor."""
+    w = w_cl(w)
+    K, C, R, S = w.shape
+    Kp, RS, ct = (K + 3) & ~3, R * S, (C + 31) // 32
+    tiles = RS * ct * ((Kp + 31) // 32)
+    rec = amax_slot(w.device)
+    wt = torch.empty(C * RS * Kp, device=w.device, dtype=torch.float32)
+    wsp, wtsp = torch.empty(K * RS * C, device=w.device, dtype=torch.float32), torch.empty_like(wt)
+    t1 = torch.tensor([[w.data_ptr(), wt.data_ptr(), K, Kp, RS, C, 0, ct, rec.data_ptr(), 0]], dtype=torch.int64, device=w.device)
+    t2 = torch.tensor([[w.data_ptr(), wtsp.data_ptr(), K, Kp, RS, C, 0, ct, rec.data_ptr(), wsp.data_ptr()]], dtype=torch.int64, device=w.device)
+    call('dsrl_conv2d_transpose_filters_batched', t1.data_ptr(), 1, tiles, _stream())
+    call('dsrl_conv2d_split_filters_batched', t2.data_ptr(), 1, tiles, _stream())
+    return rec, wsp, wtsp, wt
+
+
 def _is_krsc(w):
     """Is the (K,C,R,S) filter physically [K][R][S][C]?  (torch does not call plain-strided 1x1 filters channels_last although the
     two layouts coincide for them)"""
@@ -484,9 +507,10 @@ class _Conv2d(torch.autograd.Function):
             wa = _weight_amax(w_param)
         ctx.amax = (xa, wa)
         if stats_parts > 0:         # BatchNorm partials of y from the conv epilogue (include/dsrl_hip.h: dsrl_conv2d_fwd_stats)
-            stats = torch.empty(3 * stats_parts * K, device=x.device, dtype=torch.float32)
+            stats = torch.empty(cquery('dsrl_bn_stats_floats', 3, int(stats_parts), K), device=x.device, dtype=torch.float32)
+        wsp = _weight_split(w_param, '_dsrl_wsplit') if wa is not None else None        # the filter pre-split by ddp.FlatParams (same step, same record)
         call('dsrl_conv2d_fwd_amax', x.data_ptr(), ldx, None if xa is None else xa.data_ptr(), w.data_ptr(), None if wa is None else wa.data_ptr(),
-             None if bias is None else bias.data_ptr(), y.data_ptr(), K, *shp, ws.data_ptr(), ws.numel(),
+             None if wsp is None else wsp.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), K, *shp, ws.data_ptr(), ws.numel(),
              None if stats is None else stats.data_ptr(), int(stats_parts), _stream())
         ctx.save_for_backward(x, w)
         ctx.shp = shp
@@ -530,6 +554,7 @@ class _Conv2d(torch.autograd.Function):
             if wa is not None and ctx.wparam is not None and not getattr(getattr(ctx.wparam, '_dsrl_arena', None), 'wt_valid', False):
                 wa = None                             # the filter changed since its magnitude was taken
         p_ = lambda t_: None if t_ is None else t_.data_ptr()       # noqa: E731
+        wtsp = _weight_split(ctx.wparam, '_dsrl_wtsplit') if (wa is not None and ctx.wparam is not None) else None
         if ctx.needs_input_grad[1]:
             sink = _sink(ctx.wparam) if ctx.wparam is not None and _is_krsc(ctx.wparam) else None
             if sink is not None and wgrad_queue is not None:
@@ -566,7 +591,7 @@ class _Conv2d(torch.autograd.Function):
             elif ctx.wparam is not None:
                 # ddp.FlatParams keeps a transposed copy of every filter, refreshed by one batched launch per training step
                 arena, wt = getattr(ctx.wparam, '_dsrl_arena', None), getattr(ctx.wparam, '_dsrl_wt', None)
-                if wt is not None and arena is not None and arena.wt_valid:
+                if wt is not None and arena is not None and arena.wt_valid and arena.wt_fp32_valid:
                     wt_ptr = wt.data_ptr()
             link = ctx.in_link
             parts = 0
@@ -577,14 +602,14 @@ class _Conv2d(torch.autograd.Function):
                 parts = int(query('dsrl_conv2d_dgrad_stats_parts', *shp))
             if parts > 0:
                 # x is y = relu(bn(.)) of a BatchNorm that feeds only this conv: leave its backward partial sums with the data gradient
-                bstats = torch.empty(2 * parts * Cc, device=x.device, dtype=torch.float32)
+                bstats = torch.empty(cquery('dsrl_bn_stats_floats', 2, parts, Cc), device=x.device, dtype=torch.float32)
                 _, bld = pm(link.x)
-                call('dsrl_conv2d_dgrad_amax', dy.data_ptr(), lddy, p_(dya), w.data_ptr(), wt_ptr, p_(wa), dx.data_ptr(), Cc, *shp, ws.data_ptr(), ws.numel(),
+                call('dsrl_conv2d_dgrad_amax', dy.data_ptr(), lddy, p_(dya), w.data_ptr(), wt_ptr, p_(wa), p_(wtsp), dx.data_ptr(), Cc, *shp, ws.data_ptr(), ws.numel(),
                      link.x.data_ptr(), bld, x.data_ptr(), ldx, link.mean.data_ptr(), link.invstd.data_ptr(), int(link.relu),
                      bstats.data_ptr(), parts, int(acc), st)
                 link.stats, link.parts, link.dx_ptr = bstats, parts, dx.data_ptr()
             else:
-                call('dsrl_conv2d_dgrad_amax', dy.data_ptr(), lddy, p_(dya), w.data_ptr(), wt_ptr, p_(wa), dx.data_ptr(), Cc, *shp,
+                call('dsrl_conv2d_dgrad_amax', dy.data_ptr(), lddy, p_(dya), w.data_ptr(), wt_ptr, p_(wa), p_(wtsp), dx.data_ptr(), Cc, *shp,
                      ws.data_ptr(), ws.numel(), None, 0, None, 0, None, None, 0, None, 0, int(acc), st)
             if acc:
                 dx = None                   # the contribution went into the buffer autograd already holds for this input

@@ -58,7 +58,7 @@ int dsrl_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias /
                     void* ws, size_t ws_bytes, dsrl_stream_t stream);
 /* The same conv that additionally leaves BatchNorm partials of its output in `stats`: [3][parts][K] floats = (count, mean, centred
  * second moment) per (block of output rows, output channel), parts = dsrl_conv2d_fwd_stats_parts(shape) for the current arithmetic mode
- * (0: this launch cannot provide them - exact-fp32 kernels, split-K slabs, more than 256 row blocks). The BatchNorm that follows
+ * (0: this launch cannot provide them - exact-fp32 kernels, some split-K plans, more than 4096 row blocks). The BatchNorm that follows
  * (ASPP.py:19-20, DSRL.py:22-24,36-40,44-48, every ResNet block) then skips its own statistics pass: dsrl_bn_train_fwd_from_stats. */
 int dsrl_conv2d_fwd_stats_parts(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 int dsrl_conv2d_fwd_stats(const float* x, int ldx, const float* w, const float* bias /*nullable*/, float* y, int ldy,
@@ -74,13 +74,19 @@ int dsrl_conv2d_transpose_filter(const float* w, float* wt, int C, int K, int R,
  * (DSRL_AMAX_WORDS uint32, zeroed by the caller before the launch) into which the launch maxes the bit pattern of max |w| of that filter:
  * the filter's operand magnitude for the "f16x3" arithmetic (dsrl_amax, dsrl_conv2d_*_amax below). */
 int dsrl_conv2d_transpose_filters_batched(const int64_t* table, int n, int64_t total_tiles, dsrl_stream_t stream);
+/* Filters pre-split for the "f16x3" arithmetic, all filters in one launch behind the transpose above (which leaves the amax records this
+ * launch scales by): table rows {w, wt_split, K, Kp, R*S, C, first tile, ceil(C/32), amax record, w_split}; w_split [K][R][S][C] and
+ * wt_split [C][R][S][Kp] (either may be 0) hold, per 4 consecutive elements of the last dimension, the 4 fp16 first terms of v * 2^e
+ * followed by the 4 second terms: 16 bytes for 16 bytes of fp32, indexed like w / wt. dsrl_conv2d_fwd_amax / _dgrad_amax take them as
+ * w_split / wt_split together with the SAME amax record and then stage the filter operand without splitting it in every row tile. */
+int dsrl_conv2d_split_filters_batched(const int64_t* table, int n, int64_t total_tiles, dsrl_stream_t stream);
 size_t dsrl_conv2d_dgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 int dsrl_conv2d_dgrad(const float* dy, int lddy, const float* w, const float* wt /*nullable*/, float* dx, int lddx,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                       void* ws, size_t ws_bytes, dsrl_stream_t stream);
 /* dgrad of a conv whose input was y = relu(bn(x)) (or bn(x)): besides dx = the gradient w.r.t. y, the launch leaves the BatchNorm-backward
  * partial sums of g = dx * [y > 0] and g * xhat per (block of rows, channel) in bstats [2][parts][C], parts =
- * dsrl_conv2d_dgrad_stats_parts(shape) (0: this launch cannot - exact-fp32 kernels, split-K slabs, more than 256 row blocks). The
+ * dsrl_conv2d_dgrad_stats_parts(shape) (0: this launch cannot - exact-fp32 kernels, split-K slabs, more than 4096 row blocks). The
  * BatchNorm backward then needs no reduction of its own: dsrl_bn_bwd_from_stats. bn_y may be null when bn_relu = 0. */
 int dsrl_conv2d_dgrad_stats_parts(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 int dsrl_conv2d_dgrad_bnstats(const float* dy, int lddy, const float* w, const float* wt /*nullable*/, float* dx, int lddx,
@@ -132,11 +138,11 @@ int dsrl_conv2d_wgrad_group_launch(const void* host_table, const void* dev_table
  * bn_* arguments are then unused), accumulate as in dsrl_conv2d_dgrad_accumulate. */
 #define DSRL_AMAX_WORDS 256
 int dsrl_amax(const float* x, int ld, int64_t P, int C, uint32_t* amax, dsrl_stream_t stream);
-int dsrl_conv2d_fwd_amax(const float* x, int ldx, const uint32_t* x_amax, const float* w, const uint32_t* w_amax, const float* bias /*nullable*/,
-                         float* y, int ldy, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+int dsrl_conv2d_fwd_amax(const float* x, int ldx, const uint32_t* x_amax, const float* w, const uint32_t* w_amax, const void* w_split /*nullable*/,
+                         const float* bias /*nullable*/, float* y, int ldy, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                          void* ws, size_t ws_bytes, float* stats /*nullable*/, int stats_parts, dsrl_stream_t stream);
 int dsrl_conv2d_dgrad_amax(const float* dy, int lddy, const uint32_t* dy_amax, const float* w, const float* wt /*nullable*/, const uint32_t* w_amax,
-                           float* dx, int lddx, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                           const void* wt_split /*nullable*/, float* dx, int lddx, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                            void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y, int bn_ldy,
                            const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats /*nullable*/, int stats_parts, int accumulate,
                            dsrl_stream_t stream);
@@ -200,11 +206,14 @@ int dsrl_bn_apply(const float* x, int ldx, float* y, int ldy, int64_t P, int C,
                   const float* residual /*nullable*/, int ldr, int relu, float drop_p, uint64_t seed, uint32_t rng_stream,
                   uint32_t* y_amax /*nullable*/, dsrl_stream_t stream);
 /* dsrl_bn_train_fwd with the batch statistics taken from the partials a preceding dsrl_conv2d_fwd_stats left behind (C a multiple of 32):
- * one streaming kernel, no statistics pass over x, no device-wide barrier. Same outputs as dsrl_bn_train_fwd. */
+ * one streaming kernel, no statistics pass over x, no device-wide barrier. Same outputs as dsrl_bn_train_fwd. More than 256 row blocks of
+ * partials (up to 4096: the 65536-pixel layers) are first reduced to 32 by a small launch, into the room behind the partials: a partials
+ * buffer holds dsrl_bn_stats_floats(rows = 3 here / 2 for dsrl_bn_bwd_from_stats, parts, C) floats. */
+size_t dsrl_bn_stats_floats(int rows, int parts, int C);
 int dsrl_bn_train_fwd_from_stats(const float* x, int ldx, float* y, int ldy, int64_t P, int C, float eps, float momentum, float* mean, float* invstd,
                                  float* running_mean /*nullable*/, float* running_var /*nullable*/, const float* gamma, const float* beta,
                                  const float* residual /*nullable*/, int ldr, int relu, float drop_p, uint64_t seed, uint32_t rng_stream,
-                                 const float* stats, int stats_parts, uint32_t* y_amax /*nullable*/, dsrl_stream_t stream);
+                                 float* stats, int stats_parts, uint32_t* y_amax /*nullable*/, dsrl_stream_t stream);
 /* The fused small-tensor BN kernels (dsrl_bn_train_fwd / dsrl_bn_bwd) cross a device-wide barrier: all blocks of a launch (128, or
  * 256 for tensors of 4.2-8.4 M elements; one 512-thread block per CU) must become resident together, so they assume that the process
  * has the GPU to itself apart from its own streams. dsrl_bn_fused_max_blocks: 0 = never use them, 128 = the 128-block variant only (what
@@ -232,7 +241,7 @@ int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, const float* d
  * no reduction pass, no device-wide barrier (C a multiple of 32). */
 int dsrl_bn_bwd_from_stats(const float* x, int ldx, const float* y /*nullable*/, int ldy, const float* dy, int lddy, float* dx, int lddx,
                            float* dresidual /*nullable*/, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
-                           float* dgamma /*nullable*/, float* dbeta /*nullable*/, int relu, int training, const float* stats, int stats_parts,
+                           float* dgamma /*nullable*/, float* dbeta /*nullable*/, int relu, int training, float* stats, int stats_parts,
                            uint32_t* dx_amax /*nullable*/, dsrl_stream_t stream);
 
 /* Device-resident dropout key. By default every dropout-bearing launch (dsrl_bn_apply, dsrl_bn_train_fwd*, dsrl_dropout_*) bakes its

@@ -135,6 +135,38 @@ def test_f16x3_operand_ranges(case):
         assert not host(xt.grad).any() and not host(wt.grad).any()
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 16, 24, 96, 3, 1, 1, 1), (2, 304, 16, 32, 192, 3, 1, 1, 1), (1, 256, 32, 64, 19, 1, 1, 0, 1), (4, 1024, 16, 32, 256, 1, 1, 0, 1),
+                                   (2, 128, 16, 32, 128, 3, 2, 1, 1), (2, 512, 16, 32, 256, 3, 1, 6, 6)])
+def test_f16x3_presplit_filters_match_on_the_fly(shape):
+    """Forward and data gradient with the filter operand pre-split once (dsrl_conv2d_split_filters_batched: what ddp.FlatParams does per
+    step) are BIT-identical to the same launches splitting the filter in every row tile: same scale, same two terms, same MFMA order.
+    Odd K (19: the transposed filter is padded to 20), a channel tail (304 = 9.5 chunks), stride 2 and a dilated conv included."""
+    N, C, H, W, K, R, stride, pad, dil = shape
+    rs = np.random.RandomState(sum(shape))
+    x = dev(np.maximum(rs.standard_normal((N, C, H, W)), 0).astype(np.float32))
+    w = dev((rs.standard_normal((K, C, R, R)) / np.sqrt(C * R * R)).astype(np.float32))
+    Ho, Wo = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1, (W + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    dy, lddy = HF.pm_vec4(dev(rs.standard_normal((N, K, Ho, Wo)).astype(np.float32)))
+    HF.set_conv_precision('f16x3')
+    rec, wsp, wtsp, wtr = HF.split_filter(w)
+    xa, dya = HF.amax_for(x), HF.amax_for(dy, dy, lddy)
+    shp = (N, H, W, C, K, R, R, stride, pad, dil)
+    st = HF._stream()
+    outs = []
+    for split in (False, True):
+        y = torch.empty((N, K, Ho, Wo), device=DEV).contiguous(memory_format=torch.channels_last)
+        dx = torch.empty((N, C, H, W), device=DEV).contiguous(memory_format=torch.channels_last)
+        ws = HF._ws(HF.cquery('dsrl_conv2d_dgrad_workspace_bytes', *shp) + HF.cquery('dsrl_conv2d_fwd_workspace_bytes', *shp), x)
+        HF.call('dsrl_conv2d_fwd_amax', x.data_ptr(), C, xa.data_ptr(), w.data_ptr(), rec.data_ptr(), wsp.data_ptr() if split else None, None, y.data_ptr(), K,
+                *shp, ws.data_ptr(), ws.numel(), None, 0, st)
+        HF.call('dsrl_conv2d_dgrad_amax', dy.data_ptr(), lddy, dya.data_ptr(), w.data_ptr(), wtr.data_ptr(), rec.data_ptr(), wtsp.data_ptr() if split else None,
+                dx.data_ptr(), C, *shp, ws.data_ptr(), ws.numel(), None, 0, None, 0, None, None, 0, None, 0, 0, st)
+        outs.append((host(y), host(dx)))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    yo = O.conv2d(host(x).astype(np.float64), host(w).astype(np.float64), None, stride, pad, dil)
+    check(outs[1][0], yo, 3e-6, 'y')
+
+
 def test_pointwise_strided_golden(golden):
     g = golden('ops_micro')
     x = dev(g['conv_s8.x']).requires_grad_(True); w = dev(g['conv_s8.w']).requires_grad_(True)
@@ -443,7 +475,7 @@ def test_batchnorm_frozen_statistics_backward(C):
 def test_conv_epilogue_bn_statistics(shape):
     """conv2d_bn_act: BatchNorm batch statistics from the conv epilogue (dsrl_conv2d_fwd_stats -> dsrl_bn_train_fwd_from_stats) against
     the separate conv + BN path and the oracle; ragged row counts (33x47 maps), channel tails of the last tile (96 = 64 + 32), a shape
-    with more than 256 row blocks (falls back by itself), residual + ReLU, and the backward pass through both. The last three shapes are
+    with more than 256 row blocks (reduced to 32 by bn_stats_reduce_kernel first), residual + ReLU, and the backward pass through both. The last three shapes are
     split-K launches (layer4 conv2, a dilated ASPP branch, a ragged 9x13 map): their partials come from the slab reduce (splitk_reduce_stats_kernel)."""
     N, C, H, W, K, R, stride, pad, dil = shape
     rs = np.random.RandomState(sum(shape))
@@ -957,7 +989,7 @@ def test_bn_backward_statistics_from_dgrad_epilogue(shared):
     old, orig_call, old_shared = HF.bn_bwd_stats_enabled, HF.call, HF.bn_bwd_stats_shared
 
     def counting(name, *a):
-        key = 'dsrl_conv2d_dgrad_bnstats' if (name == 'dsrl_conv2d_dgrad_amax' and a[27] is not None) else name       # a[27]: the bstats argument
+        key = 'dsrl_conv2d_dgrad_bnstats' if (name == 'dsrl_conv2d_dgrad_amax' and a[28] is not None) else name       # a[28]: the bstats argument
         counts[-1][key] = counts[-1].get(key, 0) + 1
         return orig_call(name, *a)
 

@@ -25,17 +25,28 @@ def run(N, C, H, W, K, R, stride, pad, dil, what):
     dev = 'cuda:0'
     Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1; Wo = (W + 2 * pad - dil * (R - 1) - 1) // stride + 1
     x = torch.randn(N * H * W * C, device=dev); w = torch.randn(K * R * R * C, device=dev) * 0.05
-    y = torch.empty(N * Ho * Wo * K, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
+    y = torch.randn(N * Ho * Wo * K, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
     shp = (N, H, W, C, K, R, R, stride, pad, dil)
     ws = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     gf = 2 * lib.dsrl_conv2d_inbounds_macs(*shp) / 1e9
+    # f16x3: operand magnitudes and the pre-split filter as the training step has them (left by the producers / the per-step filter pass)
+    from dualsuperreslearningforsemseg_amd import functional as HF
+    xa = ya = wa = wsp = wtsp = wtr = None
+    if HF.get_conv_precision() == 'f16x3':
+        rec, sp, tsp, tr = HF.split_filter(w.view(K, R, R, C).permute(0, 3, 1, 2))
+        xs, ys = HF.amax_slot(x.device), HF.amax_slot(x.device)
+        HF.call('dsrl_amax', x.data_ptr(), C, N * H * W, C, xs.data_ptr(), st)
+        HF.call('dsrl_amax', y.data_ptr(), K, N * Ho * Wo, K, ys.data_ptr(), st)
+        keep = (rec, sp, tsp, tr, xs, ys)
+        xa, ya, wa, wsp, wtsp, wtr = xs.data_ptr(), ys.data_ptr(), rec.data_ptr(), sp.data_ptr(), tsp.data_ptr(), tr.data_ptr()
     if what == 'fwd':
-        f = lambda: _lib.check(lib.dsrl_conv2d_fwd(x.data_ptr(), C, w.data_ptr(), None, y.data_ptr(), K, *shp, ws.data_ptr(), ws.numel(), st), 'fwd')
+        f = lambda: _lib.check(lib.dsrl_conv2d_fwd_amax(x.data_ptr(), C, xa, w.data_ptr(), wa, wsp, None, y.data_ptr(), K, *shp, ws.data_ptr(), ws.numel(), None, 0, st), 'fwd')
     elif what == 'dgrad':
-        f = lambda: _lib.check(lib.dsrl_conv2d_dgrad(y.data_ptr(), K, w.data_ptr(), None, dx.data_ptr(), C, *shp, ws.data_ptr(), ws.numel(), st), 'dgrad')
+        f = lambda: _lib.check(lib.dsrl_conv2d_dgrad_amax(y.data_ptr(), K, ya, w.data_ptr(), wtr, wa, wtsp, dx.data_ptr(), C, *shp, ws.data_ptr(), ws.numel(),
+                                                          None, 0, None, 0, None, None, 0, None, 0, 0, st), 'dgrad')
     else:
-        f = lambda: _lib.check(lib.dsrl_conv2d_wgrad(x.data_ptr(), C, y.data_ptr(), K, dw.data_ptr(), *shp, ws.data_ptr(), ws.numel(), st), 'wgrad')
+        f = lambda: _lib.check(lib.dsrl_conv2d_wgrad_amax(x.data_ptr(), C, xa, y.data_ptr(), K, ya, dw.data_ptr(), *shp, ws.data_ptr(), ws.numel(), st), 'wgrad')
     ms = t_ms(f)
     return ms, gf / ms
 
