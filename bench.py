@@ -335,6 +335,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         del host_ms[:]
+        del step.comm_events[:]
         t0 = time.perf_counter()
         last = run(nsteps)
         torch.cuda.synchronize()
@@ -347,9 +348,26 @@ def main():
             el = float(tt)
         return el, last
 
+    step.time_collectives = world > 1
     elapsed, losses = timed(args.warmup, args.steps)
     host_enqueue = sorted(host_ms)[len(host_ms) // 2] if host_ms else 0.0
     replays = step.graph_replays
+    comm = None
+    if world > 1:
+        # the collectives of the timed region, from HIP events on the compute stream (rank 0's view): the rank-0 BatchNorm-buffer broadcast in front
+        # of the replay, and the part of the gradient all-reduce that is NOT hidden behind the second backward graph (end of that graph ->
+        # all collectives complete); plus the ADVICE check that no fused BatchNorm launch gave up at its device-wide barrier beside RCCL
+        evs = list(step.comm_events)
+        step.time_collectives = False
+        comm = {'rccl_world_size': dist.get_world_size(), 'backend': dist.get_backend(),
+                'broadcast_ms_per_step': round(sum(e[0].elapsed_time(e[1]) for e in evs) / max(len(evs), 1), 4),
+                'allreduce_exposed_ms_per_step': round(sum(e[2].elapsed_time(e[3]) for e in evs) / max(len(evs), 1), 4),
+                'steps_bracketed': len(evs), 'gradient_bytes_per_step': int(flat.numel * 4),
+                'schedule': ('two hipGraphs per step: the all-reduce of the chunks complete after the first (head, ASPP, layer4) runs beside the second (layers 3..1), '
+                             'the rest behind it' if step.split else 'one hipGraph per step, one all-reduce of the whole arena behind it')}
+        stuck = HF.bn_fused_barrier_timeouts()
+        assert stuck == 0, f'{stuck} fused BatchNorm blocks timed out at their device-wide barrier while RCCL shared the device'
+        comm['bn_fused_barrier_timeouts'] = stuck
     if world > 1:
         # data-parallel invariant: after K identical-seed steps every rank must hold bit-identical parameters
         chk = torch.stack([flat.p_flat.double().sum(), flat.p_flat.double().abs().sum()])
@@ -447,6 +465,8 @@ def main():
                        'losses_last_step': [round(v, 5) for v in losses]},
             'roofline': roof, 'roofline_hbm': hbm,
         }
+        if comm is not None:
+            line['collectives'] = comm
         if weights0 is not None:
             line['cpu_baseline'] = cpu_baseline_torch(weights0, args.stage)
             if args.stage == 3:

@@ -65,7 +65,7 @@ class SyntheticCityscapes:
 
 
 class _CapturedStep:
-    __slots__ = ('graph', 'img', 'org', 'tgt', 'outs', 'vals', 'bns', 'keep')
+    __slots__ = ('graph', 'graph_b', 'ready', 'img', 'org', 'tgt', 'outs', 'vals', 'bns', 'keep')
 
 
 class TrainStep:
@@ -94,10 +94,15 @@ class TrainStep:
         self.host_enqueue_s = 0.0
         self.graph_replays = 0
         if self.use_graph and flat.world > 1:
-            # the collectives of a replayed step run behind the graph, never beside its kernels: no hook-launched all-reduce, and the
-            # fused BatchNorm kernels can have every CU (ddp.FlatParams caps them at 128 blocks for the overlapped eager path)
+            # the collectives of a replayed step are launched between / behind its graphs (no hook-launched all-reduce).  The fused BatchNorm
+            # kernels keep the 128-block budget ddp.FlatParams selected: an all-reduce of the first gradient chunks runs beside the second
+            # half of backward (split capture), and RCCL blocks hold CUs while they wait for peers - a 256-block barrier launch needs every CU
             flat.defer_collectives = True
-            HF.set_bn_fused_max_blocks(None)
+        # Two-phase backward with more than one rank (DSRL_GRAPH_SPLIT=0: off): backward stops at the layer3 / layer4 boundary, the gradient
+        # chunks complete by then (head, ASPP, layer4) are all-reduced while layers 3..1 run, the rest behind them.  One rank: one phase.
+        self.split = flat.world > 1 and flat.defer_collectives and os.environ.get('DSRL_GRAPH_SPLIT', '1') != '0'
+        self.time_collectives = False           # bench.py: bracket the exposed part of the collectives with events
+        self.comm_events = []                   # (broadcast start, end, replay-B end, collectives end) per step
 
     def losses(self, outs, input_org, target):
         SSSR, SISR, SSSR_ft, SISR_ft = outs
@@ -107,44 +112,78 @@ class TrainStep:
         return ce, ms, fa, ce + ms + fa                                                    # :438
 
     # ------------------------------------------------------------------ the iteration itself (eager, or under capture)
-    def _body(self, input_image, input_org, target, hp, do_train, in_graph=False):
+    def _phase_a(self, input_image, input_org, target, do_train, in_graph, split):
+        """Step start, forward, losses and - when training - backward: all of it, or (split) down to the layer3 / layer4 cut."""
         flat = self.flat
-        dev_mode = self.rng is not None
+        bb = None
         if do_train:
-            if dev_mode:
+            if self.rng is not None:
                 self.rng.advance()                # this step's dropout key, derived on the device
             flat.zero_grad()                                                               # optimizer.zero_grad(), :418
             if not in_graph:
                 flat.sync_buffers()
             flat.refresh_transposed_filters()     # one launch: the [C][R][S][K] filter copies every dgrad of this step reads
+            if split:
+                bb = self.model.feature_extractor['backbone']
+                bb._dsrl_cut = []
         self.flag.zero_()
-        with t.set_grad_enabled(do_train):
-            outs = self.model(input_image)                                                 # :420
-            if self.fused_losses:
-                # CE + MSE + FA, their gradients, the NaN asserts (:426-433) and the loss mix (:435-438) in one launch set
-                vals = HF.fused_losses(outs, target, input_org, self.ignore, self.w1, self.w2, self.stage, self.flag, self.fa.subsample_factor)
-                total = vals[3]
-            else:
-                HF.nan_check_(self.flag, *[o for o in outs if o.is_cuda])                  # the four NaN asserts, :426-433
-                ce, ms, fa, total = self.losses(outs, input_org, target)
-                vals = None
-            if in_graph and os.environ.get('DSRL_GRAPH_FAIL_TEST'):
-                raise RuntimeError('DSRL_GRAPH_FAIL_TEST: simulated failure in the middle of a capture')      # tests/test_rccl_gpu.py
-            if do_train:
-                total.backward()                                                           # :444 (eager: chunked RCCL all-reduce overlaps)
-                if in_graph and flat.world > 1:
-                    HF.flush_wgrad_queue()
-                    HF.join_side_streams()        # the collectives and the update follow the replay (_replay)
-                elif flat.defer_collectives and flat.world > 1:
-                    HF.flush_wgrad_queue()
-                    HF.join_side_streams()        # graph mode, iterations before the capture: the same order of events, eagerly
-                    flat.reduce_all()
-                    flat.sgd_step(hp[0], hp[1], hp[2], hyper=self.hyper if dev_mode else None, reduce=False)
+        cuts = None
+        try:
+            with t.set_grad_enabled(do_train):
+                outs = self.model(input_image)                                             # :420
+                if self.fused_losses:
+                    # CE + MSE + FA, their gradients, the NaN asserts (:426-433) and the loss mix (:435-438) in one launch set (SURVEY f2)
+                    vals = HF.fused_losses(outs, target, input_org, self.ignore, self.w1, self.w2, self.stage, self.flag, self.fa.subsample_factor)
+                    total = vals[3]
                 else:
-                    flat.sgd_step(hp[0], hp[1], hp[2], hyper=self.hyper if dev_mode else None)     # :445
-        if vals is None:
-            vals = t.cat([t.stack([ce, ms, fa, total]).detach().float(), self.flag.float()])
-        return outs, vals.detach()
+                    HF.nan_check_(self.flag, *[o for o in outs if o.is_cuda])              # the four NaN asserts, :426-433
+                    ce, ms, fa, total = self.losses(outs, input_org, target)
+                    vals = t.cat([t.stack([ce, ms, fa, total]).detach().float(), self.flag.float()])
+                if in_graph and os.environ.get('DSRL_GRAPH_FAIL_TEST'):
+                    raise RuntimeError('DSRL_GRAPH_FAIL_TEST: simulated failure in the middle of a capture')      # tests/test_rccl_gpu.py
+                if do_train:
+                    total.backward()                                                       # :444
+                    if split:
+                        cuts = bb._dsrl_cut
+                        HF.flush_wgrad_queue(reopen=True)      # the weight gradients of head, ASPP and layer4 as one grouped launch set
+                        HF.join_side_streams()
+        finally:
+            if bb is not None:
+                bb._dsrl_cut = None
+        return outs, vals.detach(), cuts
+
+    def _phase_b(self, cuts):
+        """Second backward phase: from the cut tensors through layers 3..1 and the stem, then their grouped weight gradients."""
+        pairs = [(o, d.grad) for o, d in cuts if d.grad is not None]
+        if pairs:
+            t.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+        HF.flush_wgrad_queue()
+        HF.join_side_streams()
+
+    def _finish(self, hp, in_graph):
+        """Gradient exchange (when it did not run between the phases) and the optimiser step."""
+        flat = self.flat
+        hyper = self.hyper if self.rng is not None else None
+        if flat.world > 1 and flat.defer_collectives:
+            HF.flush_wgrad_queue()
+            HF.join_side_streams()
+            if in_graph:
+                return                            # the collectives and the update follow the replay (_replay)
+            flat.reduce_rest() if self.split else flat.reduce_all()
+            flat.sgd_step(hp[0], hp[1], hp[2], hyper=hyper, reduce=False)
+        else:
+            flat.sgd_step(hp[0], hp[1], hp[2], hyper=hyper)                                # :445 (eager, world > 1: hook-launched chunk all-reduces overlap)
+
+    def _body(self, input_image, input_org, target, hp, do_train, in_graph=False):
+        """One whole iteration, eagerly (graph mode: the iterations before the capture, with the same order of events)."""
+        split = self.split and do_train
+        outs, vals, cuts = self._phase_a(input_image, input_org, target, do_train, in_graph, split)
+        if do_train:
+            if split:
+                self.flat.reduce_chunks(self.flat.ready_chunks())      # runs beside the second phase
+                self._phase_b(cuts)
+            self._finish(hp, in_graph)
+        return outs, vals
 
     def _set_hyper(self, hp):
         vals = (float(hp[0]), float(hp[1]), float(hp[2]), 1.0 / self.flat.world)
@@ -167,16 +206,37 @@ class TrainStep:
         # pays more for its cross-queue dependencies than the overlap wins (measured 24.2 vs 23.8 ms per step), so the capture is
         # linear unless DSRL_GRAPH_OVERLAP=1
         overlap_was = HF.overlap_wgrad
+        fused_was = None
         if os.environ.get('DSRL_GRAPH_OVERLAP', '0') == '0':
             HF.overlap_wgrad = False
+        else:
+            # a forked capture can place fused BatchNorm nodes on parallel branches: they share ONE device-wide barrier word pair and must
+            # never overlap each other, so that capture takes the three-kernel BatchNorm path
+            fused_was = HF.set_bn_fused_max_blocks(0)
         c.keep = HF.graph_keepalive = []          # pinned host tables the captured copies read on every replay
         HF.capture_host, HF.capture_host_off = t.empty(2 << 20, dtype=t.uint8, pin_memory=True), 0      # allocated BEFORE the capture starts
         c.keep.append(HF.capture_host)
+        c.graph_b, c.ready = None, []
+        mode = os.environ.get('DSRL_GRAPH_CAPTURE_MODE', 'thread_local')
         try:
-            with t.cuda.graph(c.graph, capture_error_mode=os.environ.get('DSRL_GRAPH_CAPTURE_MODE', 'thread_local')):
-                c.outs, c.vals = self._body(c.img, c.org, c.tgt, hp, True, in_graph=True)
+            if self.split:
+                # two graphs sharing one memory pool: [step start .. backward down to the cut + its weight gradients] and [the rest of backward];
+                # the chunks complete after the first are recorded - on replay their all-reduce is launched between the two graphs
+                with t.cuda.graph(c.graph, capture_error_mode=mode):
+                    c.outs, c.vals, cuts = self._phase_a(c.img, c.org, c.tgt, True, True, True)
+                c.ready = self.flat.ready_chunks()
+                c.graph_b = t.cuda.CUDAGraph()
+                with t.cuda.graph(c.graph_b, pool=c.graph.pool(), capture_error_mode=mode):
+                    self._phase_b(cuts)
+                del cuts
+            else:
+                with t.cuda.graph(c.graph, capture_error_mode=mode):
+                    c.outs, c.vals, _ = self._phase_a(c.img, c.org, c.tgt, True, True, False)
+                    self._finish(hp, True)
         finally:
             HF.overlap_wgrad = overlap_was
+            if fused_was is not None:
+                HF.set_bn_fused_max_blocks(fused_was)
             HF.graph_keepalive = None
             HF.capture_host = None
         # nothing ran during the capture: take back the host-side bookkeeping of that phantom iteration
@@ -218,15 +278,29 @@ class TrainStep:
         for dst, src in ((c.img, input_image), (c.org, input_org), (c.tgt, target)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        ev = [t.cuda.Event(enable_timing=True) for _ in range(4)] if (self.time_collectives and flat.world > 1) else None
         if flat.world > 1:
+            if ev:
+                ev[0].record()
             flat.sync_buffers()
+            if ev:
+                ev[1].record()
+            flat._reduced, flat._works = set(), []      # no hook fires during a replay: the chunk bookkeeping of the step starts here
         c.graph.replay()
+        if c.graph_b is not None:
+            flat.reduce_chunks(c.ready)         # head / ASPP / layer4 chunks: their all-reduce runs beside the second graph
+            c.graph_b.replay()
         HF._rng_state['step'] += 1              # host mirror of the key the device just derived
         HF._rng_state['current'] = HF._derive(HF._rng_state['step'])
         for m in c.bns:
             m._dsrl_batches += 1
         if flat.world > 1:
-            flat.reduce_all()
+            if ev:
+                ev[2].record()
+            flat.reduce_rest() if c.graph_b is not None else flat.reduce_all()
+            if ev:
+                ev[3].record()
+                self.comm_events.append(ev)
             flat.sgd_step(0.0, 0.0, 0.0, hyper=self.hyper, reduce=False)
         self.graph_replays += 1
         return c.outs, c.vals
@@ -276,6 +350,8 @@ class TrainStep:
         ev.synchronize()
         vals = [float(v) for v in host]
         self._free.append((host, ev))
+        if int(vals[4]) & 2:
+            raise AssertionError('a target label is outside [0, num_classes) and is not the ignore index (CrossEntropyLoss would assert).')
         if vals[4] != 0:
             stuck = HF.bn_fused_barrier_timeouts()
             if stuck:

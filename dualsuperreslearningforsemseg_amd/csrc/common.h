@@ -100,6 +100,10 @@ __device__ inline void amax_publish(unsigned m, unsigned* out) {
 }
 // the same measurement as a launch of its own (conv_igemm.hip)
 int launch_amax(const float* x, int ld, long long P, int C, unsigned* out, hipStream_t st);
+// Zero-fill as a KERNEL launch (conv_igemm.hip).  Not hipMemsetAsync: captured into a hipGraph that call becomes a memset node, and on
+// ROCm 7.0 / 7.2 such a node was observed to run out of order with the kernel nodes around it (the amax scratch of the stem's weight
+// gradient, zeroed AFTER the measuring kernels in ~40 % of the replays of a two-graph step: round 3) - a kernel node keeps its place.
+int launch_zero_fill(void* p, size_t bytes, hipStream_t st);
 
 // Per-channel thread mapping for pixel-major [P][ld] tensors with C channels (channel group of <= 256):
 // G = 256 / cg pixels are processed side by side, thread t < G*cg owns channel (t % cg) of pixel slot (t / cg).

@@ -907,6 +907,10 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const lon
     }
 }
 
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* __restrict__ p, long long n16, unsigned char* __restrict__ tail, int ntail) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
 // max |x| of a pixel-major [P][ld] tensor with C channels as a bit pattern, atomically maxed into the amax record `out` (the caller zeroes
 // it; common.h): the operand scale of the f16x3 kernels when the tensor's producer did not leave one.  NaN bit patterns compare above every number.
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int ld, long long P, int C, int vec, unsigned* __restrict__ out) {
@@ -1646,6 +1650,17 @@ static int prof_family(ConvPass pass) {
 // f16x3 operand scales the caller did not provide: measured into two zeroed words at `scratch` (kAmaxScratch bytes at the end of the
 // call's workspace) by one amax launch per missing operand.
 constexpr size_t kAmaxScratch = 2 * kAmaxWords * sizeof(unsigned);      // two records
+int launch_zero_fill(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return DSRL_OK;
+    if ((uintptr_t)p % 16) {                // unaligned head: byte by byte up to the boundary is not worth a kernel of its own - callers pass 16-byte aligned buffers
+        set_error("zero_fill: pointer not 16-byte aligned");
+        return DSRL_E_BADARG;
+    }
+    const long long n16 = (long long)(bytes / 16);
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(ceil_div(n16, 256 * 8), 2048));
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(256), 0, st, (uint4*)p, n16, (unsigned char*)p + n16 * 16, (int)(bytes % 16));
+    return launch_status("zero_fill_kernel");
+}
 int launch_amax(const float* x, int ld, long long P, int C, unsigned* out, hipStream_t st) {
     const int vec = (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0) ? 1 : 0;
     const long long n = vec ? P * (C / 4) : P * C;
@@ -1660,7 +1675,7 @@ static int resolve_amax(OperandAmax& am, const float* a, int lda, long long Pa, 
     if (am.a != nullptr && am.b != nullptr) return DSRL_OK;
     DSRL_REQUIRE(ws != nullptr && ws_bytes >= align_up(ws_used, 64) + kAmaxScratch, DSRL_E_WORKSPACE, "%s: the f16x3 arithmetic measures operand magnitudes the caller did not pass in %zu bytes behind the first %zu of the workspace (got %zu)", who, kAmaxScratch, ws_used, ws_bytes);
     unsigned* scratch = (unsigned*)((char*)ws + align_up(ws_used, 64));
-    if (hipMemsetAsync(scratch, 0, kAmaxScratch, st) != hipSuccess) return launch_status("hipMemsetAsync(amax scratch)");
+    if (int e = launch_zero_fill(scratch, kAmaxScratch, st)) return e;
     if (am.a == nullptr) { if (int e = launch_amax(a, lda, Pa, Ca, scratch, st)) return e; am.a = scratch; }
     if (am.b == nullptr) { if (int e = launch_amax(b, ldb, Pb, Cb, scratch + kAmaxWords, st)) return e; am.b = scratch + kAmaxWords; }
     return DSRL_OK;
@@ -2132,7 +2147,7 @@ static int wgrad_impl(const float* x, int ldx, const float* dy, int lddy, float*
     DSRL_REQUIRE(ws_bytes >= p.ws && (p.ws == 0 || ws), DSRL_E_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, p.ws);
     const int RS = R * S;
     if (p.tl.n < RS) {      // taps that only ever see zero padding have a zero gradient
-        if (hipMemsetAsync(dw, 0, (size_t)K * RS * C * sizeof(float), st) != hipSuccess) return launch_status("hipMemsetAsync(dw)");
+        if (int e = launch_zero_fill(dw, (size_t)K * RS * C * sizeof(float), st)) return e;
     }
     if (p.tl.n == 0) return DSRL_OK;
     WgradArgs a{};
@@ -2370,7 +2385,7 @@ extern "C" int dsrl_conv2d_wgrad_group_launch(const void* host_table, const void
     for (int i = 0; i < h->n; ++i) {        // taps that only ever see zero padding have a zero gradient
         const WgradArgs& a = hargs[i];
         if (a.ntaps < a.R * a.S)
-            if (hipMemsetAsync(a.dw_final, 0, (size_t)a.K * a.R * a.S * a.C * sizeof(float), st) != hipSuccess) return launch_status("hipMemsetAsync(dw)");
+            if (int e = launch_zero_fill(a.dw_final, (size_t)a.K * a.R * a.S * a.C * sizeof(float), st)) return e;
     }
     const int npl = h->npl;
     for (int l = 0; l < h->nlaunch; ++l) {

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const float* __restrict__
     __syncthreads();
     const float scale = sh_scale;
     double loss = 0.0, cnt = 0.0;
-    bool bad = false;
+    bool bad = false, bad_label = false;
     for (long long p0 = (long long)blockIdx.x * 256; p0 < P; p0 += (long long)gridDim.x * 256) {
         const int np = (int)min(256ll, P - p0);
         const int nf = np * C;
@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const float* __restrict__
         __syncthreads();
         if ((int)threadIdx.x < np) {
             const int tg = target[p0 + threadIdx.x];
+            bad_label |= tg != ignore_index && tg >= C;         // torch's CrossEntropyLoss asserts on such a target: here it poisons the loss and raises flag bit 1
             float* v = tile + threadIdx.x * C;
             float m = v[0];
             for (int c = 1; c < C; ++c) m = fmaxf(m, v[c]);
@@ -173,10 +174,12 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const float* __restrict__
             }
         }
     }
+    if (bad_label) loss = __builtin_nan("");
     const double l = block_sum_d(loss, shd);
     const double n = block_sum_d(cnt, shd);
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = l; part[2 * blockIdx.x + 1] = n; }
     if (nan_flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
+    if (nan_flag && __any(bad_label) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 2);
 }
 // MSE forward and backward in one pass: partial sums of (a-b)^2 and da = (a-b) * 2 * grad_scale / n; NaN check of `a`
 __global__ __launch_bounds__(256) void mse_fused_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float sc, float* __restrict__ da,

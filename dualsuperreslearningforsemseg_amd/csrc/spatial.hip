@@ -904,7 +904,7 @@ extern "C" int dsrl_pointwise_strided_bwd(const float* x, const float* w, const 
     DSRL_REQUIRE(ws_bytes >= dsrl_pointwise_strided_bwd_workspace_bytes(N, H, W, C, stride), DSRL_E_WORKSPACE, "pointwise_strided_bwd: workspace too small");
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     if (!accumulate) {
-        if (hipMemsetAsync(dx, 0, (size_t)N * H * W * C * sizeof(float), st) != hipSuccess) return launch_status("hipMemsetAsync(dx)");
+        if (int e = launch_zero_fill(dx, (size_t)N * H * W * C * sizeof(float), st)) return e;
     }
     const int nb = pointwise_blocks(N, H, W, stride);
     hipLaunchKernelGGL(pointwise_bwd_kernel, dim3(nb), dim3(256), 256 * sizeof(float), st, x, w, dy, dx, (float*)ws, accumulate, N, H, W, C, stride, Ho, Wo);

@@ -84,6 +84,7 @@ class FlatParams:
                 start, count = end, 0
         self._pending = [c[2] for c in self.chunks]
         self._works = []
+        self._reduced = set()
         self._hooks = []
         self.defer_collectives = False      # set while a step is captured into a hipGraph: reduce_all() runs the collectives after the replay
         # gradient sink: kernels may write a parameter's gradient straight into its arena slot (functional._sink)
@@ -105,6 +106,12 @@ class FlatParams:
     # ------------------------------------------------------------------ gradient reduction
     def _make_hook(self, i):
         def hook(_param):
+            # torch runs the post-accumulate hook of a parameter even when its backward returned no gradient, i.e. also for a parameter
+            # whose kernel writes straight into the arena (claim): that gradient is complete when the kernel has been ENQUEUED - for a
+            # deferred weight gradient at the flush of the queue, long after this hook - and is reported by written() alone.  (Counting both
+            # made a chunk look complete after half of its notifications: found by the two-phase reduction, round 3.)
+            if i in self._claimed:
+                return
             self._on_grad_ready(i)
         return hook
 
@@ -216,8 +223,16 @@ class FlatParams:
         self._claimed.clear()
         self._pending = [c[2] for c in self.chunks]
         self._works = []
+        self._reduced = set()
         if self.device.type == 'cuda':
-            HF.open_wgrad_queue()           # the convs of this step defer their weight gradients (functional.WgradQueue)
+            # The convs of this step defer their weight gradients to grouped launches at the end of backward (functional.WgradQueue) - unless the
+            # chunk all-reduces are launched from gradient-ready notifications DURING backward (world > 1, eager): a deferred weight gradient
+            # would report ready only at the flush and every collective would start behind backward; that path keeps the per-layer
+            # side-stream launches, which also free x / dy layer by layer.
+            if self.world == 1 or self.defer_collectives:
+                HF.open_wgrad_queue()
+            else:
+                HF.wgrad_queue = None
             if HF.f16_mode():
                 HF.amax_begin_step(self.device)     # operand-magnitude slots of this step (functional.amax_slot)
 
@@ -237,6 +252,40 @@ class FlatParams:
         for w in self._works:
             w.wait()
         self._works = []
+
+    # ------------------------------------------------------------------ two-phase reduction (split hipGraph capture, world > 1)
+    def _ranges(self, idx):
+        """chunk indices -> merged (start, end) element ranges: neighbouring chunks travel as one collective (larger messages)"""
+        out = []
+        for ci in sorted(idx):
+            a, b, _ = self.chunks[ci]
+            if out and out[-1][1] == a:
+                out[-1][1] = b
+            else:
+                out.append([a, b])
+        return out
+
+    def ready_chunks(self):
+        """Chunks whose every gradient has been produced so far in this backward pass and that have not been reduced yet."""
+        return [ci for ci, left in enumerate(self._pending) if left == 0 and ci not in self._reduced]
+
+    def reduce_chunks(self, idx):
+        """Launches (asynchronously, behind what the current stream holds) the all-reduce of the given chunks; reduce_rest() waits."""
+        if self.world == 1:
+            return
+        for a, b in self._ranges(idx):
+            self._works.append(dist.all_reduce(self.g_flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self._reduced.update(idx)
+
+    def reduce_rest(self):
+        """All chunks not reduced yet, then the current stream waits for every collective of the step."""
+        if self.world == 1:
+            return
+        self.reduce_chunks([ci for ci in range(len(self.chunks)) if ci not in self._reduced])
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self._pending = [0] * len(self.chunks)
 
     def reduce_all(self):
         """All chunk all-reduces of the gradient arena at once, behind whatever the current stream holds (the replay of a captured

@@ -217,12 +217,15 @@ def open_wgrad_queue():
     return wgrad_queue
 
 
-def flush_wgrad_queue():
-    """Launches what the open queue holds and closes it: only a step that opened a queue (FlatParams.zero_grad) defers."""
+def flush_wgrad_queue(reopen=False):
+    """Launches what the open queue holds and closes it: only a step that opened a queue (FlatParams.zero_grad) defers.  `reopen`: a new
+    queue takes the weight gradients of the rest of the backward pass (two-phase backward: one grouped launch set per phase)."""
     global wgrad_queue
     q, wgrad_queue = wgrad_queue, None
     if q is not None:
         q.flush()
+        if reopen:
+            wgrad_queue = WgradQueue()
 
 
 def _need_gpu(*ts):
@@ -351,6 +354,22 @@ def _sink(param, like_shape=None):
     return param.grad
 
 
+def _deliver(param, grad):
+    """Hands a freshly computed parameter gradient to the arena instead of to autograd: when `param` lives in a ddp.FlatParams arena and this
+    is its first gradient of the pass, the values are copied into its (zeroed) arena slot on the CURRENT stream, the reducer is told, and
+    autograd gets nothing.  Besides saving autograd's own accumulation launch this keeps leaf accumulation off other streams: torch runs an
+    AccumulateGrad node on the stream its parameter was created on, which under graph capture forks the capture across streams (the warning
+    'AccumulateGrad node's stream does not match ...') - with every parameter gradient delivered here the captured step is one linear stream."""
+    if grad is None or not isinstance(param, torch.nn.Parameter):
+        return grad
+    owner = getattr(param, '_dsrl_arena', None)
+    if owner is None or not grad.is_cuda or tuple(grad.shape) != tuple(param.shape) or not owner.claim(param):
+        return grad
+    param.grad.copy_(grad)
+    owner.written(param)
+    return None
+
+
 def _weight_amax(w):
     """Magnitude slot of a conv filter that ddp.FlatParams keeps (measured by the batched filter transpose of this step), or None."""
     arena, slot = getattr(w, '_dsrl_arena', None), getattr(w, '_dsrl_wamax', None)
@@ -414,8 +433,12 @@ def peek_next_seed():
     return _derive(_rng_state['step'] + 1)
 
 
-def begin_forward():
-    """Called once per model forward: all Dropout modules of that pass share one key and differ by stream id."""
+def begin_forward(training=True):
+    """Called once per model forward: all Dropout modules of that pass share one key and differ by stream id.  An evaluation pass draws
+    no mask: while a DeviceRng is bound (the device derives the key per TRAINING step) it must not advance the host mirror either, or the
+    two would drift apart by one step per validation batch."""
+    if not training and DeviceRng._active:
+        return _rng_state['current']
     _rng_state['step'] += 1
     _rng_state['current'] = _derive(_rng_state['step'])
     return _rng_state['current']
@@ -515,6 +538,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.shp = shp
         ctx.has_bias = bias is not None
+        ctx.bparam = bias if isinstance(bias, torch.nn.Parameter) else None
         ctx.wparam = w_param if isinstance(w_param, torch.nn.Parameter) else None
         ctx.wt = None
         if pretranspose_filters and ctx.needs_input_grad[0]:
@@ -623,6 +647,9 @@ class _Conv2d(torch.autograd.Function):
             db = torch.empty(K, device=x.device, dtype=torch.float32)
             ws = _ws(cquery('dsrl_colsum_workspace_bytes', P, K), x)
             call('dsrl_colsum', dy.data_ptr(), lddy, P, K, db.data_ptr(), ws.data_ptr(), ws.numel(), st)
+            db = _deliver(ctx.bparam, db)
+        if dw is not None:
+            dw = _deliver(ctx.wparam, dw)
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -654,6 +681,7 @@ class _StemConv(torch.autograd.Function):
         call('dsrl_conv2d_rowfold_fwd', xp.data_ptr(), 4, w2.data_ptr(), None, y.data_ptr(), K, *shp, macs, ws.data_ptr(), ws.numel(), st)
         ctx.save_for_backward(xp)
         ctx.cfg = (shp, macs, tuple(w.shape), Sp)
+        ctx.wparam = w if isinstance(w, torch.nn.Parameter) else None
         return y
 
     @staticmethod
@@ -667,7 +695,7 @@ class _StemConv(torch.autograd.Function):
         dw2 = torch.empty((K, R, Sp, 4), device=dy.device, dtype=torch.float32)
         ws = _ws(cquery('dsrl_conv2d_rowfold_wgrad_workspace_bytes', *shp), dy)
         call('dsrl_conv2d_rowfold_wgrad', xp.data_ptr(), 4, dy.data_ptr(), lddy, dw2.data_ptr(), *shp, macs, ws.data_ptr(), ws.numel(), _stream())
-        dw = dw2[:, :, :S, :Cc].permute(0, 3, 1, 2)
+        dw = _deliver(ctx.wparam, dw2[:, :, :S, :Cc].permute(0, 3, 1, 2))
         return None, dw, None, None
 
 
@@ -950,6 +978,7 @@ class _ConvT2x2(torch.autograd.Function):
     def forward(ctx, x, w, bias):
         x = pm_dense(x)
         _need_gpu(w, bias)
+        w_param = w
         w = w.contiguous()
         N, Ci, H, W = x.shape
         Co = w.shape[1]
@@ -959,6 +988,7 @@ class _ConvT2x2(torch.autograd.Function):
         call('dsrl_convt2x2_fwd', x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), N, H, W, Ci, Co, _stream())
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.params = (w_param if isinstance(w_param, torch.nn.Parameter) else None, bias if isinstance(bias, torch.nn.Parameter) else None)
         return y
 
     @staticmethod
@@ -973,7 +1003,7 @@ class _ConvT2x2(torch.autograd.Function):
         ws = _ws(cquery('dsrl_convt2x2_bwd_workspace_bytes', N, H, W, Ci, Co), x)
         call('dsrl_convt2x2_bwd', x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(),
              N, H, W, Ci, Co, ws.data_ptr(), ws.numel(), _stream())
-        return dx, dw, db
+        return dx, _deliver(ctx.params[0], dw), _deliver(ctx.params[1], db)
 
 
 def conv_transpose2d_k2s2(x, weight, bias=None):
@@ -1022,6 +1052,7 @@ class _PointwiseStrided(torch.autograd.Function):
         ctx.save_for_backward(x, wf)
         ctx.stride = stride
         ctx.wshape = tuple(w.shape)
+        ctx.wparam = w if isinstance(w, torch.nn.Parameter) else None
         return y
 
     @staticmethod
@@ -1042,7 +1073,7 @@ class _PointwiseStrided(torch.autograd.Function):
              N, H, W, Cc, ctx.stride, ws.data_ptr(), ws.numel(), _stream())
         if slot is not None and not acc:
             slot.closed = True
-        return (None if acc else dx), dw.view(ctx.wshape), None, None
+        return (None if acc else dx), _deliver(ctx.wparam, dw.view(ctx.wshape)), None, None
 
 
 def pointwise_strided(x, weight, stride, out_slot=None):

@@ -121,6 +121,6 @@ class DSRL(BaseModel):
 
     def forward(self, x: t.Tensor):
         with t.autograd.profiler.record_function(DSRL.forward.__qualname__):                  # DSRL.py:159
-            HF.begin_forward()
+            HF.begin_forward(self.training)
             backbone_features, lowlevel_features = self.feature_extractor['backbone'](x)      # DSRL.py:161
             return self.forward_head(backbone_features, lowlevel_features)

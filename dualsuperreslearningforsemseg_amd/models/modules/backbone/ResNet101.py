@@ -63,6 +63,15 @@ class Bottleneck(t.nn.Module):
         return out
 
 
+def _cut(x, cut):
+    d = x.detach().requires_grad_(True)
+    a = getattr(x, '_dsrl_amax', None)
+    if a is not None:
+        d._dsrl_amax = a                # same values: the detached leaf keeps the operand-magnitude record of the tensor (functional.amax_for)
+    cut.append((x, d))
+    return d
+
+
 class ResNet101(t.nn.Module):
     PRETRAINED_WEIGHTS_URL = "https://download.pytorch.org/models/resnet101-5d3b4d8f.pth"
     PRETRAINED_WEIGHTS_FILE = 'resnet101_pretrained.pth'
@@ -137,5 +146,12 @@ class ResNet101(t.nn.Module):
         low_level_features = x                                            # ResNet101.py:98
         x = self.layer2(x)
         x = self.layer3(x)
+        # Two-phase backward (command_handlers/train_or_resume.TrainStep with more than one rank): `_dsrl_cut` is a list the training step
+        # hangs on this module; the two tensors that leave layers 1-3 are handed on as detached leaves and recorded, so that
+        # total.backward() stops there (head, ASPP and layer4: the first ~54 % of the gradient arena in backward order, whose all-reduce
+        # then runs beside the second phase) and torch.autograd.backward(originals, leaf gradients) finishes layers 3..1 and the stem.
+        cut = getattr(self, '_dsrl_cut', None)
+        if cut is not None and t.is_grad_enabled() and x.requires_grad:
+            x, low_level_features = _cut(x, cut), _cut(low_level_features, cut)
         x = self.layer4(x)
         return x, low_level_features

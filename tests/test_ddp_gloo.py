@@ -54,6 +54,33 @@ def _worker(rank, world, port, q):
         flat.reduce_all()
         flat.defer_collectives = False
         assert torch.allclose(flat.g_flat, hooked, rtol=1e-6, atol=1e-7)
+        # two-phase form (TrainStep's split capture): backward down to a detached cut, the chunks complete by then are all-reduced while the
+        # rest of backward runs, the others behind it - same sums; and the chunk bookkeeping ends at exactly zero outstanding notifications
+        flat.defer_collectives = True
+        flat.zero_grad()
+        h = model[1](model[0](xs[rank]))
+        hd = h.detach().requires_grad_(True)
+        model[3](model[2](hd)).square().mean().backward()
+        ready = flat.ready_chunks()
+        assert ready and len(ready) < len(flat.chunks), (ready, flat._pending)      # the last conv's chunks, not the first conv's
+        flat.reduce_chunks(ready)
+        torch.autograd.backward([h], [hd.grad])
+        assert flat._pending == [0] * len(flat.chunks), flat._pending
+        flat.reduce_rest()
+        flat.defer_collectives = False
+        assert torch.allclose(flat.g_flat, hooked, rtol=1e-6, atol=1e-7)
+        # a parameter whose kernel writes its gradient straight into the arena (claim) is reported by written() only: torch runs its
+        # post-accumulate hook as well, which must not count (it did until round 3: a chunk looked complete after half of its notifications)
+        flat.zero_grad()
+        p0 = flat.params[0]
+        assert flat.claim(p0) and not flat.claim(p0)
+        before = list(flat._pending)
+        flat._make_hook(0)(p0)
+        assert flat._pending == before
+        flat.defer_collectives = True
+        flat.written(p0)
+        flat.defer_collectives = False
+        assert flat._pending[flat._chunk_of[0]] == before[flat._chunk_of[0]] - 1
         # buffers travel from rank 0
         model[1].running_mean.fill_(float(rank + 1))
         flat.sync_buffers()

@@ -822,6 +822,12 @@ def test_fused_losses_nan_flag_and_eval_mode():
         with torch.no_grad():
             v = HF.fused_losses((bad[0], bad[1], ft1, ft2), tgt, org, 255, 0.1, 1.0, 3, flag, 8)
         assert int(flag) == 1 and float(v[4]) == 1.0, which
+    # a label outside [0, 19) that is not the ignore index: torch's CrossEntropyLoss asserts; here flag bit 1 and a NaN loss (TrainStep.collect raises)
+    flag.zero_()
+    tb = tgt.clone(); tb[1, 3, 5] = 200
+    with torch.no_grad():
+        v = HF.fused_losses((sssr, sisr, ft1, ft2), tb, org, 255, 0.1, 1.0, 3, flag, 8)
+    assert int(flag) == 2 and np.isnan(float(v[0])) and np.isnan(float(v[3]))
 
 
 def test_train_steps_golden(golden):

@@ -50,9 +50,18 @@ def _make(world_claim, graph, lr):
 def test_rccl_reduction_paths_match_half_lr_single_process():
     import torch.distributed as dist
     from dualsuperreslearningforsemseg_amd import ddp, functional as HF
-    plain, flat0, step0 = _make(1, False, 0.003)
-    p_plain = flat0.p_flat.clone()
-    step0.release()
+    # two single-process references at half the learning rate: with the grouped weight-gradient launches (what the graph paths run) and with
+    # the per-layer side-stream launches (what the eager N > 1 path runs, so that its chunk all-reduces start during backward: ddp.FlatParams.zero_grad)
+    plains = {}
+    for grouped in (True, False):
+        was = HF.group_wgrad
+        HF.group_wgrad = grouped
+        try:
+            hist0, flat0, step0 = _make(1, False, 0.003)
+        finally:
+            HF.group_wgrad = was
+        plains[grouped] = (hist0, flat0.p_flat.clone())
+        step0.release()
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=torch.device(DEV))
     calls = {'all_reduce': 0, 'broadcast': 0}
@@ -66,26 +75,39 @@ def test_rccl_reduction_paths_match_half_lr_single_process():
         calls['broadcast'] += 1
         return real_bc(*a, **k)
     ddp.dist.all_reduce, ddp.dist.broadcast = counted_ar, counted_bc
+    import os
+    finals = {}
     try:
-        for graph in (False, True):
+        for graph, split in ((False, '1'), (True, '1'), (True, '0')):
+            os.environ['DSRL_GRAPH_SPLIT'] = split
             calls['all_reduce'] = calls['broadcast'] = 0
             hist, flat, step = _make(2, graph, 0.006)
             assert HF.bn_fused_barrier_timeouts() == 0
             # every step reduces the whole gradient arena exactly once - chunk by chunk from the gradient-ready notifications in the eager
-            # path, as one large collective behind the replay in the graph path - and broadcasts the BN buffers once (+2 at construction)
-            assert calls['all_reduce'] == STEPS * (1 if graph else len(flat.chunks)), (calls, len(flat.chunks))
+            # path; in the graph path as TWO collectives: the chunks complete at the layer3 / layer4 cut between the two graphs of a step
+            # (beside the second one), the rest behind it - and broadcasts the BN buffers once (+2 at construction)
+            assert calls['all_reduce'] == STEPS * ((2 if split == '1' else 1) if graph else len(flat.chunks)), (calls, len(flat.chunks))
+            finals[(graph, split)] = flat.p_flat.clone()
+            if graph and split == '1':
+                c = next(iter(step._graphs.values()))
+                done = sum(flat.chunks[ci][1] - flat.chunks[ci][0] for ci in c.ready)
+                assert step.split and c.graph_b is not None and 0.3 < done / flat.numel < 0.7, (c.ready, done / flat.numel)
             assert calls['broadcast'] == STEPS + 2, calls
             if graph:
                 assert step.graph_replays == STEPS - step.GRAPH_WARMUP and flat.defer_collectives
             else:
                 assert step.graph_replays == 0 and not flat.defer_collectives
+            plain, p_plain = plains[graph]
             worst = max(abs(a - b) / max(abs(a), 1e-6) for u, v in zip(plain, hist) for a, b in zip(u, v))
             assert worst < 1e-5, (graph, worst, plain[-1], hist[-1])
             assert np.isfinite(hist[-1]).all()
             rel = float((flat.p_flat - p_plain).norm() / p_plain.norm())
             assert rel < 1e-6, (graph, rel)
             step.release()
+        # the two-graph step (collectives between and behind the graphs) and the one-graph step (one collective behind it) are the same arithmetic
+        assert torch.equal(finals[(True, '1')], finals[(True, '0')])
     finally:
+        os.environ.pop('DSRL_GRAPH_SPLIT', None)
         ddp.dist.all_reduce, ddp.dist.broadcast = real_ar, real_bc
         HF.set_bn_fused_max_blocks(None)
         dist.destroy_process_group()
