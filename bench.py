@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument('--stage', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-kernel roofline passes and the per-arithmetic runs')
+    ap.add_argument('--no-config5', action='store_true', help="skip the bounded BASELINE config-5 run (512x1024 -> 1024x2048, 8 steps) of the default line")
     return ap.parse_args()
 
 
@@ -88,7 +89,7 @@ def host_cores():
     except Exception:
         pass
     if n > 32 and not os.environ.get('DSRL_CPU_BASELINE_THREADS'):
-        n = 16          # no quota visible on a many-core host: the documented CPU share of a one-GPU box
+        n = 16          # no quota visible on a many-core host: the documented CPU share of a one-GPU box (both CPU legs are LIMITED to this count)
     return int(os.environ.get('DSRL_CPU_BASELINE_THREADS', n))
 
 
@@ -97,11 +98,11 @@ def cpu_baseline_torch(state_dict, stage, batch=2, height=256, width=512):
     runs (utils.py:259-260).  One warm-up + one timed step of B=2 at 256x512 (bounded: ~10 s on 8 cores, less on a GPU box's host)."""
     from oracle.torch_cpu_model import time_train_step
     cores = host_cores()
-    ips, threads, dt, n = time_train_step(state_dict, batch, height, width, stage, threads=cores, repeats=1, budget_s=12.0)
-    return {'value': round(ips, 4), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'impl': 'torch-cpu',
-            'sample': f'stock torch.nn CPU modules (same layer graph and weights; ATen/oneDNN kernels, {threads} threads), whole stage-{stage} step: '
-                      f'forward, CE/MSE/FA, backward, torch.optim.SGD; B={batch} at {height}x{width}->{2 * height}x{2 * width}; best of {n} timed step(s) '
-                      f'after one warm-up = {dt:.2f} s'}
+    ips, threads, dt, n, med = time_train_step(state_dict, batch, height, width, stage, threads=cores, repeats=4, budget_s=12.0)
+    return {'value': round(ips, 4), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'impl': 'torch-cpu', 'median_value': round(batch / med, 4), 'steps_timed': n,
+            'sample': f'stock torch.nn CPU modules (same layer graph and weights; ATen/oneDNN kernels, limited to {threads} threads = cores), whole stage-{stage} step: '
+                      f'forward, CE/MSE/FA, backward, torch.optim.SGD; B={batch} at {height}x{width}->{2 * height}x{2 * width}; {n} timed step(s) within a 12 s '
+                      f'budget after one warm-up: best {dt:.2f} s (value), median {med:.2f} s'}
 
 
 def cpu_baseline_numpy(state_dict, batch=1, height=256, width=512):
@@ -113,17 +114,21 @@ def cpu_baseline_numpy(state_dict, batch=1, height=256, width=512):
     x = rs.standard_normal((batch, 3, height, width)).astype(np.float32)
     org = rs.standard_normal((batch, 3, 2 * height, 2 * width)).astype(np.float32)
     tg = rs.randint(0, 19, (batch, 2 * height, 2 * width)).astype(np.uint8); tg[rs.uniform(size=tg.shape) < 0.1] = 255
-    t0 = time.time()
-    out = O.model_forward(sd, x, 3, batch > 1)          # B=1: BatchNorm in eval mode (the global-pool BN needs B >= 2 to train, ASPP.py:39-40)
-    O.total_loss(out, tg, org, 3)
-    dt = time.time() - t0
     cores = host_cores()
-    try:                                        # threads the BLAS behind numpy actually uses
-        from threadpoolctl import threadpool_info
-        blas = [i.get('num_threads') for i in threadpool_info() if i.get('user_api') == 'blas']
+
+    def one_pass():
+        t0 = time.time()
+        out = O.model_forward(sd, x, 3, batch > 1)          # B=1: BatchNorm in eval mode (the global-pool BN needs B >= 2 to train, ASPP.py:39-40)
+        O.total_loss(out, tg, org, 3)
+        return time.time() - t0
+    try:                                        # the BLAS behind numpy limited to the same core count as the torch leg; `cores` = what it then uses
+        from threadpoolctl import threadpool_info, threadpool_limits
+        with threadpool_limits(limits=cores, user_api='blas'):
+            dt = one_pass()
+            blas = [i.get('num_threads') for i in threadpool_info() if i.get('user_api') == 'blas']
         cores = max(blas) if blas else cores
-    except Exception:
-        pass
+    except ImportError:
+        dt = one_pass()
     return {'value': round(batch / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port', 'impl': 'numpy oracle',
             'sample': f'numpy oracle (fp32, multi-threaded BLAS), ResNet-101 + head forward, CE/MSE/FA, full backward, no optimizer update; '
                       f'B={batch} at {height}x{width}; one pass = {dt:.1f} s'}
@@ -314,12 +319,13 @@ def main():
     weights0 = None if (args.no_cpu_baseline or world > 1) else {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
     host_ms = []
+    batch_now = [img, org, tgt]             # the batch run() trains on (the config-5 figure swaps in a 512x1024 one)
 
     def run(n):
         # train_or_resume()'s loop: iteration k's loss/NaN readback is collected after iteration k+1 has been enqueued
         last = None
         for _ in range(n):
-            step.enqueue(img, org, tgt, hp['lr'], hp['momentum'], hp['weight_decay'], True)
+            step.enqueue(batch_now[0], batch_now[1], batch_now[2], hp['lr'], hp['momentum'], hp['weight_decay'], True)
             host_ms.append(step.host_enqueue_s * 1e3)
             while step.pending() > 1:
                 last = step.collect()
@@ -389,6 +395,24 @@ def main():
             by_arith[mode] = round(gb * args.steps / el, 1)
         HF.set_conv_precision(None)
 
+    # BASELINE config 5's size (512x1024 -> 1024x2048, per-GPU batch 8) as a bounded extra of the default line: 4 untimed + 8 timed steps
+    config5 = None
+    if not args.no_config5 and world == 1 and (args.stage, args.height, args.width, args.batch) == (3, 256, 512, 8):
+        (img5, org5), (tgt5, _) = next(iter(SyntheticCityscapes(args.batch, (512, 1024), dev, rank=rank, length=1)))
+        batch_now[:] = [img5, org5, tgt5]
+        config5 = {'workload': 'the same stage-3 step at 512x1024 input -> 1024x2048 logits, per-GPU batch 8 (BASELINE.json configs[4] on one GPU), 4 untimed + 8 timed steps',
+                   'steps': 8, 'images_per_s_by_conv_arithmetic': {}}
+        for mode in (default_mode, 'bf16x3'):           # bf16x3: the reduced-precision ('O2') arithmetic that configuration names
+            HF.set_conv_precision(mode)
+            el5, l5 = timed(4, 8)
+            config5['images_per_s_by_conv_arithmetic'][mode] = round(args.batch * 8 / el5, 1)
+            if mode == default_mode:
+                config5.update(value=round(args.batch * 8 / el5, 2), unit='images/s', ms_per_step=round(1e3 * el5 / 8, 2), losses_last_step=[round(v, 5) for v in l5])
+        HF.set_conv_precision(None)
+        batch_now[:] = [img, org, tgt]
+        del img5, org5, tgt5
+        run(3); torch.cuda.synchronize()            # back on the headline shape (its graph is still cached) before the per-kernel passes
+
     def read_prof(nsteps, stride=1):
         fams = []
         for fam in range(12):                # family = 3 * arithmetic + pass (include/dsrl_hip.h)
@@ -428,14 +452,19 @@ def main():
                             'launch stream, weight-gradient side stream disabled (exclusive kernel execution)')
         step.use_graph, HF.overlap_wgrad = graph_was, overlap_was
         try:        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (not collectable in-process)
-            for fn in ('round2_pmc_traffic.json', 'round1_pmc_traffic.json'):
+            import hashlib
+            src_now = hashlib.sha256(open(os.path.join(ROOT, 'dualsuperreslearningforsemseg_amd', 'csrc', 'conv_igemm.hip'), 'rb').read()).hexdigest()[:16]
+            for fn in ('round3_pmc_traffic.json', 'round2_pmc_traffic.json', 'round1_pmc_traffic.json'):
                 path = os.path.join(ROOT, 'profiles', fn)
                 if not os.path.isfile(path):
                     continue
                 pmc = json.load(open(path))
                 if (args.stage, args.height, args.width, args.batch) == (3, 256, 512, 8) and roof.get('kernel') in pmc:
                     roof['traffic'] = pmc[roof['kernel']]['hbm_bytes_per_launch']
-                    roof['traffic_source'] = f'profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950)'
+                    stamp = pmc.get('_stamp', {})
+                    roof['traffic_source'] = (f'profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950), taken at commit '
+                                              f"{stamp.get('commit', 'unknown')} with conv_igemm.hip sha256 {stamp.get('conv_igemm_sha16', 'unknown')}")
+                    roof['traffic_kernel_source_unchanged'] = stamp.get('conv_igemm_sha16') == src_now      # false: the kernels changed since that profile
                     break
         except Exception:
             pass
@@ -467,6 +496,8 @@ def main():
         }
         if comm is not None:
             line['collectives'] = comm
+        if config5 is not None:
+            line['config5'] = config5
         if weights0 is not None:
             line['cpu_baseline'] = cpu_baseline_torch(weights0, args.stage)
             if args.stage == 3:

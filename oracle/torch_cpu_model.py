@@ -144,7 +144,7 @@ def total_loss(outs, target, input_org, stage=3, w1=0.1, w2=1.0, ignore_index=25
 
 def time_train_step(state_dict, batch=2, height=256, width=512, stage=3, threads=None, repeats=1, budget_s=12.0):
     """One warm-up + up to `repeats` timed stage-`stage` training steps (forward, losses, backward, SGD) of the stock-torch CPU
-    graph with the given weights; returns (images/s of the best step, threads, seconds of that step, steps timed).  The warm-up
+    graph with the given weights; returns (images/s of the best step, threads, seconds of that step, steps timed, median seconds).  The warm-up
     is skipped (and the first step reported) when it alone exceeds the budget."""
     if threads:
         torch.set_num_threads(int(threads))
@@ -168,4 +168,4 @@ def time_train_step(state_dict, batch=2, height=256, width=512, stage=3, threads
             break
     timed = times[1:] if len(times) > 1 else times
     best = min(timed)
-    return batch / best, torch.get_num_threads(), best, len(timed)
+    return batch / best, torch.get_num_threads(), best, len(timed), sorted(timed)[len(timed) // 2]

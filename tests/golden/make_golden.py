@@ -315,6 +315,52 @@ def golden_head_256x512():
     print('head_256x512.npz', out['losses'], out['margin_q'])
 
 
+def golden_head_train_256x512():
+    """BASELINE's actual workload shape in TRAIN mode (round 3): 256x512 input -> 512x1024 logits, B=2, BatchNorm batch statistics over
+    16x32 / 64x128 feature maps, Dropout modules in eval (set_mode), stage 3: the loss tuple, a strided logits / SISR sample, and for EVERY
+    head parameter and both backbone-feature inputs the gradient of Total = CE + 0.1 MSE + FA (small tensors whole, large ones as a
+    strided 4096-sample plus the order-independent checksum)."""
+    out = {}
+    head, outs, L, grads = run_head(gen.FULL, 3, 909, 1010, 2, 16, 32, True, True)
+    out['losses'] = np.array([float(x.detach()) for x in L], dtype=np.float64)
+    out['SSSR_sample'] = gen.strided_sample(np_(outs[0]), 1 << 16)
+    out['SISR_sample'] = gen.strided_sample(np_(outs[1]), 1 << 14)
+    out['SSSR_ft'] = np_(outs[2]); out['SISR_ft'] = np_(outs[3])
+    for k, g in grads.items():
+        if g.size <= 8192:
+            out[f'grad.{k}'] = g
+        else:
+            out[f'gradsample.{k}'] = gen.strided_sample(g, 4096)
+            out[f'gradsum.{k}'] = gen.checksum(g)
+    # The SAME reference modules in float64 on the same inputs: the backward pass through batch-statistics BatchNorm cancels heavily, and the
+    # reference's own fp32 gradients are 1e-3 .. 2e-2 of their range away from these (err32.*) - a bound on "as accurate as the reference"
+    # needs the exact values next to the fp32 ones.
+    P = gen.make_head_params(909, gen.FULL, 3)
+    x16, x4, target, org = gen.make_head_inputs(1010, 2, 16, 32, gen.FULL)
+    head64 = RefHead(gen.FULL, 3)
+    load_params(head64, P)
+    head64 = head64.double()
+    set_mode(head64, True)
+    a = t.from_numpy(x16).double().requires_grad_(True); b = t.from_numpy(x4).double().requires_grad_(True)
+    outs64 = head64(a, b)
+    L64 = losses(head64, outs64, target, org.astype(np.float64))
+    L64[3].backward()
+    g64 = {k: p.grad.numpy() for k, p in head64.named_parameters()}
+    g64['backbone_features'], g64['lowlevel_features'] = a.grad.numpy(), b.grad.numpy()
+    out['losses64'] = np.array([float(x.detach()) for x in L64], dtype=np.float64)
+    out['SSSR_sample64'] = gen.strided_sample(outs64[0].detach().numpy(), 1 << 16)
+    for k, g in g64.items():
+        s64 = g if g.size <= 8192 else gen.strided_sample(g, 4096)
+        s32 = out[f'grad.{k}'] if g.size <= 8192 else out[f'gradsample.{k}']
+        out[f'grad64.{k}'] = np.asarray(s64, np.float64)
+        out[f'err32.{k}'] = np.array(np.abs(np.asarray(s32, np.float64) - s64).max() / max(np.abs(s64).max(), 1e-300))
+    for k, v in head.state_dict().items():
+        if 'running_' in k and v.numel() <= 256:
+            out[f'new.{k}'] = np_(v)
+    np.savez_compressed(os.path.join(HERE, 'head_train_256x512.npz'), **out)
+    print('head_train_256x512.npz', out['losses'], len(out), 'arrays')
+
+
 def golden_head_512x1024():
     """BASELINE config 5 size (512x1024 input -> 1024x2048 logits), eval forward, B=1: argmax map, top-2 margins, strided logits
     sample, checksums, feature-transformer maps (FA on 32x32 similarity matrices, n = 1024) and loss values."""
@@ -403,6 +449,8 @@ if __name__ == '__main__':
         golden_pipeline_and_metrics(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'c5':
         golden_head_512x1024(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'train256':
+        golden_head_train_256x512(); sys.exit(0)
     golden_pipeline_and_metrics()
     golden_fa()
     golden_ops()
@@ -410,4 +458,5 @@ if __name__ == '__main__':
     golden_head_fullwidth()
     golden_head_256x512()
     golden_head_512x1024()
+    golden_head_train_256x512()
     golden_train_steps()

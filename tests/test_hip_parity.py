@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 import gen                     # noqa: E402
 import oracle as O             # noqa: E402
 from hip_helpers import *      # noqa: E402,F401,F403
-from hip_helpers import DEV, HF, D, check, dev, host, make_head, hip_losses, rel_err   # noqa: E402
+from hip_helpers import DEV, HF, D, check, check_elementwise, dev, host, make_head, hip_losses, rel_err   # noqa: E402
 
 TOL = 1e-3
 HEAD_GRAD_BOUND, ARENA_GRAD_BOUND = 2e-3, 1e-1         # fixed bounds of test_full_model_total_loss_backward_with_fa_vs_oracle (measured: 3e-4 and 3.5e-2)
@@ -657,6 +657,51 @@ def test_head_fullwidth_golden(golden, mode):
                 check(gen.strided_sample(gr, 4096), g[f'train.gradsample.{k}'], 3e-3, 'gradsample ' + k)
 
 
+def test_head_train_256x512_golden(golden):
+    """BASELINE's workload in TRAIN mode against vectors generated by the imported reference (round 3): 256x512 input, B=2, BatchNorm batch
+    statistics over 16x32 / 64x128 maps, Dropout modules in eval, stage 3.  Losses 1e-4 and logits 1e-3 (range-relative and per element)
+    against the reference's fp32 run.  Gradients of the total loss w.r.t. EVERY head parameter and both backbone-feature tensors: the backward
+    pass through batch-statistics BatchNorm cancels heavily, so the reference's own fp32 gradients sit 1e-4 .. 2e-2 of their range away from
+    the same reference modules run in float64 (err32.* in the fixture: 2.2e-2 for the low-level features, 2e-3 for the shortcut and cat_conv
+    weights); the HIP path is held to the float64 values within 3e-3, or - where the reference itself is further off - within 2 x the
+    reference's own fp32 error (a 4096-element sample's max norm moves by that much between two fp32 summation orders: the reference's
+    full cat_conv.0 gradient is 3.5e-3 off where its sample is 1.2e-3 off); over all tensors together the HIP errors must not exceed the
+    reference's by more than 1.5 x in the geometric mean.  The arithmetic mode does not move these numbers (exact-product fp32 MFMA, bf16x6 and f16x3 agree to 10 %)."""
+    g = golden('head_train_256x512')
+    head, _ = make_head(gen.FULL, 3, 909, True)
+    x16, x4, target, org = gen.make_head_inputs(1010, 2, 16, 32, gen.FULL)
+    a, b = dev(x16).requires_grad_(True), dev(x4).requires_grad_(True)
+    outs = head(a, b)
+    L = hip_losses(outs, dev(target), dev(org), 3)
+    L[3].backward()
+    check(np.array([float(v.detach()) for v in L]), g['losses'], 1e-4, 'losses')
+    check(np.array([float(v.detach()) for v in L]), g['losses64'], 1e-5, 'losses vs the float64 reference')
+    ss = gen.strided_sample(host(outs[0]), 1 << 16)
+    check(ss, g['SSSR_sample'], TOL, 'logits'); check_elementwise(ss, g['SSSR_sample'], TOL, name='logits')
+    check(ss, g['SSSR_sample64'], 2e-5, 'logits vs the float64 reference')
+    check(gen.strided_sample(host(outs[1]), 1 << 14), g['SISR_sample'], TOL, 'SISR')
+    check(host(outs[2]), g['SSSR_ft'], TOL); check(host(outs[3]), g['SISR_ft'], TOL)
+    grads = {k: host(p.grad) for k, p in head.named_parameters()}
+    grads['backbone_features'], grads['lowlevel_features'] = host(a.grad), host(b.grad)
+    rows, bad = [], {}
+    for k, gr in grads.items():
+        got = gr if f'grad.{k}' in g else gen.strided_sample(gr, 4096)
+        e64, eref = rel_err(got, g[f'grad64.{k}']), float(g[f'err32.{k}'])
+        rows.append((k, e64, eref))
+        if e64 > max(3e-3, 2.0 * eref):
+            bad[k] = (e64, eref)
+    assert len(rows) == len(grads) and len(rows) >= 40
+    rows.sort(key=lambda r: -r[1])
+    print('gradients vs float64 reference (HIP, reference fp32):', [(k, '%.1e' % e, '%.1e' % r) for k, e, r in rows[:6]])
+    assert not bad, bad
+    # as a whole the HIP gradients are as close to float64 as the reference's fp32 gradients are (geometric mean of the ratios)
+    ratio = float(np.exp(np.mean([np.log(max(e, 1e-9) / max(r, 1e-9)) for _, e, r in rows])))
+    assert ratio < 1.5, ratio
+    for k, v in head.state_dict().items():
+        if f'new.{k}' in g:
+            check(host(v), g[f'new.{k}'], 1e-4, 'running statistic ' + k)
+
+
 def test_head_256x512_golden(golden):
     """BASELINE.json's size: 256x512 input -> 512x1024 logits, B=2, eval: identical argmax map, logits within 1e-3."""
     g = golden('head_256x512')
@@ -667,6 +712,7 @@ def test_head_256x512_golden(golden):
         L = hip_losses(outs, dev(target), dev(org), 3)
     sssr = host(outs[0])
     check(gen.strided_sample(sssr, 1 << 17), g['SSSR_sample'], TOL)
+    print('logits element-wise', '%.1e' % check_elementwise(gen.strided_sample(sssr, 1 << 17), g['SSSR_sample'], TOL, name='logits'))     # north_star's 1e-3, per element
     am = sssr.argmax(axis=1).astype(np.uint8)
     diff = am != g['SSSR_argmax']
     # a flip is tolerated only where the reference's own top-2 margin is below fp32 resolution of the logits
@@ -1197,6 +1243,60 @@ def test_full_model_vs_stock_torch_fp64():
     print({k: '%.2e' % v for k, v in rep.items()})
     assert rep['SSSR_decoder.upsample16_pred.6.weight'] <= HEAD_GRAD_BOUND and rep['SISR_decoder.0.weight'] <= HEAD_GRAD_BOUND, rep
     assert rep['all gradients (L2)'] <= ARENA_GRAD_BOUND, rep
+
+
+def test_full_model_frozen_bn_every_gradient_vs_stock_torch_fp64():
+    """The well-conditioned whole-model pin (round 3): BatchNorm frozen as train_or_resume.py:379-382 does with --freeze-batch-norm (every BN
+    module in eval: running statistics, no batch-statistics terms in the backward pass), 128x256 input, B=2, stage 3.  Without the 2-image batch
+    statistics of a random-init net the assembled 101-layer backward is no longer ill-conditioned, so EVERY gradient tensor is held to a FIXED
+    bound against the fp64 stock-torch graph: 5e-3 of its own range, 95 % of the tensors 2e-3 (the self-calibrating bounds of
+    test_full_model_vs_oracle stay for the batch-statistics case)."""
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    from oracle.torch_cpu_model import TorchCpuDSRL, total_loss
+    torch.manual_seed(33)
+    model = D.DSRL(3, cs)
+    rs = np.random.RandomState(4)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):        # running statistics of a "trained" net: non-trivial, well scaled
+                m.running_mean.copy_(torch.from_numpy(rs.standard_normal(m.num_features).astype(np.float32) * 0.1))
+                m.running_var.copy_(torch.from_numpy(rs.uniform(0.5, 1.5, m.num_features).astype(np.float32)))
+            if hasattr(m, 'bn3'):
+                m.bn3.weight.fill_(0.5)
+        model.SSSR_feature_transformer[1].bias.fill_(0.3); model.SISR_feature_transformer[1].bias.fill_(0.3)
+    ref = TorchCpuDSRL(3)
+    missing, unexpected = ref.load_state_dict({k: v.detach().clone() for k, v in model.state_dict().items()}, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    ref = ref.double().train()
+    model = model.to(DEV).to(memory_format=torch.channels_last).train()
+    for net in (model, ref):
+        for m in net.modules():
+            if isinstance(m, (torch.nn.Dropout, torch.nn.modules.batchnorm._BatchNorm)):
+                m.eval()                                                    # freeze_batch_norm (and dropout off, as in every parity run)
+    x = rs.standard_normal((2, 3, 128, 256)).astype(np.float32)
+    tg = rs.randint(0, 19, (2, 256, 512)).astype(np.uint8); tg[rs.uniform(size=tg.shape) < 0.1] = 255
+    org = rs.standard_normal((2, 3, 256, 512)).astype(np.float32)
+    outs = model(dev(x, cl=False))
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    vals = HF.fused_losses(outs, dev(tg), dev(org), 255, 0.1, 1.0, 3, flag)
+    vals[3].backward()
+    r_outs = ref(torch.from_numpy(x).double())
+    r_L = total_loss(r_outs, torch.from_numpy(tg), torch.from_numpy(org).double(), 3)
+    r_L[3].backward()
+    check(host(vals[:4]), np.array([float(v.detach()) for v in r_L]), 1e-4, 'losses (CE, MSE, FA, total)')
+    check(host(outs[0]), r_outs[0].detach().numpy(), 1e-3, 'logits'); check_elementwise(host(outs[0]), r_outs[0].detach().numpy(), 1e-3, name='logits')
+    assert (host(outs[0]).argmax(1) == r_outs[0].detach().numpy().argmax(1)).mean() > 0.9999
+    P, R = dict(model.named_parameters()), dict(ref.named_parameters())
+    errs = {k: rel_err(host(P[k].grad), R[k].grad.numpy()) for k in P if P[k].grad is not None and R[k].grad is not None}
+    assert len(errs) >= 350, len(errs)
+    bad = {k: '%.1e' % v for k, v in errs.items() if v > 5e-3}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    vs = np.sort(np.array(list(errs.values())))
+    print('gradient tensors', len(errs), 'worst', worst, 'median %.1e 95%% %.1e above 2e-3: %d' % (vs[len(vs) // 2], vs[int(0.95 * len(vs))], int((vs > 2e-3).sum())))
+    # fixed bounds: every one of the 350+ tensors within 5e-3 of its range, 95 % of them within 2e-3 (measured: 2 tensors above 2e-3, worst 4.1e-3 -
+    # one fp32 pass through 101 layers against float64)
+    assert not bad, bad
+    assert vs[int(0.95 * len(vs))] <= 2e-3, vs[int(0.95 * len(vs))]
 
 
 def test_train_or_resume_end_to_end(tmp_path):

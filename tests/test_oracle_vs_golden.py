@@ -277,3 +277,40 @@ def test_torch_cpu_baseline_graph_vs_reference(golden, mode):
     assert (outs[0].detach().numpy().argmax(axis=1) == g[f'{mode}.SSSR_argmax']).mean() > 0.9999
     close(outs[2].detach().numpy(), g[f'{mode}.SSSR_ft'], 1e-4)
     close(np.array([float(v) for v in L]), g[f'{mode}.losses'], 1e-4)
+
+
+def test_torch_cpu_baseline_graph_vs_reference_train_256x512(golden):
+    """The same graph on the reference-generated TRAIN-mode vectors of BASELINE's real shape (256x512 input, B=2, batch-statistics BatchNorm):
+    losses, logits sample and every head gradient (tests/golden/make_golden.py: golden_head_train_256x512)."""
+    import torch
+    from oracle.torch_cpu_model import TorchCpuDSRL, total_loss
+    g = golden('head_train_256x512')
+    model = TorchCpuDSRL(3)
+    sd = {k: torch.from_numpy(v) for k, v in gen.make_head_params(909, gen.FULL, 3).items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    x16, x4, target, org = gen.make_head_inputs(1010, 2, 16, 32, gen.FULL)
+    a, b = torch.from_numpy(x16).requires_grad_(True), torch.from_numpy(x4).requires_grad_(True)
+    outs = model.forward_head(a, b)
+    L = total_loss(outs, torch.from_numpy(target), torch.from_numpy(org), 3)
+    L[3].backward()
+    close(np.array([float(v) for v in L]), g['losses'], 1e-4)
+    close(gen.strided_sample(outs[0].detach().numpy(), 1 << 16), g['SSSR_sample'], 1e-4)
+    grads = {k: p.grad.numpy() for k, p in model.named_parameters() if p.grad is not None}
+    grads['backbone_features'], grads['lowlevel_features'] = a.grad.numpy(), b.grad.numpy()
+    seen = 0
+    for k, gr in grads.items():
+        if f'grad.{k}' in g:
+            close(gr, g[f'grad.{k}'], 1e-3); seen += 1
+        elif f'gradsample.{k}' in g:
+            close(gen.strided_sample(gr, 4096), g[f'gradsample.{k}'], 1e-3); seen += 1
+    assert seen >= 40, seen
+    # the fixture's float64 twins really are the more exact values: the fp32 run is the distance err32 away from them, no more
+    for k, gr in grads.items():
+        got = gr if f'grad.{k}' in g else gen.strided_sample(gr, 4096)
+        d = np.abs(np.asarray(got, np.float64) - g[f'grad64.{k}']).max() / np.abs(g[f'grad64.{k}']).max()
+        assert d <= 1.2 * float(g[f'err32.{k}']) + 1e-6, (k, d, float(g[f'err32.{k}']))
