@@ -311,9 +311,28 @@ __device__ void fa_pool(const float* __restrict__ fm, long long sh_, long long s
     __syncthreads();
 }
 
-// leaves: sm.g0 = G, sm.vec = unit dominant eigenvector, sm.scal[0] = lambda (float), returns lambda (double, uniform)
+// wave-wide helpers on doubles: every lane of the wave takes part (wp <= 32 values sit in lanes 0..wp-1, the others carry neutral elements)
+__device__ __forceinline__ double shfl_xor_d(double v, int o) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl_xor((int)(b & 0xffffffffll), o, 64), hi = __shfl_xor((int)(b >> 32), o, 64);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave32_max_d(double v) {        // all 64 lanes receive the result (lanes >= wp carry the neutral element)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, shfl_xor_d(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave32_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += shfl_xor_d(v, o);
+    return v;
+}
+
+// leaves: sm.g0 = G, sm.vec = unit dominant eigenvector, returns lambda (double, uniform).  Round 3: nothing in the loop is serial any more - the
+// largest diagonal entry, the best column, the norm and the Rayleigh quotient used to be loops of wp dependent LDS reads in EVERY thread (the
+// kernel took 100 us for two 16x16 problems per slice); they are wave reductions over lanes 0..wp-1 now, done redundantly by each wave.
 __device__ double fa_top_eig(FaSmem& sm, int hp, int wp) {
-    const int nn = wp * wp;
+    const int nn = wp * wp, lane = threadIdx.x & 63;
     for (int e = threadIdx.x; e < nn; e += 256) {
         const int a = e / wp, b = e - a * wp;
         double s = 0.0;
@@ -324,8 +343,7 @@ __device__ double fa_top_eig(FaSmem& sm, int hp, int wp) {
     double* cur = sm.ga; double* nxt = sm.gb;
     for (int it = 0; it < FA_SQUARINGS; ++it) {
         // normalise by the largest diagonal entry (G is PSD: max |entry| sits on the diagonal)
-        double mx = 0.0;
-        for (int a = 0; a < wp; ++a) mx = fmax(mx, cur[a * wp + a]);
+        const double mx = wave32_max_d(lane < wp ? cur[lane * wp + lane] : 0.0);
         if (!(mx > 0.0)) break;             // all-zero (or NaN) map: lambda = 0 -> S = 0/0 = NaN exactly like the reference
         const double inv = 1.0 / mx;
         for (int e = threadIdx.x; e < nn; e += 256) {
@@ -337,67 +355,77 @@ __device__ double fa_top_eig(FaSmem& sm, int hp, int wp) {
         __syncthreads();
         double* t = cur; cur = nxt; nxt = t;
     }
-    // dominant eigenvector ~ the column of G^(2^s) with the largest diagonal entry
-    int best = 0; double bd = -1.0;
-    for (int a = 0; a < wp; ++a) { const double d = cur[a * wp + a]; if (d > bd) { bd = d; best = a; } }
-    double nrm = 0.0;
-    for (int a = 0; a < wp; ++a) nrm += cur[a * wp + best] * cur[a * wp + best];
-    nrm = sqrt(nrm);
-    if ((int)threadIdx.x < wp) sm.vec[threadIdx.x] = nrm > 0.0 ? cur[threadIdx.x * wp + best] / nrm : (threadIdx.x == 0 ? 1.0 : 0.0);
+    // dominant eigenvector ~ the column of G^(2^s) with the largest diagonal entry (the first such column)
+    const double dg = lane < wp ? cur[lane * wp + lane] : -1.0;
+    const double bd = wave32_max_d(dg);
+    const unsigned long long hit = __ballot(lane < wp && dg == bd);
+    const int best = hit ? __builtin_ctzll(hit) : 0;
+    const double col = lane < wp ? cur[lane * wp + best] : 0.0;
+    const double nrm = sqrt(wave32_sum_d(col * col));
+    if ((int)threadIdx.x < wp) sm.vec[threadIdx.x] = nrm > 0.0 ? col / nrm : (threadIdx.x == 0 ? 1.0 : 0.0);
     __syncthreads();
-    double lam = 0.0;                        // Rayleigh quotient on the original G (every thread computes it: wp^2 <= 1024 fp64 FMAs)
-    for (int a = 0; a < wp; ++a) {
-        double s = 0.0;
-        for (int b = 0; b < wp; ++b) s += sm.g0[a * wp + b] * sm.vec[b];
-        lam += sm.vec[a] * s;
+    double row = 0.0;                        // Rayleigh quotient on the original G: lane a holds v_a (G v)_a
+    if (lane < wp) {
+        for (int b = 0; b < wp; ++b) row += sm.g0[lane * wp + b] * sm.vec[b];
+        row *= sm.vec[lane];
     }
-    return lam;
+    return wave32_sum_d(row);
 }
 
-__global__ __launch_bounds__(256) void fa_fwd_kernel(const float* __restrict__ fm1, const float* __restrict__ fm2, int C, int hp, int wp, int k,
-                                                      long long sb, long long sc, long long sh_, long long sw_, int reduction,
-                                                      float* __restrict__ out_none, float* __restrict__ saved, long long saved_stride, double* __restrict__ part) {
+// One (slice, map) per block (round 3: the two maps of a slice used to run one after the other in one block): pooled map -> G = X^T X -> lambda,
+// v1 -> S = G / lambda, and what the backward pass needs, into `saved` [S1 n][S2 n][sigma1, sigma2][u1 hp][v1 wp][u2 hp][v2 wp].
+__global__ __launch_bounds__(256) void fa_sim_kernel(const float* __restrict__ fm1, const float* __restrict__ fm2, int C, int hp, int wp, int k,
+                                                      long long sb, long long sc, long long sh_, long long sw_, float* __restrict__ saved, long long saved_stride) {
     __shared__ FaSmem sm;
-    const int slice = blockIdx.x, b = slice / C, c = slice - b * C;
+    const int slice = blockIdx.x, map = blockIdx.y, b = slice / C, c = slice - b * C;
     const int n = wp * wp;
-    float* sv = saved + (long long)slice * saved_stride;      // [S1 n][S2 n][sigma1, sigma2][u1 hp][v1 wp][u2 hp][v2 wp]
-    for (int map = 0; map < 2; ++map) {
-        const float* fm = (map == 0 ? fm1 : fm2) + b * sb + c * sc;
-        fa_pool(fm, sh_, sw_, hp, wp, k, sm.x);
-        const double lam = fa_top_eig(sm, hp, wp);
-        const double sigma = sqrt(lam);
-        float* S = map == 0 ? sm.s1 : sm.s2;
-        for (int e = threadIdx.x; e < n; e += 256) { const float v = (float)(sm.g0[e] / lam); S[e] = v; sv[map * n + e] = v; }
-        float* uv = sv + 2 * n + 2 + map * (hp + wp);
-        for (int i = threadIdx.x; i < hp; i += 256) {
-            double s = 0.0;
-            for (int a = 0; a < wp; ++a) s += (double)sm.x[i * wp + a] * sm.vec[a];
-            uv[i] = (float)(s / sigma);
-        }
-        if ((int)threadIdx.x < wp) uv[hp + threadIdx.x] = (float)sm.vec[threadIdx.x];
-        if (threadIdx.x == 0) sv[2 * n + map] = (float)sigma;
-        __syncthreads();
+    float* sv = saved + (long long)slice * saved_stride;
+    const float* fm = (map == 0 ? fm1 : fm2) + b * sb + c * sc;
+    fa_pool(fm, sh_, sw_, hp, wp, k, sm.x);
+    const double lam = fa_top_eig(sm, hp, wp);
+    const double sigma = sqrt(lam);
+    for (int e = threadIdx.x; e < n; e += 256) sv[map * n + e] = (float)(sm.g0[e] / lam);
+    float* uv = sv + 2 * n + 2 + map * (hp + wp);
+    for (int i = threadIdx.x; i < hp; i += 256) {
+        double s = 0.0;
+        for (int a = 0; a < wp; ++a) s += (double)sm.x[i * wp + a] * sm.vec[a];
+        uv[i] = (float)(s / sigma);
     }
-    // all pairs |S1_i - S2_j|
+    if ((int)threadIdx.x < wp) uv[hp + threadIdx.x] = (float)sm.vec[threadIdx.x];
+    if (threadIdx.x == 0) sv[2 * n + map] = (float)sigma;
+}
+// all pairs |S1_i - S2_j| of one slice, rows i dealt over kFaPairBlocks blocks; one fp64 partial per block (summed in a fixed order by fa_finalize_kernel)
+constexpr int kFaPairBlocks = 8;
+__global__ __launch_bounds__(256) void fa_pairs_kernel(const float* __restrict__ saved, long long saved_stride, int n, int reduction,
+                                                        float* __restrict__ out_none, double* __restrict__ part) {
+    __shared__ float s2[FA_MAXW * FA_MAXW];
+    __shared__ double red[4];
+    const int slice = blockIdx.x, chunk = blockIdx.y;
+    const float* sv = saved + (long long)slice * saved_stride;
+    for (int e = threadIdx.x; e < n; e += 256) s2[e] = sv[n + e];
+    __syncthreads();
+    const int per = (n + kFaPairBlocks - 1) / kFaPairBlocks, i0 = chunk * per, i1 = min(n, i0 + per);
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float a = sm.s1[i];
+    // a row is shared by 8 lanes (j = sub, sub + 8, ...: 32 rows per pass over 256 threads), so that even n = 256 keeps every thread busy
+    const int sub = threadIdx.x & 7;
+    for (int i = i0 + (int)(threadIdx.x >> 3); i < i1; i += 32) {
+        const float a = sv[i];
         float s = 0.f;
         if (reduction == 2) {
             float* o = out_none + ((long long)slice * n + i) * n;
-            for (int j = 0; j < n; ++j) { const float d = fabsf(a - sm.s2[j]); o[j] = d; }
+            for (int j = sub; j < n; j += 8) o[j] = fabsf(a - s2[j]);
         } else {
-            for (int j = 0; j < n; ++j) s += fabsf(a - sm.s2[j]);
+            for (int j = sub; j < n; j += 8) s += fabsf(a - s2[j]);
         }
         acc += (double)s;
     }
-    const double tot = block_sum_d(acc, sm.red);
-    if (threadIdx.x == 0) part[slice] = tot;
+    const double tot = block_sum_d(acc, red);
+    if (threadIdx.x == 0) part[slice * kFaPairBlocks + chunk] = tot;
 }
 __global__ void fa_finalize_kernel(const double* __restrict__ part, int nslices, int n, int reduction, float* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         double s = 0;
-        for (int i = 0; i < nslices; ++i) s += part[i];
+        for (int i = 0; i < nslices * kFaPairBlocks; ++i) s += part[i];
         out[0] = (float)(reduction == 0 ? s / ((double)nslices * n * n) : s);
     }
 }
@@ -416,7 +444,8 @@ __global__ __launch_bounds__(256) void fa_bwd_kernel(const float* __restrict__ f
     for (int e = threadIdx.x; e < n; e += 256) { S1[e] = sv[e]; S2[e] = sv[n + e]; }
     __syncthreads();
     const float scale = grad_out[0] * (reduction == 0 ? (float)(1.0 / ((double)nslices * n * n)) : 1.f);
-    for (int map = 0; map < 2; ++map) {
+    {
+        const int map = blockIdx.y;            // round 3: the two maps of a slice in two blocks
         // dS_map
         for (int e = threadIdx.x; e < n; e += 256) {
             int cnt = 0;
@@ -450,7 +479,6 @@ __global__ __launch_bounds__(256) void fa_bwd_kernel(const float* __restrict__ f
             if (i < hp && a < wp) v = (dXn[i * wp + a] / sigma + dsigma * u1[i] * v1[a]) * invk2;
             dst[e] = v;
         }
-        __syncthreads();
     }
 }
 
@@ -663,7 +691,7 @@ extern "C" size_t dsrl_fa_saved_floats(int B, int C, int H, int W, int k) {
     if (k <= 0) return 0;
     return (size_t)B * C * fa_saved_stride(H / k, W / k);
 }
-extern "C" size_t dsrl_fa_workspace_bytes(int B, int C, int H, int W, int k) { (void)H; (void)W; (void)k; return (size_t)B * C * sizeof(double); }
+extern "C" size_t dsrl_fa_workspace_bytes(int B, int C, int H, int W, int k) { (void)H; (void)W; (void)k; return (size_t)B * C * kFaPairBlocks * sizeof(double); }
 
 extern "C" int dsrl_fa_fwd(const float* fm1, const float* fm2, int B, int C, int H, int W, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
                            int k, int reduction, float* out, float* saved, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
@@ -673,9 +701,11 @@ extern "C" int dsrl_fa_fwd(const float* fm1, const float* fm2, int B, int C, int
     DSRL_REQUIRE(ws_bytes >= dsrl_fa_workspace_bytes(B, C, H, W, k), DSRL_E_WORKSPACE, "fa_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
-    hipLaunchKernelGGL(fa_fwd_kernel, dim3(B * C), dim3(256), 0, st, fm1, fm2, C, hp, wp, k, (long long)sb, (long long)sc, (long long)sh, (long long)sw, reduction,
-                       out, saved, fa_saved_stride(hp, wp), (double*)ws);
-    if (int e = launch_status("fa_fwd_kernel")) return e;
+    hipLaunchKernelGGL(fa_sim_kernel, dim3(B * C, 2), dim3(256), 0, st, fm1, fm2, C, hp, wp, k, (long long)sb, (long long)sc, (long long)sh, (long long)sw,
+                       saved, fa_saved_stride(hp, wp));
+    if (int e = launch_status("fa_sim_kernel")) return e;
+    hipLaunchKernelGGL(fa_pairs_kernel, dim3(B * C, kFaPairBlocks), dim3(256), 0, st, (const float*)saved, fa_saved_stride(hp, wp), wp * wp, reduction, out, (double*)ws);
+    if (int e = launch_status("fa_pairs_kernel")) return e;
     if (reduction != 2) {
         hipLaunchKernelGGL(fa_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, B * C, wp * wp, reduction, out);
         return launch_status("fa_finalize_kernel");
@@ -691,7 +721,7 @@ extern "C" int dsrl_fa_bwd(const float* fm1, const float* fm2, int B, int C, int
     if (int e = fa_dims(H, W, k, hp, wp)) return e;
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
-    hipLaunchKernelGGL(fa_bwd_kernel, dim3(B * C), dim3(256), 0, st, fm1, fm2, B * C, C, H, W, hp, wp, k, (long long)sb, (long long)sc, (long long)sh, (long long)sw,
+    hipLaunchKernelGGL(fa_bwd_kernel, dim3(B * C, 2), dim3(256), 0, st, fm1, fm2, B * C, C, H, W, hp, wp, k, (long long)sb, (long long)sc, (long long)sh, (long long)sw,
                        reduction, grad_out, saved, fa_saved_stride(hp, wp), d1, d2);
     return launch_status("fa_bwd_kernel");
 }

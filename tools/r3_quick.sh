@@ -3,7 +3,7 @@
 tag=$1; shift
 mkdir -p gpurun_out
 for m in "$@" "$@"; do
-  DSRL_CONV_PRECISION=$m timeout -k 10 300 python bench.py --no-prof --no-cpu-baseline --steps 40 --warmup 12 > gpurun_out/${tag}_bench_m$m.txt 2>&1 || { echo "bench m$m failed"; tail -5 gpurun_out/${tag}_bench_m$m.txt; exit 1; }
+  DSRL_CONV_PRECISION=$m timeout -k 10 300 python bench.py --no-prof --no-cpu-baseline --no-config5 --steps 40 --warmup 12 > gpurun_out/${tag}_bench_m$m.txt 2>&1 || { echo "bench m$m failed"; tail -5 gpurun_out/${tag}_bench_m$m.txt; exit 1; }
   python - <<PY
 import json
 for l in open('gpurun_out/${tag}_bench_m$m.txt'):
