@@ -369,15 +369,20 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
 // filter in "plane" form - per 4 consecutive channels 4 fp16 first terms followed by the 4 second terms, 16 bytes for 16 bytes of fp32, same
 // indexing - written once per training step by weight_split_batched_kernel with the scale of a.amax_b): its staged float4 are stored to
 // LDS as they come, which removes half of the split work of a chunk - work that every one of the M / BM row tiles used to repeat.
+// WGM * WGN = 4 waves (256 threads per K group) or, round 3, 8 waves (512 threads, KG = 1: the 256x128 and 256x256 tiles - a wave still owns
+// MR x NR tiles of 32x32, but the block stages 0.75x / 0.5x the bytes of 128x128 tiles per multiply-add, through LDS and from L2).
 template <int MR, int NR, int WGM, int WGN, bool DGRAD, int NPL, int KG = 1, int ARITH = 0>
-__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WGM * WGN * KG, KG == 1 ? 2 : 1)
+void conv_igemm_split_kernel(const ConvArgs a) {
     constexpr bool F16 = ARITH != 0, PREB = ARITH == 2;
+    constexpr int NT = 64 * WGM * WGN, RP = NT / 4;          // threads of one K group; rows per staging pass (4 lanes per row)
+    static_assert(NT == 256 || (NT == 512 && KG == 1), "4 waves per K group, or one group of 8 waves");
     static_assert(!F16 || NPL == 2, "f16x3 carries two fp16 terms per operand");
     using PT = Plane<F16>;
     using pl4 = typename PT::v4; using pl8 = typename PT::v8;
     const int sh_a = F16 ? amax_shift(a.amax_a) : 0, sh_b = F16 ? amax_shift(a.amax_b) : 0;
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
-    constexpr int A_IT = (BM + 63) / 64, B_IT = (BN + 63) / 64;      // 64 rows per staging pass (4 lanes per row)
+    constexpr int A_IT = (BM + RP - 1) / RP, B_IT = (BN + RP - 1) / RP;
     constexpr int NV = A_IT + B_IT;
     constexpr int ROWB = 32;
     constexpr int STAGE = (BM + BN) * NPL * ROWB;                     // bytes
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
     char* const S0 = reinterpret_cast<char*>(smem) + grp * 2 * STAGE;
     char* const S1 = S0 + STAGE;
 
-    const int tid = threadIdx.x & 255;          // thread within its K group
+    const int tid = threadIdx.x & (NT - 1);     // thread within its K group
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
@@ -395,13 +400,13 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
     const int HoWo = a.Ho * a.Wo;
 
     const int c4 = tid & 3, r0 = tid >> 2;
-    const bool b_rows = (BN % 64 == 0) || r0 < BN;                   // BN = 32: only waves 0,1 stage filter rows
+    const bool b_rows = (BN % RP == 0) || r0 < BN;                   // BN < rows per pass: only the first waves stage filter rows
     int a_n[A_IT], a_h[A_IT], a_w[A_IT];
     bool a_ok[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + r0 + 64 * i;
-        a_ok[i] = m < a.M;
+        const int m = m0 + r0 + RP * i;
+        a_ok[i] = m < a.M && (BM % RP == 0 || r0 + RP * i < BM);
         const int mm = a_ok[i] ? ((DGRAD && a.par) ? dgrad_pix(a, m) : m) : 0;
         const int n = mm / HoWo, rem = mm - n * HoWo;
         const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
     unsigned b_off[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int k = n0 + r0 + 64 * i;
+        const int k = n0 + r0 + RP * i;
         b_off[i] = (k < a.K && b_rows) ? (unsigned)k * (unsigned)(RS * a.C) * 4u : kOOB;
     }
 
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
         if (PREB && v >= A_IT) {                // filter rows arrive split: first terms in .x .y, second terms in .z .w
             if (pl == 0 && b_rows) {
                 const float4 x = R[v][hf];
-                char* q = nb + (NPL * BM + r0 + 64 * (v - A_IT)) * ROWB + w_swz;
+                char* q = nb + (NPL * BM + r0 + RP * (v - A_IT)) * ROWB + w_swz;
                 *reinterpret_cast<uint2*>(q) = make_uint2(__float_as_uint(x.x), __float_as_uint(x.y));
                 *reinterpret_cast<uint2*>(q + BN * ROWB) = make_uint2(__float_as_uint(x.z), __float_as_uint(x.w));
             }
@@ -545,9 +550,9 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_igemm_split_ke
         }
         const pl4 t = PT::cvt(res);
         if (v < A_IT) {
-            *reinterpret_cast<pl4*>(nb + (pl * BM + r0 + 64 * v) * ROWB + w_swz) = t;
+            *reinterpret_cast<pl4*>(nb + (pl * BM + r0 + RP * v) * ROWB + w_swz) = t;
         } else if (b_rows) {
-            *reinterpret_cast<pl4*>(nb + (NPL * BM + pl * BN + r0 + 64 * (v - A_IT)) * ROWB + w_swz) = t;
+            *reinterpret_cast<pl4*>(nb + (NPL * BM + pl * BN + r0 + RP * (v - A_IT)) * ROWB + w_swz) = t;
         }
         if (pl + 1 < NPL) PT::residual(res, t);
     };
@@ -1563,8 +1568,10 @@ struct ProfScope {
 };
 
 // tile configurations <MR,NR,WGM,WGN>: block tile = (32*MR*WGM) x (32*NR*WGN), always 4 waves
-enum TileCfg { T128x128, T256x64, T256x32, T64x64, T128x64, T64x128, T128x32, kNumCfg };
-static const int kCfgDims[kNumCfg][2] = {{128, 128}, {256, 64}, {256, 32}, {64, 64}, {128, 64}, {64, 128}, {128, 32}};
+// the last two are 8-wave blocks (512 threads) of the split-precision forward / dgrad kernel only: kNumCfg4 counts the 4-wave tiles every kernel has
+enum TileCfg { T128x128, T256x64, T256x32, T64x64, T128x64, T64x128, T128x32, T256x128, T256x256, kNumCfg };
+constexpr int kNumCfg4 = T256x128;
+static const int kCfgDims[kNumCfg][2] = {{128, 128}, {256, 64}, {256, 32}, {64, 64}, {128, 64}, {64, 128}, {128, 32}, {256, 128}, {256, 256}};
 #define DSRL_CFG_SWITCH(cfg, LAUNCH)                 \
     switch (cfg) {                                   \
         case T128x128: LAUNCH(2, 2, 2, 2); break;    \
@@ -1579,9 +1586,10 @@ static void cfg_dims(TileCfg c, int& bm, int& bn) { bm = kCfgDims[c][0]; bn = kC
 // forward / dgrad (rows = pixels M, columns = output channels N).  Measured on MI355X (tools/sweep_igemm.py): take the largest
 // tile that still yields >= 3 blocks per CU, fall back to 64x64; split K only when the tap/channel loop is very long (ASPP).
 static long long cfg_blocks(TileCfg c, long long M, int N) { return ceil_div(M, kCfgDims[c][0]) * ceil_div(N, kCfgDims[c][1]); }
+static int conv_precision_mode();
 static TileCfg pick_cfg(long long M, int N) {
     const int forced = env_int("DSRL_FORCE_CFG", -1);
-    if (forced >= 0 && forced < kNumCfg) return (TileCfg)forced;
+    if (forced >= 0 && forced < kNumCfg && (forced < kNumCfg4 || conv_precision_mode() == 4)) return (TileCfg)forced;
     if (N <= 32) return cfg_blocks(T256x32, M, N) >= 3 * kNumCU ? T256x32 : T128x32;
     const int r = N % 128;
     const bool narrow = N <= 64 || (r > 0 && r <= 64);
@@ -1596,9 +1604,9 @@ static TileCfg pick_cfg(long long M, int N) {
 static TileCfg pick_cfg_wgrad(int K, int C) {
     int forced = env_int("DSRL_FORCE_CFG", -1);
     if (forced < 0) forced = env_int("DSRL_WGRAD_CFG", -1);
-    if (forced >= 0 && forced < kNumCfg) return (TileCfg)forced;
+    if (forced >= 0 && forced < kNumCfg4) return (TileCfg)forced;
     const int big = env_int("DSRL_WGRAD_BIG_CFG", -1);          // experiment: this tile for layers with K >= 128 and C >= 128
-    if (big >= 0 && big < kNumCfg && K >= 128 && C >= 128) return (TileCfg)big;
+    if (big >= 0 && big < kNumCfg4 && K >= 128 && C >= 128) return (TileCfg)big;
     if (C <= 32) return T128x32;
     return K <= 64 ? T64x64 : T128x64;
 }
@@ -1720,6 +1728,23 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
             return launch_status("conv_igemm_split_kernel<K groups>");
         }
         const size_t lds2 = stages;
+        if (cfg == T256x128 || cfg == T256x256) {               // 8 waves; f16x3 with or without pre-split filters, and bf16x6
+#define DSRL_LAUNCH_BIG(a_, b_, c_, d_)                                                                                                   \
+            {                                                                                                                              \
+                if (f16 && a.w_split) {                                                                                                    \
+                    static const hipError_t at_ = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); (void)at_; \
+                    hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2>), grid, dim3(512), lds2, st, a);             \
+                } else if (f16) {                                                                                                          \
+                    static const hipError_t at_ = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); (void)at_; \
+                    hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 1>), grid, dim3(512), lds2, st, a);             \
+                } else {                                                                                                                   \
+                    set_error("conv_igemm_split_kernel: the 8-wave tiles exist for the f16x3 arithmetic only"); return DSRL_E_UNSUPPORTED;   \
+                }                                                                                                                          \
+            }
+            if (cfg == T256x128) DSRL_LAUNCH_BIG(2, 2, 4, 2) else DSRL_LAUNCH_BIG(4, 2, 2, 4)
+#undef DSRL_LAUNCH_BIG
+            return launch_status("conv_igemm_split_kernel<f16x3, 8 waves>");
+        }
 #define DSRL_LAUNCH_SPLIT(a_, b_, c_, d_)                                                                                    \
         if (f16 && a.w_split) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2>), grid, dim3(256), lds2, st, a); \
         else if (f16) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 1>), grid, dim3(256), lds2, st, a); \
@@ -1783,9 +1808,17 @@ static int pick_kg(long long tiles, int nq, TileCfg cfg, int npl) {
 //   b) when even 64x64 tiles do not fill the chip, 128x128 tiles with split-K <= 4 beat 64x64 K groups if they reach >= 512 blocks
 //      (layer4, M = 4096 and N >= 512), or >= 256 blocks on very long K loops (dilated ASPP convs);
 //   c) 385..767 tiles of 64x64 (layer2 3x3): a 64x128 / 128x64 tile with two K groups.
-static void pick_split_plan(long long M, int N, int nq, TileCfg& cfg, int& splits, int& kg) {
+//   d) f16x3 only, the 8-wave tiles (profiles/round3_sweep_8wave_tiles.txt): with a long K loop (>= 32 chunks) and at least one block per
+//      CU the forward pass takes 256x256 tiles (cat / SISR 3x3 convs: -8..-17 %), dgrad 256x128 at >= 2 blocks per CU (-4..-7 %; its
+//      256x256 build spills); the dilated ASPP forward convs (M = 4096, 576 chunks) take 256x128 with split-K 8 (-22 %).
+static void pick_split_plan(long long M, int N, int nq, bool dgrad, TileCfg& cfg, int& splits, int& kg) {
     const bool forced = env_int("DSRL_FORCE_CFG", -1) >= 0 || env_int("DSRL_FORCE_SPLITS", 0) > 0 || env_int("DSRL_FORCE_KG", 0) > 0;
     if (forced || N <= 32 || !env_int("DSRL_SPLIT_PLAN", 1)) return;
+    if (conv_precision_mode() == 4 && env_int("DSRL_BIG_TILES", 1) && N >= 192 && nq >= 32) {                                         // d)
+        if (!dgrad && cfg_blocks(T256x256, M, N) >= kNumCU) { cfg = T256x256; splits = 1; kg = 1; return; }
+        if (dgrad && cfg_blocks(T256x128, M, N) >= 2 * kNumCU) { cfg = T256x128; splits = 1; kg = 1; return; }
+        if (!dgrad && nq >= 256 && cfg_blocks(T256x128, M, N) * 8 >= kNumCU && cfg_blocks(T128x128, M, N) < kNumCU) { cfg = T256x128; splits = 8; kg = 1; return; }
+    }
     const int r = N % 128;
     const bool narrow = N <= 64 || (r > 0 && r <= 64);
     const TileCfg wide[2] = {T128x128, T128x64}, nar[2] = {T256x64, T128x64};
@@ -1800,7 +1833,7 @@ static void pick_split_plan(long long M, int N, int nq, TileCfg& cfg, int& split
         cfg = (N % 128 == 0) ? T64x128 : T128x64; splits = 1; kg = 2;
     }
 }
-static FwdPlan plan_fwd(int N, int Hin, int Win, int Cin, int Kout, int R, int S, int Ho, int Wo, int npl) {
+static FwdPlan plan_fwd(int N, int Hin, int Win, int Cin, int Kout, int R, int S, int Ho, int Wo, int npl, bool dgrad = false) {
     FwdPlan p; p.Ho = Ho; p.Wo = Wo; p.M = N * Ho * Wo; p.cchunks = (int)ceil_div(Cin, BK);
     p.cfg = pick_cfg(p.M, Kout);
     int bm, bn; cfg_dims(p.cfg, bm, bn);
@@ -1808,13 +1841,14 @@ static FwdPlan plan_fwd(int N, int Hin, int Win, int Cin, int Kout, int R, int S
     const int nq = R * S * p.cchunks;
     p.kg = pick_kg(tiles, nq, p.cfg, npl);
     p.splits = p.kg > 1 ? 1 : pick_splits(tiles, nq);
-    if (npl) pick_split_plan(p.M, Kout, nq, p.cfg, p.splits, p.kg);
+    if (npl) pick_split_plan(p.M, Kout, nq, dgrad, p.cfg, p.splits, p.kg);
     p.ws = p.splits > 1 ? (size_t)p.splits * p.M * Kout * sizeof(float) : 0;
     return p;
 }
 // workspace queries do not know which arithmetic the launch will run in: the larger of the two plans
 static size_t plan_fwd_ws(int N, int Hin, int Win, int Cin, int Kout, int R, int S, int Ho, int Wo) {
-    return std::max(plan_fwd(N, Hin, Win, Cin, Kout, R, S, Ho, Wo, 0).ws, plan_fwd(N, Hin, Win, Cin, Kout, R, S, Ho, Wo, 3).ws);
+    return std::max({plan_fwd(N, Hin, Win, Cin, Kout, R, S, Ho, Wo, 0).ws, plan_fwd(N, Hin, Win, Cin, Kout, R, S, Ho, Wo, 3).ws,
+                     plan_fwd(N, Hin, Win, Cin, Kout, R, S, Ho, Wo, 3, true).ws});
 }
 static size_t with_amax_scratch(size_t ws) { return align_up(ws, 64) + kAmaxScratch; }      // every conv workspace ends with the f16x3 scratch words
 
@@ -1845,7 +1879,7 @@ static int fwd_stats_parts(const FwdPlan& p, int npl, bool dgrad = false) {
         return ((p.ws / ((size_t)p.splits * p.M * sizeof(float))) % 32 == 0 && ceil_div(p.M, 64) <= 256) ? (int)ceil_div(p.M, 64) : 0;
     if (!npl || p.splits > 1) return 0;
     int bm, bn; cfg_dims(p.cfg, bm, bn);
-    static const int kWGM[kNumCfg] = {2, 4, 4, 2, 2, 2, 4};          // waves along M per block tile, DSRL_CFG_SWITCH order
+    static const int kWGM[kNumCfg] = {2, 4, 4, 2, 2, 2, 4, 4, 2};    // waves along M per block tile, DSRL_CFG_SWITCH order (+ the two 8-wave tiles)
     const long long parts = ceil_div(p.M, bm) * kWGM[p.cfg];
     return parts <= kMaxStatsParts ? (int)parts : 0;       // more than 256: the BatchNorm kernels reduce them to 32 first (bn.hip: stats_reduce)
 }
@@ -1977,7 +2011,7 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
     const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
-    const FwdPlan p = plan_fwd(N, Ho, Wo, Kp, C, R, S, H, W, conv_planes(PASS_DGRAD));
+    const FwdPlan p = plan_fwd(N, Ho, Wo, Kp, C, R, S, H, W, conv_planes(PASS_DGRAD), true);
     const size_t wtb = dgrad_wt_bytes(C, K, R, S);
     DSRL_REQUIRE(ws && ws_bytes >= wtb + p.ws, DSRL_E_WORKSPACE, "conv2d_dgrad: workspace %zu < %zu", ws_bytes, wtb + p.ws);
     const float* wt = wt_in;
@@ -2038,7 +2072,7 @@ extern "C" int dsrl_conv2d_dgrad_stats_parts(int N, int H, int W, int C, int K, 
     const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
     if (Ho <= 0 || Wo <= 0) return 0;
     const int npl = conv_planes(PASS_DGRAD);
-    return fwd_stats_parts(plan_fwd(N, Ho, Wo, pad4(K), C, R, S, H, W, npl), npl, true);
+    return fwd_stats_parts(plan_fwd(N, Ho, Wo, pad4(K), C, R, S, H, W, npl, true), npl, true);
 }
 extern "C" int dsrl_conv2d_dgrad_bnstats(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
                                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

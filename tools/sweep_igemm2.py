@@ -3,7 +3,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from sweep_conv import SHAPES, run
-names = ['T128x128', 'T256x64', 'T256x32', 'T64x64', 'T128x64', 'T64x128', 'T128x32']
+names = ['T128x128', 'T256x64', 'T256x32', 'T64x64', 'T128x64', 'T64x128', 'T128x32', 'T256x128', 'T256x256']
 SHAPES['l4_3x3'] = (8, 512, 16, 32, 512, 3, 1, 2, 2)
 SHAPES['l4_1x1_up'] = (8, 512, 16, 32, 2048, 1, 1, 0, 1)
 SHAPES['l4_1x1_dn'] = (8, 2048, 16, 32, 512, 1, 1, 0, 1)
@@ -27,10 +27,10 @@ for name in which:
         if auto_only:
             print(f'{name:10s} {what:5s} ' + line[0], flush=True)
             continue
-        for cfg in (0, 1, 3, 4, 5):
+        for cfg in [int(c) for c in os.environ.get('SWEEP_CFGS', '0,1,3,4,5').split(',')]:
             os.environ['DSRL_FORCE_CFG'] = str(cfg)
             res = []
-            for kg, sp in ((1, 1), (1, 2), (1, 4), (2, 1), (4, 1)):
+            for kg, sp in (((1, 1), (1, 2), (1, 4), (1, 8)) if cfg >= 7 else ((1, 1), (1, 2), (1, 4), (2, 1), (4, 1))):
                 os.environ['DSRL_FORCE_KG'] = str(kg); os.environ['DSRL_FORCE_SPLITS'] = str(sp)
                 ms, tf = run(*SHAPES[name], what)
                 res.append(f'{ms*1e3:.0f}')
