@@ -371,9 +371,11 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
 // LDS as they come, which removes half of the split work of a chunk - work that every one of the M / BM row tiles used to repeat.
 // WGM * WGN = 4 waves (256 threads per K group) or, round 3, 8 waves (512 threads, KG = 1: the 256x128 and 256x256 tiles - a wave still owns
 // MR x NR tiles of 32x32, but the block stages 0.75x / 0.5x the bytes of 128x128 tiles per multiply-add, through LDS and from L2).
-template <int MR, int NR, int WGM, int WGN, bool DGRAD, int NPL, int KG = 1, int ARITH = 0>
+template <int MR, int NR, int WGM, int WGN, bool DGRAD, int NPL, int KG = 1, int ARITH = 0, bool STR1 = false>
 __global__ __launch_bounds__(64 * WGM * WGN * KG, KG == 1 ? 2 : 1)
 void conv_igemm_split_kernel(const ConvArgs a) {
+    // STR1: the launch has stride 1 (110 of the step's 114 data gradients): no divisibility tests, no parity order - the gather is a forward conv's
+    const int stride = STR1 ? 1 : a.stride, par = STR1 ? 0 : a.par;
     constexpr bool F16 = ARITH != 0, PREB = ARITH == 2;
     constexpr int NT = 64 * WGM * WGN, RP = NT / 4;          // threads of one K group; rows per staging pass (4 lanes per row)
     static_assert(NT == 256 || (NT == 512 && KG == 1), "4 waves per K group, or one group of 8 waves");
@@ -407,12 +409,12 @@ void conv_igemm_split_kernel(const ConvArgs a) {
     for (int i = 0; i < A_IT; ++i) {
         const int m = m0 + r0 + RP * i;
         a_ok[i] = m < a.M && (BM % RP == 0 || r0 + RP * i < BM);
-        const int mm = a_ok[i] ? ((DGRAD && a.par) ? dgrad_pix(a, m) : m) : 0;
+        const int mm = a_ok[i] ? ((DGRAD && par) ? dgrad_pix(a, m) : m) : 0;
         const int n = mm / HoWo, rem = mm - n * HoWo;
         const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
         a_n[i] = n;
         if (DGRAD) { a_h[i] = ho + a.pad; a_w[i] = wo + a.pad; }
-        else { a_h[i] = ho * a.stride - a.pad; a_w[i] = wo * a.stride - a.pad; }
+        else { a_h[i] = ho * stride - a.pad; a_w[i] = wo * stride - a.pad; }
     }
     const int RS = a.R * a.S;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
@@ -434,19 +436,19 @@ void conv_igemm_split_kernel(const ConvArgs a) {
             hf = (mf - nf * HoWo) / a.Wo; hl = (ml - nl * HoWo) / a.Wo;
             if (hf == hl) { wf = (mf - nf * HoWo) - hf * a.Wo; wl = (ml - nl * HoWo) - hl * a.Wo; }
         }
-        const int pcls = (DGRAD && a.par) ? (m0 / BM) % (a.par * a.par) : 0;  // parity class of this tile
-        const int ph = (DGRAD && a.par) ? pcls / a.par : 0, pw = (DGRAD && a.par) ? pcls - ph * a.par : 0;
-        if (DGRAD && a.par) { hf = 0; hl = a.Ho - 1; wf = 0; wl = a.Wo - 1; }     // the row range of a parity-ordered tile is not an interval: no bounds pruning
+        const int pcls = (DGRAD && par) ? (m0 / BM) % (par * par) : 0;  // parity class of this tile
+        const int ph = (DGRAD && par) ? pcls / par : 0, pw = (DGRAD && par) ? pcls - ph * par : 0;
+        if (DGRAD && par) { hf = 0; hl = a.Ho - 1; wf = 0; wl = a.Wo - 1; }     // the row range of a parity-ordered tile is not an interval: no bounds pruning
         for (int r = 0; r < a.R; ++r)
             for (int s = 0; s < a.S; ++s) {
                 bool act;
                 if (DGRAD) {
-                    act = (hl + a.pad - r * a.dil >= 0) && (hf + a.pad - r * a.dil <= (a.H - 1) * a.stride) &&
-                          (wl + a.pad - s * a.dil >= 0) && (wf + a.pad - s * a.dil <= (a.W - 1) * a.stride);
-                    if (a.par) act = act && ((ph + a.pad - r * a.dil) % a.par == 0) && ((pw + a.pad - s * a.dil) % a.par == 0);
+                    act = (hl + a.pad - r * a.dil >= 0) && (hf + a.pad - r * a.dil <= (a.H - 1) * stride) &&
+                          (wl + a.pad - s * a.dil >= 0) && (wf + a.pad - s * a.dil <= (a.W - 1) * stride);
+                    if (par) act = act && ((ph + a.pad - r * a.dil) % par == 0) && ((pw + a.pad - s * a.dil) % par == 0);
                 } else {
-                    act = (hl * a.stride - a.pad + r * a.dil >= 0) && (hf * a.stride - a.pad + r * a.dil <= a.H - 1) &&
-                          (wl * a.stride - a.pad + s * a.dil >= 0) && (wf * a.stride - a.pad + s * a.dil <= a.W - 1);
+                    act = (hl * stride - a.pad + r * a.dil >= 0) && (hf * stride - a.pad + r * a.dil <= a.H - 1) &&
+                          (wl * stride - a.pad + s * a.dil >= 0) && (wf * stride - a.pad + s * a.dil <= a.W - 1);
                 }
                 if (act) tapmask |= 1ull << (r * a.S + s);
             }
@@ -484,8 +486,8 @@ void conv_igemm_split_kernel(const ConvArgs a) {
             int hi, wi; bool ok = a_ok[i];
             if (DGRAD) {
                 const int hn = a_h[i] - r * a.dil, wn_ = a_w[i] - s * a.dil;
-                hi = hn / a.stride; wi = wn_ / a.stride;
-                ok = ok && hn >= 0 && wn_ >= 0 && hi * a.stride == hn && wi * a.stride == wn_ && hi < a.H && wi < a.W;
+                hi = hn / stride; wi = wn_ / stride;
+                ok = ok && hn >= 0 && wn_ >= 0 && hi * stride == hn && wi * stride == wn_ && hi < a.H && wi < a.W;
             } else {
                 hi = a_h[i] + r * a.dil; wi = a_w[i] + s * a.dil;
                 ok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
@@ -664,7 +666,7 @@ void conv_igemm_split_kernel(const ConvArgs a) {
         for (int i = 0; i < MR; ++i) {
             const int mb32 = m0 + (wm * MR + i) * 32, mb = mb32 + rq;
             // pixel of row m of this 32-row block: m itself, or (parity-ordered dgrad) 32 consecutive pixels of one class: stride par apart
-            const int pix0 = (DGRAD && a.par) ? dgrad_pix(a, min(mb32, a.M - 1)) : mb32, pst = (DGRAD && a.par) ? a.par : 1;
+            const int pix0 = (DGRAD && par) ? dgrad_pix(a, min(mb32, a.M - 1)) : mb32, pst = (DGRAD && par) ? par : 1;
             if (a.accumulate && a.splits == 1) {        // y += result: all 16 old values of the tile are fetched before the first store
                 float old[16];
 #pragma unroll
@@ -700,7 +702,7 @@ void conv_igemm_split_kernel(const ConvArgs a) {
             for (int i = 0; i < MR; ++i) {
                 float xv[16], yv[16];
                 const int mb32 = m0 + (wm * MR + i) * 32;
-                const int pix0 = a.par ? dgrad_pix(a, min(mb32, a.M - 1)) : mb32, pst = a.par ? a.par : 1;
+                const int pix0 = par ? dgrad_pix(a, min(mb32, a.M - 1)) : mb32, pst = par ? par : 1;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {          // all loads of the tile first
                     const int m = mb32 + rq + (e & 3) + 8 * (e >> 2);
@@ -1700,6 +1702,9 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
     const bool f16 = conv_f16();
     const long long nblocks = (long long)grid.x * grid.y * grid.z;
     if (f16 && (a.amax_a == nullptr || a.amax_b == nullptr)) { set_error("conv_igemm_split_kernel<f16x3>: operand magnitudes missing"); return DSRL_E_BADARG; }
+    // stride-1 data gradients with pre-split filters run the build without divisibility tests / parity bookkeeping (template STR1; a forward launch
+    // passes DGRAD = false in that slot, i.e. the same instantiation as without it)
+    const bool s1 = DGRAD && a.stride == 1 && a.par == 0 && env_int("DSRL_DGRAD_S1", 1);
     if (npl) {
         const int kg = a.kg > 1 ? a.kg : 1;
         const size_t stages = (size_t)2 * (bm + bn) * npl * 32;      // two stages of 32-byte rows per K group: <= 60 KiB for every tile
@@ -1708,14 +1713,14 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
             // accumulator sets of the final reduction, whichever is larger (up to 96 KiB: opt-in attribute, set once per instantiation)
             grid = dim3((unsigned)(a.mtiles * a.ntiles), 1u, 1u);
             const size_t lds = std::max(stages * kg, (size_t)(kg - 1) * (bm / 32) * (bn / 32) / 4 * 16384);
-#define DSRL_LAUNCH_KG(a_, b_, c_, d_, NPL_, KG_, F16_)                                                                               \
+#define DSRL_LAUNCH_KG(a_, b_, c_, d_, NPL_, KG_, F16_, S1_)                                                                          \
             {                                                                                                                          \
-                static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_, F16_>, \
+                static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_, F16_, S1_>, \
                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);            \
                 (void)attr;                                                                                                            \
-                hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_, F16_>), grid, dim3(256 * KG_), lds, st, a); \
+                hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_, F16_, S1_>), grid, dim3(256 * KG_), lds, st, a); \
             }
-#define DSRL_KG_BY_ARITH(a_, b_, c_, d_, KG_) { if (f16 && a.w_split) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 2) else if (f16) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 1) else if (npl == 2) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 0) else DSRL_LAUNCH_KG(a_, b_, c_, d_, 3, KG_, 0) }
+#define DSRL_KG_BY_ARITH(a_, b_, c_, d_, KG_) { if (f16 && a.w_split && s1) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 2, DGRAD) else if (f16 && a.w_split) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 2, false) else if (f16) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 1, false) else if (npl == 2) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 0, false) else DSRL_LAUNCH_KG(a_, b_, c_, d_, 3, KG_, 0, false) }
             if (cfg == T64x64) {
                 if (kg == 4) DSRL_KG_BY_ARITH(1, 1, 2, 2, 4) else DSRL_KG_BY_ARITH(1, 1, 2, 2, 2)
             } else if (cfg == T128x64) {
@@ -1731,7 +1736,10 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
         if (cfg == T256x128 || cfg == T256x256) {               // 8 waves; f16x3 with or without pre-split filters, and bf16x6
 #define DSRL_LAUNCH_BIG(a_, b_, c_, d_)                                                                                                   \
             {                                                                                                                              \
-                if (f16 && a.w_split) {                                                                                                    \
+                if (f16 && a.w_split && s1) {                                                                                              \
+                    static const hipError_t at_ = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2, DGRAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); (void)at_; \
+                    hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2, DGRAD>), grid, dim3(512), lds2, st, a);      \
+                } else if (f16 && a.w_split) {                                                                                             \
                     static const hipError_t at_ = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); (void)at_; \
                     hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2>), grid, dim3(512), lds2, st, a);             \
                 } else if (f16) {                                                                                                          \
@@ -1746,7 +1754,8 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
             return launch_status("conv_igemm_split_kernel<f16x3, 8 waves>");
         }
 #define DSRL_LAUNCH_SPLIT(a_, b_, c_, d_)                                                                                    \
-        if (f16 && a.w_split) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2>), grid, dim3(256), lds2, st, a); \
+        if (f16 && a.w_split && s1) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2, DGRAD>), grid, dim3(256), lds2, st, a); \
+        else if (f16 && a.w_split) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2>), grid, dim3(256), lds2, st, a); \
         else if (f16) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 1>), grid, dim3(256), lds2, st, a); \
         else if (npl == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2>), grid, dim3(256), lds2, st, a); \
         else hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 3>), grid, dim3(256), lds2, st, a);
