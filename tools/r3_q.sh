@@ -1,5 +1,3 @@
 #!/bin/bash
-mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_hip_parity.py -x -q -k "conv_golden or precision_modes or f16x3 or strided_dgrad or real_shapes or channel_slices or epilogue or bn_backward_statistics or grad_slots or head_small" > gpurun_out/r3q_t.txt 2>&1; rc=$?; echo "tests rc=$rc"; tail -3 gpurun_out/r3q_t.txt
-[ $rc -ne 0 ] && exit 1
-bash tools/ab_env.sh DSRL_DGRAD_S1=0 3
+SWEEP_CFGS=0,1,7,8 timeout -k 10 600 python tools/sweep_igemm2.py cat0 cat4 sisr aspp_d6 l4_3x3 l4_1x1_up > gpurun_out/r3q_sweep2.txt 2>&1
+grep dgrad gpurun_out/r3q_sweep2.txt | cut -c1-250
