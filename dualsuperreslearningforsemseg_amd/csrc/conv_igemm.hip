@@ -615,32 +615,33 @@ void conv_igemm_split_kernel(const ConvArgs a) {
             __syncthreads();
         }
     }
+    constexpr int EPG = 16 / KG;                // accumulator registers per 32x32 tile that one K group stores in the epilogue
     if constexpr (KG > 1) {
-        // ---- sum the KG accumulator sets through LDS (the stages are free now), fixed order g = 1 .. KG-1; group 0 stores
+        // ---- sum the KG accumulator sets through LDS (the stages are free now) in the fixed order g = 0 .. KG-1.  EVERY group forms the sums, so
+        //      all of them hold the finished tile and share the epilogue: group g stores (and, dgrad, takes the BatchNorm sums of) the registers
+        //      g*EPG .. g*EPG+EPG-1 of every 32x32 tile = a quarter / half of its rows - 16 waves instead of 4 behind the main loop.
         float4* red = reinterpret_cast<float4*>(smem);
         constexpr int NQ = MR * NR * 4;         // float4 per thread
-        if (grp > 0) {
 #pragma unroll
-            for (int i = 0; i < MR; ++i)
+        for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int j = 0; j < NR; ++j)
+            for (int j = 0; j < NR; ++j)
 #pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4)
-                        red[((grp - 1) * NQ + (i * NR + j) * 4 + e4) * 256 + tid] =
-                            make_float4(acc[i][j][4 * e4], acc[i][j][4 * e4 + 1], acc[i][j][4 * e4 + 2], acc[i][j][4 * e4 + 3]);
-        }
+                for (int e4 = 0; e4 < 4; ++e4)
+                    red[(grp * NQ + (i * NR + j) * 4 + e4) * 256 + tid] =
+                        make_float4(acc[i][j][4 * e4], acc[i][j][4 * e4 + 1], acc[i][j][4 * e4 + 2], acc[i][j][4 * e4 + 3]);
         __syncthreads();
-        if (grp > 0) return;
 #pragma unroll
-        for (int g = 1; g < KG; ++g)
+        for (int g = 0; g < KG; ++g)
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int j = 0; j < NR; ++j)
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) {
-                        const float4 v = red[((g - 1) * NQ + (i * NR + j) * 4 + e4) * 256 + tid];
-                        acc[i][j][4 * e4] += v.x; acc[i][j][4 * e4 + 1] += v.y; acc[i][j][4 * e4 + 2] += v.z; acc[i][j][4 * e4 + 3] += v.w;
+                        const float4 v = red[(g * NQ + (i * NR + j) * 4 + e4) * 256 + tid];
+                        if (g == 0) { acc[i][j][4 * e4] = v.x; acc[i][j][4 * e4 + 1] = v.y; acc[i][j][4 * e4 + 2] = v.z; acc[i][j][4 * e4 + 3] = v.w; }
+                        else { acc[i][j][4 * e4] += v.x; acc[i][j][4 * e4 + 1] += v.y; acc[i][j][4 * e4 + 2] += v.z; acc[i][j][4 * e4 + 3] += v.w; }
                     }
     }
 
@@ -653,10 +654,27 @@ void conv_igemm_split_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][jj][e] = __builtin_ldexpf(acc[i][jj][e], sh);
     }
+    // this group's share of the tile (static register indices per group: grp is wave-uniform); one group: the accumulators themselves
+    float mine[KG > 1 ? MR : 1][KG > 1 ? NR : 1][KG > 1 ? EPG : 1];
+    if constexpr (KG > 1) {
+#pragma unroll
+        for (int g = 0; g < KG; ++g)
+            if (grp == g) {
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+#pragma unroll
+                        for (int k = 0; k < EPG; ++k) mine[i][j][k] = acc[i][j][g * EPG + k];
+            }
+    }
+    auto share = [&](int i, int j, int e) -> float { if constexpr (KG > 1) return mine[i][j][e]; else return acc[i][j][e]; };
+    auto share_add = [&](int i, int j, int e, float v) { if constexpr (KG > 1) mine[i][j][e] += v; else acc[i][j][e] += v; };
+    const int rowg = 8 * ((grp * EPG) >> 2);    // first row of the group's registers inside a 32-row tile: register e <-> row (e&3) + 8*(e>>2) + 4*(lane>>5)
     // ---- epilogue: D[row][col], col = lane&31 (out channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); bounds by the descriptor
     float* yout = a.y + (a.splits > 1 ? (long long)z * a.slab : 0ll);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)yout, 0, (int)a.y_bytes, 0x00020000);
-    const int col = lane & 31, rq = (lane >> 5) * 4;
+    const int col = lane & 31, rq = (lane >> 5) * 4 + rowg;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int k = n0 + (wn * NR + j) * 32 + col;
@@ -667,31 +685,31 @@ void conv_igemm_split_kernel(const ConvArgs a) {
             const int mb32 = m0 + (wm * MR + i) * 32, mb = mb32 + rq;
             // pixel of row m of this 32-row block: m itself, or (parity-ordered dgrad) 32 consecutive pixels of one class: stride par apart
             const int pix0 = (DGRAD && par) ? dgrad_pix(a, min(mb32, a.M - 1)) : mb32, pst = (DGRAD && par) ? par : 1;
-            if (a.accumulate && a.splits == 1) {        // y += result: all 16 old values of the tile are fetched before the first store
-                float old[16];
+            if (a.accumulate && a.splits == 1) {        // y += result: all old values of the share are fetched before the first store
+                float old[EPG];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
+                for (int e = 0; e < EPG; ++e) {
                     const int m = mb + (e & 3) + 8 * (e >> 2);
                     const unsigned off = (kok && m < a.M) ? ((unsigned)(pix0 + (m - mb32) * pst) * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
                     old[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, (int)off, 0, 0));     // out-of-bounds offsets read 0
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] += old[e];
+                for (int e = 0; e < EPG; ++e) share_add(i, j, e, old[e]);
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+            for (int e = 0; e < EPG; ++e) {
                 const int m = mb + (e & 3) + 8 * (e >> 2);
                 const unsigned off = (kok && m < a.M) ? ((unsigned)(pix0 + (m - mb32) * pst) * (unsigned)a.ldy + (unsigned)k) * 4u : kOOB;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e] + bv), yr, (int)off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(share(i, j, e) + bv), yr, (int)off, 0, 0);
             }
         }
     }
-    // ---- BatchNorm partials of the tile this wave just wrote: for every output channel (n, mean, M2) over the wave's 32*MR rows,
-    //      two passes over the registers (exact centred second moment), the two lanes that share a channel combined with one shuffle.
-    //      Layout [3][mtiles * WGM][K] = what bn_partial4_kernel writes, consumed by dsrl_bn_train_fwd_from_stats.
     if (DGRAD && a.bstats != nullptr && a.splits == 1) {
-        // BatchNorm-backward partials of the gradient tile just written (values as stored: acc, no bias in a dgrad)
+        // BatchNorm-backward partials of the gradient tile just written (values as stored, no bias in a dgrad): sum(g), sum(g * xhat) per channel over
+        // the wave's 32*MR rows, g = the gradient behind the ReLU mask; layout [2][mtiles * WGM][K] (dsrl_bn_bwd_from_stats).  K groups: every
+        // group sums its share of the rows, the shares meet in LDS (behind the reduction area) and group 0 adds them in the order g = 0 .. KG-1.
         const int nparts = a.mtiles * WGM, part = (tile / a.ntiles) * WGM + wm;
+        float* ex = reinterpret_cast<float*>(smem) + (size_t)KG * MR * NR * 4 * 256 * 4;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int k = n0 + (wn * NR + j) * 32 + col;
@@ -700,11 +718,11 @@ void conv_igemm_split_kernel(const ConvArgs a) {
             float sg = 0.f, sgx = 0.f;
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
-                float xv[16], yv[16];
+                float xv[EPG], yv[EPG];
                 const int mb32 = m0 + (wm * MR + i) * 32;
                 const int pix0 = par ? dgrad_pix(a, min(mb32, a.M - 1)) : mb32, pst = par ? par : 1;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {          // all loads of the tile first
+                for (int e = 0; e < EPG; ++e) {          // all loads of the share first
                     const int m = mb32 + rq + (e & 3) + 8 * (e >> 2);
                     const bool ok = kok && m < a.M;
                     const long long px = pix0 + (m - mb32) * pst;
@@ -712,21 +730,49 @@ void conv_igemm_split_kernel(const ConvArgs a) {
                     yv[e] = (ok && a.bn_relu) ? a.bn_y[px * a.bn_ldy + k] : 1.f;
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + (wm * MR + i) * 32 + rq + (e & 3) + 8 * (e >> 2);
+                for (int e = 0; e < EPG; ++e) {
+                    const int m = mb32 + rq + (e & 3) + 8 * (e >> 2);
                     if (kok && m < a.M) {
-                        const float g = (a.bn_relu && !(yv[e] > 0.f)) ? 0.f : acc[i][j][e];
+                        const float g = (a.bn_relu && !(yv[e] > 0.f)) ? 0.f : share(i, j, e);
                         sg += g; sgx += g * ((xv[e] - mu) * is);
                     }
                 }
             }
             sg += __shfl_xor(sg, 32); sgx += __shfl_xor(sgx, 32);
-            if (lane < 32 && kok) {
-                float* o = a.bstats + (long long)part * a.K + k;
-                o[0] = sg; o[(long long)nparts * a.K] = sgx;
+            if (KG == 1) {
+                if (lane < 32 && kok) {
+                    float* o = a.bstats + (long long)part * a.K + k;
+                    o[0] = sg; o[(long long)nparts * a.K] = sgx;
+                }
+            } else if (lane < 32) {
+                ex[(((grp * 4 + wave) * NR + j) * 2 + 0) * 32 + lane] = sg;
+                ex[(((grp * 4 + wave) * NR + j) * 2 + 1) * 32 + lane] = sgx;
+            }
+        }
+        if constexpr (KG > 1) {
+            __syncthreads();
+            if (grp == 0 && lane < 32) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int k = n0 + (wn * NR + j) * 32 + col;
+                    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+                    for (int g = 0; g < KG; ++g) {
+                        sg += ex[(((g * 4 + wave) * NR + j) * 2 + 0) * 32 + lane];
+                        sgx += ex[(((g * 4 + wave) * NR + j) * 2 + 1) * 32 + lane];
+                    }
+                    if (k < a.K) {
+                        float* o = a.bstats + (long long)part * a.K + k;
+                        o[0] = sg; o[(long long)nparts * a.K] = sgx;
+                    }
+                }
             }
         }
     }
+    if (KG > 1 && grp > 0) return;              // the forward statistics below are taken by group 0 from the whole tile
+    // ---- BatchNorm partials of the tile this block just wrote: for every output channel (n, mean, M2) over the wave's 32*MR rows,
+    //      two passes over the registers (exact centred second moment), the two lanes that share a channel combined with one shuffle.
+    //      Layout [3][mtiles * WGM][K] = what bn_partial4_kernel writes, consumed by dsrl_bn_train_fwd_from_stats.
     if (a.stats != nullptr && a.splits == 1) {
         const int nparts = a.mtiles * WGM, part = (tile / a.ntiles) * WGM + wm;
 #pragma unroll
@@ -1710,9 +1756,9 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
         const size_t stages = (size_t)2 * (bm + bn) * npl * 32;      // two stages of 32-byte rows per K group: <= 60 KiB for every tile
         if (kg > 1) {
             // K groups (64x64 tiles: 2 or 4 groups, 128x64 / 64x128: 2): block of 256*kg threads, LDS = kg stage pairs or the (kg-1)
-            // accumulator sets of the final reduction, whichever is larger (up to 96 KiB: opt-in attribute, set once per instantiation)
+            // accumulator sets of the final reduction (all kg of them: every group sums, every group stores a share), whichever is larger (up to 72 KiB)
             grid = dim3((unsigned)(a.mtiles * a.ntiles), 1u, 1u);
-            const size_t lds = std::max(stages * kg, (size_t)(kg - 1) * (bm / 32) * (bn / 32) / 4 * 16384);
+            const size_t lds = std::max(stages * kg, (size_t)kg * (bm / 32) * (bn / 32) / 4 * 16384 + 8192);      // every group's accumulators + the BatchNorm-sum exchange
 #define DSRL_LAUNCH_KG(a_, b_, c_, d_, NPL_, KG_, F16_, S1_)                                                                          \
             {                                                                                                                          \
                 static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_, F16_, S1_>, \
@@ -2119,7 +2165,7 @@ static void launch_wgrad(const WgradArgs& a_in, TileCfg cfg, int bm, int bn, dim
         const size_t stages = (size_t)2 * npl * 16 * ((bm * 2 + 64) + (bn * 2 + 64));     // two stages: <= 60 KiB for every tile
         const int kg = a.kg > 1 ? a.kg : 1;
         if (kg > 1) {
-            const size_t lds = std::max(stages * kg, (size_t)(kg - 1) * (bm / 32) * (bn / 32) / 4 * 16384);
+            const size_t lds = std::max(stages * kg, (size_t)kg * (bm / 32) * (bn / 32) / 4 * 16384 + 8192);      // every group's accumulators + the BatchNorm-sum exchange
 #define DSRL_LAUNCH_WKG(a_, b_, c_, d_, NPL_, KG_, F16_)                                                                            \
             {                                                                                                                        \
                 static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_split_kernel<a_, b_, c_, d_, NPL_, KG_, F16_>,  \

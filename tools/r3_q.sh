@@ -1,3 +1,6 @@
 #!/bin/bash
-SWEEP_CFGS=0,1,7,8 timeout -k 10 600 python tools/sweep_igemm2.py cat0 cat4 sisr aspp_d6 l4_3x3 l4_1x1_up > gpurun_out/r3q_sweep2.txt 2>&1
-grep dgrad gpurun_out/r3q_sweep2.txt | cut -c1-250
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_hip_parity.py -x -q -k "conv_golden or precision_modes or f16x3 or strided_dgrad or real_shapes or channel_slices or epilogue or bn_backward_statistics or grad_slots or head_small or full_model_vs_oracle or head_train" > gpurun_out/r3q_t.txt 2>&1; rc=$?; echo "tests rc=$rc"; tail -3 gpurun_out/r3q_t.txt
+[ $rc -ne 0 ] && exit 1
+python tools/epi_cost.py 2>&1 | grep -v amdgpu
+bash tools/ab.sh
