@@ -76,14 +76,19 @@ __device__ inline double wave_sum_d(double v) {
 constexpr int kAmaxShards = 16, kAmaxShardStride = 16, kAmaxWords = kAmaxShards * kAmaxShardStride;     // 1 KiB per record
 __device__ inline unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
 __device__ inline unsigned* amax_shard(unsigned* rec) { return rec + (((blockIdx.x + 5u * blockIdx.y) & (kAmaxShards - 1)) * kAmaxShardStride); }
-// maximum over the shards of a record, wave-uniform (every lane of the wave must be active)
-__device__ inline unsigned amax_read(const unsigned* rec) {
+// maximum over the shards of a record, wave-uniform (every lane of the wave must be active).  Two halves so that a kernel can request the
+// shards at its very start (amax_fetch: one load per lane, no wait) and consume them where the value is first needed (amax_reduce): the conv
+// kernels used to sit through two dependent load latencies - one per operand record - before they computed a single address.
+__device__ inline unsigned amax_fetch(const unsigned* rec) {
     const int lane = threadIdx.x & 63;
-    unsigned m = lane < kAmaxShards ? rec[lane * kAmaxShardStride] : 0u;
+    return lane < kAmaxShards ? rec[lane * kAmaxShardStride] : 0u;
+}
+__device__ inline unsigned amax_reduce(unsigned m) {
 #pragma unroll
     for (int o = kAmaxShards / 2; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
     return __builtin_amdgcn_readfirstlane(m);
 }
+__device__ inline unsigned amax_read(const unsigned* rec) { return amax_reduce(amax_fetch(rec)); }
 __device__ inline unsigned abs_bits4(unsigned m, float a, float b, float c, float d) {
     return max(max(m, abs_bits(a)), max(max(abs_bits(b), abs_bits(c)), abs_bits(d)));
 }

@@ -66,12 +66,17 @@ template <> struct Plane<true> {
 };
 // e with max|x| * 2^e in [2^14, 2^15) from the bit pattern of max|x| (zero / subnormal maxima count as 2^-126; Inf / NaN maxima give a
 // finite e: such tensors turn into NaN in the split by themselves)
-__device__ __forceinline__ int amax_shift(const unsigned* p) {
-    const unsigned u = amax_read(p);
+__device__ __forceinline__ int amax_shift_of(unsigned fetched) {      // fetched: this lane's amax_fetch() of the record
+    const unsigned u = amax_reduce(fetched);
     int ex = (int)((u >> 23) & 0xffu);
     if (ex == 0) ex = 1;
     return 14 - (ex - 127);
 }
+__device__ __forceinline__ int amax_shift(const unsigned* p) { return amax_shift_of(amax_fetch(p)); }
+
+// q = n / d for 0 <= n < 2^31: m = ceil(2^(31+l) / d) with l = ceil(log2 d) >= 1, q = mulhi(n, m) >> (l - 1), exact; d = 1 is
+// flagged by shift 255 (host side: make_magic)
+__device__ __forceinline__ int fast_div(int n, unsigned m, unsigned s) { return s == 255u ? n : (int)(__umulhi((unsigned)n, m) >> s); }
 
 struct ConvArgs {
     const float* x; const float* w; const float* bias; float* y;
@@ -102,6 +107,7 @@ struct ConvArgs {
     int par, Hh, Wh, pbm;
     const unsigned* amax_a; const unsigned* amax_b;     // f16x3: amax records of the input tensor x and of the filter w
     int w_split;                                        // f16x3: `w` is the pre-split filter (kernel ARITH = 2)
+    unsigned mHW, sHW, mW, sW, mNT, sNT;                // split kernels: magic numbers of the divisions by Ho*Wo, Wo and ntiles (fast_div; host: make_magic)
 };
 __device__ __forceinline__ int dgrad_pix(const ConvArgs& a, int m) {        // row of the parity-ordered GEMM -> pixel index (n*Ho + h)*Wo + w
     const int t = m / a.pbm, p2 = a.par * a.par, c = t % p2, j = (t / p2) * a.pbm + (m - t * a.pbm);
@@ -382,7 +388,10 @@ void conv_igemm_split_kernel(const ConvArgs a) {
     static_assert(!F16 || NPL == 2, "f16x3 carries two fp16 terms per operand");
     using PT = Plane<F16>;
     using pl4 = typename PT::v4; using pl8 = typename PT::v8;
-    const int sh_a = F16 ? amax_shift(a.amax_a) : 0, sh_b = F16 ? amax_shift(a.amax_b) : 0;
+    // f16x3 operand scales: both records are requested before anything else and consumed behind the first operand loads (in-order return:
+    // waiting for them does not wait for the tiles)
+    const unsigned am_a = F16 ? amax_fetch(a.amax_a) : 0u, am_b = F16 ? amax_fetch(a.amax_b) : 0u;
+    int sh_a = 0, sh_b = 0;
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
     constexpr int A_IT = (BM + RP - 1) / RP, B_IT = (BN + RP - 1) / RP;
     constexpr int NV = A_IT + B_IT;
@@ -398,7 +407,8 @@ void conv_igemm_split_kernel(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
     const int tile = a.xcd_remap ? xcd_contiguous(blockIdx.x, a.mtiles * a.ntiles) : blockIdx.x;
-    const int m0 = (tile / a.ntiles) * BM, n0 = (tile % a.ntiles) * BN, z = blockIdx.z;
+    const int tile_m = fast_div(tile, a.mNT, a.sNT);           // the prologue runs on every wave of the block at once: no integer divides in it
+    const int m0 = tile_m * BM, n0 = (tile - tile_m * a.ntiles) * BN, z = blockIdx.z;
     const int HoWo = a.Ho * a.Wo;
 
     const int c4 = tid & 3, r0 = tid >> 2;
@@ -410,8 +420,8 @@ void conv_igemm_split_kernel(const ConvArgs a) {
         const int m = m0 + r0 + RP * i;
         a_ok[i] = m < a.M && (BM % RP == 0 || r0 + RP * i < BM);
         const int mm = a_ok[i] ? ((DGRAD && par) ? dgrad_pix(a, m) : m) : 0;
-        const int n = mm / HoWo, rem = mm - n * HoWo;
-        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        const int n = fast_div(mm, a.mHW, a.sHW), rem = mm - n * HoWo;
+        const int ho = fast_div(rem, a.mW, a.sW), wo = rem - ho * a.Wo;
         a_n[i] = n;
         if (DGRAD) { a_h[i] = ho + a.pad; a_w[i] = wo + a.pad; }
         else { a_h[i] = ho * stride - a.pad; a_w[i] = wo * stride - a.pad; }
@@ -428,12 +438,14 @@ void conv_igemm_split_kernel(const ConvArgs a) {
 
     // ---- taps that touch at least one in-bounds input pixel for this tile (block-uniform)
     unsigned long long tapmask = 0ull;
-    {
+    if (a.R * a.S == 1 && a.pad == 0) {
+        tapmask = 1ull;                         // 1x1 without padding: the one tap is always in bounds
+    } else {
         const int mf = m0, ml = min(m0 + BM, a.M) - 1;
-        const int nf = mf / HoWo, nl = ml / HoWo;
+        const int nf = fast_div(mf, a.mHW, a.sHW), nl = fast_div(ml, a.mHW, a.sHW);
         int hf = 0, hl = a.Ho - 1, wf = 0, wl = a.Wo - 1;
         if (nf == nl) {
-            hf = (mf - nf * HoWo) / a.Wo; hl = (ml - nl * HoWo) / a.Wo;
+            hf = fast_div(mf - nf * HoWo, a.mW, a.sW); hl = fast_div(ml - nl * HoWo, a.mW, a.sW);
             if (hf == hl) { wf = (mf - nf * HoWo) - hf * a.Wo; wl = (ml - nl * HoWo) - hl * a.Wo; }
         }
         const int pcls = (DGRAD && par) ? (m0 / BM) % (par * par) : 0;  // parity class of this tile
@@ -455,7 +467,8 @@ void conv_igemm_split_kernel(const ConvArgs a) {
     }
     const int ntaps = __builtin_popcountll(tapmask);
     const int nq = ntaps * a.cchunks;
-    const int q0 = (int)((long long)nq * z / a.splits), q1 = (int)((long long)nq * (z + 1) / a.splits);
+    int q0 = 0, q1 = nq;
+    if (a.splits > 1) { q0 = (int)((long long)nq * z / a.splits); q1 = (int)((long long)nq * (z + 1) / a.splits); }
 
     f32x16 acc[MR][NR];
 #pragma unroll
@@ -469,9 +482,11 @@ void conv_igemm_split_kernel(const ConvArgs a) {
     int cc = 0, tap = 0, pos = q0;
     unsigned long long rem_mask = tapmask;
     if (q0 < q1) {
-        int skip = q0 / a.cchunks;
-        cc = q0 - skip * a.cchunks;
-        while (skip--) rem_mask &= rem_mask - 1;
+        if (q0 > 0) {                           // split-K launches only
+            int skip = q0 / a.cchunks;
+            cc = q0 - skip * a.cchunks;
+            while (skip--) rem_mask &= rem_mask - 1;
+        }
         tap = __builtin_ctzll(rem_mask);
     }
     auto advance = [&](int n) {                 // wave-uniform; only ever asked to step onto an existing chunk
@@ -597,6 +612,12 @@ void conv_igemm_split_kernel(const ConvArgs a) {
     if (q0 < q1) {
         issue(R0);
         issue(R1);
+    }
+    if (F16) {
+        __builtin_amdgcn_sched_barrier(0);
+        sh_a = amax_shift_of(am_a); sh_b = amax_shift_of(am_b);
+    }
+    if (q0 < q1) {
 #pragma unroll
         for (int c = 0; c < CSTEPS; ++c) cstep(S0, R0, 0, c);
         __syncthreads();
@@ -708,7 +729,7 @@ void conv_igemm_split_kernel(const ConvArgs a) {
         // BatchNorm-backward partials of the gradient tile just written (values as stored, no bias in a dgrad): sum(g), sum(g * xhat) per channel over
         // the wave's 32*MR rows, g = the gradient behind the ReLU mask; layout [2][mtiles * WGM][K] (dsrl_bn_bwd_from_stats).  K groups: every
         // group sums its share of the rows, the shares meet in LDS (behind the reduction area) and group 0 adds them in the order g = 0 .. KG-1.
-        const int nparts = a.mtiles * WGM, part = (tile / a.ntiles) * WGM + wm;
+        const int nparts = a.mtiles * WGM, part = tile_m * WGM + wm;
         float* ex = reinterpret_cast<float*>(smem) + (size_t)KG * MR * NR * 4 * 256 * 4;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
@@ -774,7 +795,7 @@ void conv_igemm_split_kernel(const ConvArgs a) {
     //      two passes over the registers (exact centred second moment), the two lanes that share a channel combined with one shuffle.
     //      Layout [3][mtiles * WGM][K] = what bn_partial4_kernel writes, consumed by dsrl_bn_train_fwd_from_stats.
     if (a.stats != nullptr && a.splits == 1) {
-        const int nparts = a.mtiles * WGM, part = (tile / a.ntiles) * WGM + wm;
+        const int nparts = a.mtiles * WGM, part = tile_m * WGM + wm;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int k = n0 + (wn * NR + j) * 32 + col;
@@ -1198,9 +1219,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------ split-precision wgrad
-// q = n / d for 0 <= n < 2^31: m = ceil(2^(31+l) / d) with l = ceil(log2 d) >= 1, q = mulhi(n, m) >> (l - 1), exact; d = 1 is
-// flagged by shift 255 (host side: make_magic)
-__device__ __forceinline__ int fast_div(int n, unsigned m, unsigned s) { return s == 255u ? n : (int)(__umulhi((unsigned)n, m) >> s); }
 
 // bf16x3 / bf16x6 weight gradient, software-pipelined like conv_igemm_split_kernel: a 32-pixel chunk is fetched into one of two
 // register sets and consumed as two 16-pixel half-steps (= one 16-deep MFMA step each) through two LDS stages; the split /
@@ -1215,7 +1233,12 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
     static_assert(!F16 || NPL == 2, "f16x3 carries two fp16 terms per operand");
     using PT = Plane<F16>;
     using pl4 = typename PT::v4; using pl8 = typename PT::v8;
-    const int sh_a = F16 ? amax_shift(a.amax_dy) : 0, sh_b = F16 ? amax_shift(a.amax_x) : 0;
+    // f16x3 operand scales: records requested first, consumed behind the first operand loads (see conv_igemm_split_kernel)
+    const unsigned am_a = F16 ? amax_fetch(a.amax_dy) : 0u, am_b = F16 ? amax_fetch(a.amax_x) : 0u;
+    int sh_a = 0, sh_b = 0;
+    auto take_scales = [&]() {
+        if (F16) { __builtin_amdgcn_sched_barrier(0); sh_a = amax_shift_of(am_a); sh_b = amax_shift_of(am_b); }
+    };
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
     constexpr int A_V = BM / 4, B_V = BN / 4;                 // float4 per pixel row
     constexpr int A_RP = 256 / A_V, B_RP = 256 / B_V;          // pixel rows per staging pass
@@ -1383,6 +1406,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
     if constexpr (KG == 1) {
         bool v0 = issue(RA0, RB0);
         bool v1 = v0 && issue(RA1, RB1);
+        take_scales();
         if (v0) {
 #pragma unroll
             for (int c = 0; c < CSTEPS; ++c) cstep(S0, RA0, RB0, 0, c);
@@ -1419,6 +1443,9 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
         if (nloc > 0) {
             issue_g(RA0, RB0);
             issue_g(RA1, RB1);
+        }
+        take_scales();
+        if (nloc > 0) {
 #pragma unroll
             for (int c = 0; c < CSTEPS; ++c) cstep(S0, RA0, RB0, 0, c);
             __syncthreads();
@@ -1737,11 +1764,20 @@ static int resolve_amax(OperandAmax& am, const float* a, int lda, long long Pa, 
     return DSRL_OK;
 }
 
+static void make_magic(int d, unsigned& m, unsigned& sh) {
+    if (d <= 1) { m = 0; sh = 255u; return; }
+    int l = 0;
+    while ((1ll << l) < d) ++l;
+    const unsigned long long k = 31 + l;
+    m = (unsigned)((((unsigned long long)1 << k) + (unsigned long long)d - 1) / (unsigned long long)d);
+    sh = (unsigned)(l - 1);
+}
 template <bool DGRAD>
 static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
     int bm, bn; cfg_dims(cfg, bm, bn);
     ConvArgs a = a_in;
     a.mtiles = (int)ceil_div(a.M, bm); a.ntiles = (int)ceil_div(a.K, bn);
+    make_magic(a.Ho * a.Wo, a.mHW, a.sHW); make_magic(a.Wo, a.mW, a.sW); make_magic(a.ntiles, a.mNT, a.sNT);
     a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
     dim3 grid((unsigned)(a.mtiles * a.ntiles), 1u, (unsigned)a.splits);
     const int npl = conv_planes(DGRAD ? PASS_DGRAD : PASS_FWD);
@@ -2147,14 +2183,6 @@ extern "C" int dsrl_conv2d_dgrad_accumulate(const float* dy, int lddy, const flo
     return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, 1);
 }
 
-static void make_magic(int d, unsigned& m, unsigned& sh) {
-    if (d <= 1) { m = 0; sh = 255u; return; }
-    int l = 0;
-    while ((1ll << l) < d) ++l;
-    const unsigned long long k = 31 + l;
-    m = (unsigned)((((unsigned long long)1 << k) + (unsigned long long)d - 1) / (unsigned long long)d);
-    sh = (unsigned)(l - 1);
-}
 static void launch_wgrad(const WgradArgs& a_in, TileCfg cfg, int bm, int bn, dim3 grid, hipStream_t st) {
     const int npl = conv_planes(PASS_WGRAD);
     const bool f16 = conv_f16();
