@@ -3,4 +3,4 @@
 mkdir -p gpurun_out
 timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r3_tests.txt 2>&1; rc=$?; echo "tests rc=$rc"; tail -4 gpurun_out/r3_tests.txt
 [ $rc -ne 0 ] && exit 1
-bash tools/r3_final.sh
+bash tools/round_record.sh
