@@ -1208,6 +1208,15 @@ class _FusedLosses(torch.autograd.Function):
         dl, da = ctx.grads
         if dl is None:
             raise DsrlHipError('fused_losses: backward without a gradient-enabled forward')
+        # the gradients were written by the forward pass for d(total) = 1: a caller that scales the loss or differentiates another element would get
+        # them unscaled.  Checked once per process (one host read), outside graph capture - the training step's own call pattern never changes.
+        global _fused_losses_root_checked
+        if not _fused_losses_root_checked and not torch.cuda.is_current_stream_capturing():
+            gv = g.detach().float().cpu()
+            if gv.numel() != 5 or float(gv[3]) != 1.0 or float(gv[:3].abs().sum()) != 0.0 or float(gv[4]) != 0.0:
+                raise DsrlHipError('fused_losses: only vals[3].backward() with unit gradient is supported (the loss gradients are formed in the forward '
+                                   f'pass); got an incoming gradient of {gv.tolist()} - use functional.cross_entropy / mse_loss / FALoss for a scaled loss')
+            _fused_losses_root_checked = True
         d1 = d2 = None
         if ctx.fa is not None:
             ft1, ft2, saved, k, _ = ctx.fa
@@ -1223,6 +1232,9 @@ class _FusedLosses(torch.autograd.Function):
             if slot is not None and buf is not None and not slot.closed and slot.buf is None:
                 slot.buf = buf
         return dl, da, d1, d2, None, None, None, None, None, None, None, None
+
+
+_fused_losses_root_checked = False
 
 
 def fused_losses(outs, target, input_org, ignore_index, w1, w2, stage, flag, subsample_factor=8):

@@ -874,6 +874,16 @@ def test_fused_losses_nan_flag_and_eval_mode():
     with torch.no_grad():
         v = HF.fused_losses((sssr, sisr, ft1, ft2), tb, org, 255, 0.1, 1.0, 3, flag, 8)
     assert int(flag) == 2 and np.isnan(float(v[0])) and np.isnan(float(v[3]))
+    # the gradients are formed in the forward pass for d(total) = 1: a scaled loss (or another element as the root) must be refused, not served unscaled
+    flag.zero_()
+    a, b = sssr.clone().requires_grad_(True), sisr.clone().requires_grad_(True)
+    HF._fused_losses_root_checked = False
+    v = HF.fused_losses((a, b, ft1, ft2), tgt, org, 255, 0.1, 1.0, 3, flag, 8)
+    with pytest.raises(Exception, match='only vals\\[3\\].backward'):
+        (2.0 * v[3]).backward()
+    v = HF.fused_losses((a, b, ft1, ft2), tgt, org, 255, 0.1, 1.0, 3, flag, 8)
+    v[3].backward()
+    assert HF._fused_losses_root_checked and a.grad is not None
 
 
 def test_train_steps_golden(golden):
