@@ -142,7 +142,10 @@ class TrainStep:
                 if in_graph and os.environ.get('DSRL_GRAPH_FAIL_TEST'):
                     raise RuntimeError('DSRL_GRAPH_FAIL_TEST: simulated failure in the middle of a capture')      # tests/test_rccl_gpu.py
                 if do_train:
-                    total.backward()                                                       # :444
+                    if self.fused_losses:
+                        HF.fused_losses_backward(vals)                                     # :444 (total.backward(), the root gradient a cached constant)
+                    else:
+                        total.backward()                                                   # :444
                     if split:
                         cuts = bb._dsrl_cut
                         HF.flush_wgrad_queue(reopen=True)      # the weight gradients of head, ASPP and layer4 as one grouped launch set

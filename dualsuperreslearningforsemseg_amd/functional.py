@@ -354,6 +354,23 @@ def _sink(param, like_shape=None):
     return param.grad
 
 
+def _sink_flat(param, n):
+    """The arena slot of `param` as the n-float output of its gradient kernel, when the parameter's memory is dense in logical order (biases,
+    ConvTranspose weights, the 1xCx1x1 feature-transformer filters) and this is its first gradient of the pass - else None.  The caller
+    launches the kernel into it and then calls _sunk(param): no temporary, no copy launch (they were 4-5 us each, ~10 per step)."""
+    owner = getattr(param, '_dsrl_arena', None)
+    if owner is None or not isinstance(param, torch.nn.Parameter) or param.grad is None:
+        return None
+    g = param.grad
+    if not g.is_cuda or g.numel() != n or not g.is_contiguous() or not owner.claim(param):
+        return None
+    return g
+
+
+def _sunk(param):
+    param._dsrl_arena.written(param)
+
+
 def _deliver(param, grad):
     """Hands a freshly computed parameter gradient to the arena instead of to autograd: when `param` lives in a ddp.FlatParams arena and this
     is its first gradient of the pass, the values are copied into its (zeroed) arena slot on the CURRENT stream, the reducer is told, and
@@ -644,10 +661,14 @@ class _Conv2d(torch.autograd.Function):
                     slot.closed = True      # a separate gradient is on its way to autograd: nobody may touch the published buffer any more
         if ctx.has_bias and ctx.needs_input_grad[2]:
             P = dy.shape[0] * dy.shape[2] * dy.shape[3]
-            db = torch.empty(K, device=x.device, dtype=torch.float32)
+            bsink = _sink_flat(ctx.bparam, K)
+            db = bsink if bsink is not None else torch.empty(K, device=x.device, dtype=torch.float32)
             ws = _ws(cquery('dsrl_colsum_workspace_bytes', P, K), x)
             call('dsrl_colsum', dy.data_ptr(), lddy, P, K, db.data_ptr(), ws.data_ptr(), ws.numel(), st)
-            db = _deliver(ctx.bparam, db)
+            if bsink is not None:
+                _sunk(ctx.bparam); db = None
+            else:
+                db = _deliver(ctx.bparam, db)
         if dw is not None:
             dw = _deliver(ctx.wparam, dw)
         return dx, dw, db, None, None, None, None, None, None
@@ -672,7 +693,13 @@ class _StemConv(torch.autograd.Function):
         xp = torch.empty((N, Hp, Wp, 4), device=x.device, dtype=torch.float32)
         sn, sc, sh, sw = x.stride()
         call('dsrl_pad_image_nhwc', x.data_ptr(), sn, sc, sh, sw, xp.data_ptr(), N, Cc, H, W, 4, pad, pad, Hp, Wp, st)
-        w2 = torch.zeros((K, R, Sp, 4), device=x.device, dtype=torch.float32)
+        # zero-padded [K][R][Sp][4] copy of the filter: the padding never changes, so the buffer is kept with the weight and only the filter taps are
+        # re-copied (one launch instead of a fill + a copy per step)
+        w2 = getattr(w, '_dsrl_stem_pad', None)
+        if w2 is None or tuple(w2.shape) != (K, R, Sp, 4) or w2.device != x.device:
+            w2 = torch.zeros((K, R, Sp, 4), device=x.device, dtype=torch.float32)
+            if isinstance(w, torch.nn.Parameter):
+                w._dsrl_stem_pad = w2
         w2[:, :, :S, :Cc] = w.detach().permute(0, 2, 3, 1)
         y = new_cl((N, K, Ho, Wo), x)
         macs = cquery('dsrl_conv2d_inbounds_macs', N, H, W, Cc, K, R, S, stride, pad, 1)
@@ -998,11 +1025,17 @@ class _ConvT2x2(torch.autograd.Function):
         Co = w.shape[1]
         dy = pm_dense(dy)
         dx = new_cl((N, Ci, H, W), x)
-        dw = torch.empty_like(w)
-        db = torch.empty(Co, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        wsink = _sink_flat(ctx.params[0], w.numel())
+        bsink = _sink_flat(ctx.params[1], Co) if ctx.has_bias else None
+        dw = wsink if wsink is not None else torch.empty_like(w)
+        db = (bsink if bsink is not None else torch.empty(Co, device=x.device, dtype=torch.float32)) if ctx.has_bias else None
         ws = _ws(cquery('dsrl_convt2x2_bwd_workspace_bytes', N, H, W, Ci, Co), x)
         call('dsrl_convt2x2_bwd', x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(),
              N, H, W, Ci, Co, ws.data_ptr(), ws.numel(), _stream())
+        if wsink is not None:
+            _sunk(ctx.params[0]); dw = None
+        if bsink is not None:
+            _sunk(ctx.params[1]); db = None
         return dx, _deliver(ctx.params[0], dw), _deliver(ctx.params[1], db)
 
 
@@ -1067,12 +1100,16 @@ class _PointwiseStrided(torch.autograd.Function):
         acc = (slot is not None and not slot.closed and slot.buf is not None and tuple(slot.buf.shape) == (N, Cc, H, W)
                and _ld_of(slot.buf) == Cc)
         dx = slot.buf if acc else new_cl((N, Cc, H, W), x)
-        dw = torch.empty(Cc, device=x.device, dtype=torch.float32)
+        wsink = _sink_flat(ctx.wparam, Cc)
+        dw = wsink if wsink is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
         ws = _ws(cquery('dsrl_pointwise_strided_bwd_workspace_bytes', N, H, W, Cc, ctx.stride), x)
         call('dsrl_pointwise_strided_bwd', x.data_ptr(), wf.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), int(acc),
              N, H, W, Cc, ctx.stride, ws.data_ptr(), ws.numel(), _stream())
         if slot is not None and not acc:
             slot.closed = True
+        if wsink is not None:
+            _sunk(ctx.wparam)
+            return (None if acc else dx), None, None, None
         return (None if acc else dx), _deliver(ctx.wparam, dw.view(ctx.wshape)), None, None
 
 
@@ -1221,7 +1258,7 @@ class _FusedLosses(torch.autograd.Function):
         if ctx.fa is not None:
             ft1, ft2, saved, k, _ = ctx.fa
             B, Cf, Hf, Wf = ft1.shape
-            gw = torch.full((1,), ctx.w2, device=ft1.device, dtype=torch.float32)
+            gw = _const1(ctx.w2, ft1.device)
             d1 = torch.empty((B, Cf, Hf, Wf), device=ft1.device, dtype=torch.float32)
             d2 = torch.empty_like(d1)
             sb, sc, sh, sw = ft1.stride()
@@ -1235,6 +1272,31 @@ class _FusedLosses(torch.autograd.Function):
 
 
 _fused_losses_root_checked = False
+_const_cache = {}
+
+
+def _const1(value, device):
+    """One-element fp32 device constant, created once per (value, device): a torch.full per step is a 5 us launch."""
+    key = (float(value), device)
+    c = _const_cache.get(key)
+    if c is None:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.full((1,), float(value), device=device, dtype=torch.float32)
+        c = _const_cache[key] = torch.full((1,), float(value), device=device, dtype=torch.float32)
+    return c
+
+
+def fused_losses_backward(vals):
+    """vals[3].backward() without autograd's select / ones / zeros launches at the root of the pass: the unit gradient of element 3 is a
+    cached constant."""
+    key = ('e3', vals.device)
+    e3 = _const_cache.get(key)
+    if e3 is None:
+        if torch.cuda.is_current_stream_capturing():
+            vals[3].backward()
+            return
+        e3 = _const_cache[key] = torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0], device=vals.device, dtype=torch.float32)
+    torch.autograd.backward([vals], [e3])
 
 
 def fused_losses(outs, target, input_org, ignore_index, w1, w2, stage, flag, subsample_factor=8):

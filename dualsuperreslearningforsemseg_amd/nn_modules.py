@@ -60,6 +60,15 @@ class HipDropout(nn.Dropout):
 
 
 class HipConvTranspose2d(nn.ConvTranspose2d):
+    def _apply(self, fn, *args, **kwargs):
+        # model.to(memory_format=channels_last) re-lays every 4-D parameter; the k2s2 kernels read this (Cin,Cout,2,2) filter in its logical order,
+        # so it is kept contiguous here instead of being copied by a .contiguous() launch in every forward and backward
+        r = super()._apply(fn, *args, **kwargs)
+        if self.weight.dim() == 4 and not self.weight.is_contiguous():
+            with torch.no_grad():
+                self.weight.data = self.weight.data.contiguous()
+        return r
+
     def forward(self, x):
         if self.kernel_size != (2, 2) or self.stride != (2, 2) or self.padding != (0, 0) or self.output_padding != (0, 0) or self.groups != 1:
             raise HF.DsrlHipError('HipConvTranspose2d implements kernel_size=2, stride=2, padding=0 (DSRL.py:55-69)')
