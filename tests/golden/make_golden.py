@@ -315,13 +315,13 @@ def golden_head_256x512():
     print('head_256x512.npz', out['losses'], out['margin_q'])
 
 
-def golden_head_train_256x512():
-    """BASELINE's actual workload shape in TRAIN mode (round 3): 256x512 input -> 512x1024 logits, B=2, BatchNorm batch statistics over
-    16x32 / 64x128 feature maps, Dropout modules in eval (set_mode), stage 3: the loss tuple, a strided logits / SISR sample, and for EVERY
-    head parameter and both backbone-feature inputs the gradient of Total = CE + 0.1 MSE + FA (small tensors whole, large ones as a
-    strided 4096-sample plus the order-independent checksum)."""
+def golden_head_train(fname='head_train_256x512.npz', pseed=909, iseed=1010, h16=16, w16=32):
+    """BASELINE's actual workload shape in TRAIN mode (round 3): 256x512 input -> 512x1024 logits (h16 x w16 = 16 x 32; `train512`: config 5's
+    512x1024 -> 1024x2048, 32 x 64), B=2, BatchNorm batch statistics, Dropout modules in eval (set_mode), stage 3: the loss tuple, a strided
+    logits / SISR sample, and for EVERY head parameter and both backbone-feature inputs the gradient of Total = CE + 0.1 MSE + FA (small tensors
+    whole, large ones as a strided 4096-sample plus the order-independent checksum)."""
     out = {}
-    head, outs, L, grads = run_head(gen.FULL, 3, 909, 1010, 2, 16, 32, True, True)
+    head, outs, L, grads = run_head(gen.FULL, 3, pseed, iseed, 2, h16, w16, True, True)
     out['losses'] = np.array([float(x.detach()) for x in L], dtype=np.float64)
     out['SSSR_sample'] = gen.strided_sample(np_(outs[0]), 1 << 16)
     out['SISR_sample'] = gen.strided_sample(np_(outs[1]), 1 << 14)
@@ -335,8 +335,8 @@ def golden_head_train_256x512():
     # The SAME reference modules in float64 on the same inputs: the backward pass through batch-statistics BatchNorm cancels heavily, and the
     # reference's own fp32 gradients are 1e-3 .. 2e-2 of their range away from these (err32.*) - a bound on "as accurate as the reference"
     # needs the exact values next to the fp32 ones.
-    P = gen.make_head_params(909, gen.FULL, 3)
-    x16, x4, target, org = gen.make_head_inputs(1010, 2, 16, 32, gen.FULL)
+    P = gen.make_head_params(pseed, gen.FULL, 3)
+    x16, x4, target, org = gen.make_head_inputs(iseed, 2, h16, w16, gen.FULL)
     head64 = RefHead(gen.FULL, 3)
     load_params(head64, P)
     head64 = head64.double()
@@ -357,8 +357,17 @@ def golden_head_train_256x512():
     for k, v in head.state_dict().items():
         if 'running_' in k and v.numel() <= 256:
             out[f'new.{k}'] = np_(v)
-    np.savez_compressed(os.path.join(HERE, 'head_train_256x512.npz'), **out)
-    print('head_train_256x512.npz', out['losses'], len(out), 'arrays')
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, out['losses'], len(out), 'arrays')
+
+
+def golden_head_train_256x512():
+    golden_head_train()
+
+
+def golden_head_train_512x1024():
+    """The same at BASELINE config 5's size (round 3): 512x1024 input -> 1024x2048 logits, B=2, train mode."""
+    golden_head_train('head_train_512x1024.npz', 1111, 1212, 32, 64)
 
 
 def golden_head_512x1024():
@@ -451,6 +460,8 @@ if __name__ == '__main__':
         golden_head_512x1024(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'train256':
         golden_head_train_256x512(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'train512':
+        golden_head_train_512x1024(); sys.exit(0)
     golden_pipeline_and_metrics()
     golden_fa()
     golden_ops()
@@ -459,4 +470,5 @@ if __name__ == '__main__':
     golden_head_256x512()
     golden_head_512x1024()
     golden_head_train_256x512()
+    golden_head_train_512x1024()
     golden_train_steps()

@@ -279,21 +279,22 @@ def test_torch_cpu_baseline_graph_vs_reference(golden, mode):
     close(np.array([float(v) for v in L]), g[f'{mode}.losses'], 1e-4)
 
 
-def test_torch_cpu_baseline_graph_vs_reference_train_256x512(golden):
-    """The same graph on the reference-generated TRAIN-mode vectors of BASELINE's real shape (256x512 input, B=2, batch-statistics BatchNorm):
-    losses, logits sample and every head gradient (tests/golden/make_golden.py: golden_head_train_256x512)."""
+@pytest.mark.parametrize('fixture,pseed,iseed,h16,w16', [('head_train_256x512', 909, 1010, 16, 32), ('head_train_512x1024', 1111, 1212, 32, 64)])
+def test_torch_cpu_baseline_graph_vs_reference_train(golden, fixture, pseed, iseed, h16, w16):
+    """The same graph on the reference-generated TRAIN-mode vectors of BASELINE's real shapes (256x512 input, and config 5's 512x1024; B=2,
+    batch-statistics BatchNorm): losses, logits sample and every head gradient (tests/golden/make_golden.py: golden_head_train)."""
     import torch
     from oracle.torch_cpu_model import TorchCpuDSRL, total_loss
-    g = golden('head_train_256x512')
+    g = golden(fixture)
     model = TorchCpuDSRL(3)
-    sd = {k: torch.from_numpy(v) for k, v in gen.make_head_params(909, gen.FULL, 3).items()}
+    sd = {k: torch.from_numpy(v) for k, v in gen.make_head_params(pseed, gen.FULL, 3).items()}
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected
     model.train()
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.eval()
-    x16, x4, target, org = gen.make_head_inputs(1010, 2, 16, 32, gen.FULL)
+    x16, x4, target, org = gen.make_head_inputs(iseed, 2, h16, w16, gen.FULL)
     a, b = torch.from_numpy(x16).requires_grad_(True), torch.from_numpy(x4).requires_grad_(True)
     outs = model.forward_head(a, b)
     L = total_loss(outs, torch.from_numpy(target), torch.from_numpy(org), 3)
