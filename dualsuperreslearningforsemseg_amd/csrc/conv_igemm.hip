@@ -489,13 +489,14 @@ void conv_igemm_split_kernel(const ConvArgs a) {
         }
         tap = __builtin_ctzll(rem_mask);
     }
-    auto advance = [&](int n) {                 // wave-uniform; only ever asked to step onto an existing chunk
-        for (int i = 0; i < n; ++i, ++pos)
-            if (++cc == a.cchunks) { cc = 0; rem_mask &= rem_mask - 1; tap = __builtin_ctzll(rem_mask); }
+    auto advance = [&](int n) {                 // wave-uniform; only ever asked to step onto an existing chunk.  O(taps crossed), not O(n): a K-group
+        cc += n; pos += n;                      // block steps KG chunks at a time, and this sits between a wave's last MFMA and its barrier
+        while (cc >= a.cchunks) { cc -= a.cchunks; rem_mask &= rem_mask - 1; tap = __builtin_ctzll(rem_mask); }
     };
     unsigned a_off[A_IT];
+    const unsigned inv_s = 65536u / (unsigned)a.S + 1u;        // t / S without a divide for t < 64, S <= 8 (checked exhaustively): set_tap runs inside the K loop
     auto set_tap = [&](int t) {
-        const int r = t / a.S, s = t - r * a.S;
+        const int r = a.S <= 8 ? (int)(((unsigned)t * inv_s) >> 16) : t / a.S, s = t - r * a.S;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             int hi, wi; bool ok = a_ok[i];
