@@ -244,11 +244,11 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
     auto gload = [&](float4* ra, float4* rb, int t, int ch) {
         const int c = ch * BK + c4 * 4;
         const unsigned coff = c < a.C ? (unsigned)c * 4u : kOOB;          // channel tail of the last chunk reads as zeros
-        const unsigned woff = coff + (unsigned)(t * a.C) * 4u;
+        const unsigned woff = __builtin_elementwise_add_sat(coff, (unsigned)(t * a.C) * 4u);       // saturating: two out-of-range parts must not wrap back into range
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) ra[i] = buf_load4(xr, a_off[i] + coff);
+        for (int i = 0; i < A_IT; ++i) ra[i] = buf_load4(xr, __builtin_elementwise_add_sat(a_off[i], coff));
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) rb[i] = buf_load4(wr, b_off[i] + woff);
+        for (int i = 0; i < B_IT; ++i) rb[i] = buf_load4(wr, __builtin_elementwise_add_sat(b_off[i], woff));
     };
 
     const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
@@ -515,31 +515,32 @@ void conv_igemm_split_kernel(const ConvArgs a) {
     float4 R0[NV][2], R1[NV][2];
 #pragma unroll
     for (int v = 0; v < NV; ++v) { R0[v][0] = R0[v][1] = R1[v][0] = R1[v][1] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    auto gload = [&](float4 (*R)[2], int t, int ch) {
+    // Offsets are added with unsigned saturation: a padding pixel (a_off = kOOB) in the channel tail (coff = kOOB) must stay out of range instead of
+    // wrapping to offset 0 (its product is multiplied by a zero filter value, but a NaN at x[0] would have leaked into border outputs).
+    auto gload = [&](float4 (*R)[2], int t, int ch, unsigned dead) {          // dead: 0, or kOOB = every load of the set out of range (zeros)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int c = ch * 32 + hf * 16 + c4 * 4;
-            const unsigned coff = c < a.C ? (unsigned)c * 4u : kOOB;          // channel tail of the last chunk reads as zeros
-            const unsigned woff = coff + (unsigned)(t * a.C) * 4u;
+            const unsigned coff = (c < a.C ? (unsigned)c * 4u : kOOB) | dead;   // channel tail of the last chunk reads as zeros
+            const unsigned woff = __builtin_elementwise_add_sat(coff, (unsigned)(t * a.C) * 4u);
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) R[i][hf] = buf_load4(xr, a_off[i] + coff);
+            for (int i = 0; i < A_IT; ++i) R[i][hf] = buf_load4(xr, __builtin_elementwise_add_sat(a_off[i], coff));
 #pragma unroll
-            for (int i = 0; i < B_IT; ++i) R[A_IT + i][hf] = buf_load4(wr, b_off[i] + woff);
+            for (int i = 0; i < B_IT; ++i) R[A_IT + i][hf] = buf_load4(wr, __builtin_elementwise_add_sat(b_off[i], woff));
         }
     };
     int nextq = q0 + grp, tap_set = -1;         // next chunk of this group; tap whose a_off[] is current
+    // Every call issues the same NV * 2 loads - past the end of the group's (or the block's) chunks with out-of-range offsets, which return zeros: an
+    // exhausted K group keeps iterating with the others on zero operands, and the compiler can count the loads in flight (with a path that issues
+    // none it must assume the fewest: its s_waitcnt in front of the older register set then also drained the set issued a moment ago).
     auto issue = [&](float4 (*R)[2]) {
-        if (nextq >= q1) {
-            if (KG > 1) {                           // an exhausted group keeps iterating with the others: feed it zeros
-#pragma unroll
-                for (int v = 0; v < NV; ++v) R[v][0] = R[v][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            return;
+        const bool live = nextq < q1;
+        if (live) {
+            advance(nextq - pos);
+            if (tap != tap_set) { set_tap(tap); tap_set = tap; }
+            nextq += KG;
         }
-        advance(nextq - pos);
-        if (tap != tap_set) { set_tap(tap); tap_set = tap; }
-        gload(R, tap, cc);
-        nextq += KG;
+        gload(R, tap, cc, live ? 0u : kOOB);
     };
 
     // ---- LDS addressing (swizzle: 16-byte half h of row r lives at half h ^ bit3(r))
@@ -1145,7 +1146,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs a) 
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int p = pb + a_row + i * A_RP;
-            ra[i] = buf_load4(dr, (p < Pi ? (unsigned)p * (unsigned)a.lddy * 4u : kOOB) + a_coff);
+            ra[i] = buf_load4(dr, __builtin_elementwise_add_sat(p < Pi ? (unsigned)p * (unsigned)a.lddy * 4u : kOOB, a_coff));
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
@@ -1157,7 +1158,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs a) 
                 const int hi = ho * a.stride + dh, wi = wo * a.stride + dw_;
                 if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) off = (unsigned)((n * a.H + hi) * a.W + wi) * (unsigned)a.ldx * 4u;
             }
-            rb[i] = buf_load4(xr, off + b_coff);
+            rb[i] = buf_load4(xr, __builtin_elementwise_add_sat(off, b_coff));
         }
     };
     // a 32-pixel chunk whose pixels all read zero padding for this tap contributes nothing: skip it (block-uniform test)
@@ -1302,7 +1303,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int p = pb + a_row + i * A_RP;
-            ra[i] = buf_load4(dr, (p < Pi ? (unsigned)p * (unsigned)g_lddy * 4u : kOOB) + a_coff);
+            ra[i] = buf_load4(dr, __builtin_elementwise_add_sat(p < Pi ? (unsigned)p * (unsigned)g_lddy * 4u : kOOB, a_coff));
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
@@ -1314,7 +1315,7 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
                 const int hi = ho * g_stride + dh, wi = wo * g_stride + dw_;
                 if (hi >= 0 && hi < g_H && wi >= 0 && wi < g_W) off = (unsigned)((n * g_H + hi) * g_W + wi) * (unsigned)g_ldx * 4u;
             }
-            rb[i] = buf_load4(xr, off + b_coff);
+            rb[i] = buf_load4(xr, __builtin_elementwise_add_sat(off, b_coff));
         }
     };
     // a 32-pixel chunk whose pixels all read zero padding for this tap contributes nothing: skip it (block-uniform test)

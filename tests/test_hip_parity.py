@@ -135,6 +135,24 @@ def test_f16x3_operand_ranges(case):
         assert not host(xt.grad).any() and not host(wt.grad).any()
 
 
+@pytest.mark.parametrize('mode', ['f16x3', 'bf16x6', 'fp32'])
+def test_nan_at_first_element_stays_local_with_a_channel_tail(mode):
+    """Padding taps and the channel tail of the last 32-channel chunk are both served by out-of-range buffer offsets; their sum must stay out of
+    range (saturating add) instead of wrapping to offset 0: a NaN in x[0, 0:4, 0, 0] may only reach the outputs pixel (0, 0) touches, like in the
+    fp64 oracle - not every border pixel (round 3)."""
+    N, C, H, W, K, R, stride, pad, dil = 2, 48, 12, 16, 64, 3, 1, 1, 1
+    rs = np.random.RandomState(11)
+    x = rs.standard_normal((N, C, H, W)).astype(np.float32); x[0, 0:4, 0, 0] = np.nan
+    w = (rs.standard_normal((K, C, R, R)) / np.sqrt(C * R * R)).astype(np.float32)
+    HF.set_conv_precision(mode)
+    try:
+        y = host(HF.conv2d(dev(x), dev(w), None, stride, pad, dil))
+    finally:
+        HF.set_conv_precision(None)
+    yo = O.conv2d(x.astype(np.float64), w.astype(np.float64), None, stride, pad, dil)
+    assert np.array_equal(np.isnan(y), np.isnan(yo)), (int(np.isnan(y).sum()), int(np.isnan(yo).sum()))
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 16, 24, 96, 3, 1, 1, 1), (2, 304, 16, 32, 192, 3, 1, 1, 1), (1, 256, 32, 64, 19, 1, 1, 0, 1), (4, 1024, 16, 32, 256, 1, 1, 0, 1),
                                    (2, 128, 16, 32, 128, 3, 2, 1, 1), (2, 512, 16, 32, 256, 3, 1, 6, 6)])
 def test_f16x3_presplit_filters_match_on_the_fly(shape):
