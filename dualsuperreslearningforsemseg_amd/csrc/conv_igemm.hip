@@ -76,7 +76,10 @@ __device__ __forceinline__ int amax_shift(const unsigned* p) { return amax_shift
 
 // q = n / d for 0 <= n < 2^31: m = ceil(2^(31+l) / d) with l = ceil(log2 d) >= 1, q = mulhi(n, m) >> (l - 1), exact; d = 1 is
 // flagged by shift 255 (host side: make_magic)
-__device__ __forceinline__ int fast_div(int n, unsigned m, unsigned s) { return s == 255u ? n : (int)(__umulhi((unsigned)n, m) >> s); }
+__device__ __forceinline__ int fast_div(int n, unsigned m, unsigned s) {       // a select, not a branch: it sits inside the K loops (scalar and vector)
+    const int q = (int)(__umulhi((unsigned)n, m) >> (s & 31u));
+    return s == 255u ? n : q;
+}
 
 struct ConvArgs {
     const float* x; const float* w; const float* bias; float* y;
@@ -1319,7 +1322,9 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int b
         }
     };
     // a 32-pixel chunk whose pixels all read zero padding for this tap contributes nothing: skip it (block-uniform test)
+    const bool tap_centred = dh == 0 && dw_ == 0;        // 1x1 convs and centre taps never read padding: no liveness test in their K loop
     auto chunk_live = [&](int ch) -> bool {
+        if (tap_centred) return true;
         const int pf = ch * 32, pl = min(pf + 32, Pi) - 1;
         const int nf = fast_div(pf, g_mHW, g_sHW), nl = fast_div(pl, g_mHW, g_sHW);
         if (nf != nl) return true;
