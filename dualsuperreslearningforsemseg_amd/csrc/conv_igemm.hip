@@ -582,17 +582,23 @@ void conv_igemm_split_kernel(const ConvArgs a) {
     constexpr int MPS = NMFMA / CSTEPS > 0 ? NMFMA / CSTEPS : 1;
     auto pipe = [&](const char* cur, char* nxt, float4 (*R)[2], int hf) {
         // every fragment read first (the compiler cannot prove the two stages disjoint: a read placed after a write would wait)
+        // in the order the MFMAs below need them (LDS reads return in order, so the first MFMA waits for two reads, not for all of them): the last
+        // plane of the filter fragments, the first plane of the pixel fragments, then the rest
         pl8 fa[MR][NPL], fb[NR][NPL];
+        auto rd_a = [&](int i, int pl) { fa[i][pl] = *reinterpret_cast<const pl8*>(cur + (pl * BM + (wm * MR + i) * 32 + frag_row) * ROWB + r_swz); };
+        auto rd_b = [&](int j, int pl) { fb[j][pl] = *reinterpret_cast<const pl8*>(cur + (NPL * BM + pl * BN + (wn * NR + j) * 32 + frag_row) * ROWB + r_swz); };
 #pragma unroll
-        for (int i = 0; i < MR; ++i)
+        for (int j = 0; j < NR; ++j) rd_b(j, NPL - 1);
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl)
-                fa[i][pl] = *reinterpret_cast<const pl8*>(cur + (pl * BM + (wm * MR + i) * 32 + frag_row) * ROWB + r_swz);
+        for (int i = 0; i < MR; ++i) rd_a(i, 0);
 #pragma unroll
-        for (int j = 0; j < NR; ++j)
+        for (int pl = 1; pl < NPL; ++pl)
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl)
-                fb[j][pl] = *reinterpret_cast<const pl8*>(cur + (NPL * BM + pl * BN + (wn * NR + j) * 32 + frag_row) * ROWB + r_swz);
+            for (int i = 0; i < MR; ++i) rd_a(i, pl);
+#pragma unroll
+        for (int pl = NPL - 2; pl >= 0; --pl)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) rd_b(j, pl);
         __builtin_amdgcn_sched_barrier(0);
         int m = 0;
         // small terms first; consecutive MFMAs go to different accumulator tiles; a convert step after every MPS-th MFMA
