@@ -40,6 +40,8 @@ PROTOTYPES = {
     'dsrl_conv2d_transposed_filter_floats': (sz, [i32] * 4),
     'dsrl_conv2d_transpose_filter': (i32, [fp, fp, i32, i32, i32, i32, stream_t]),
     'dsrl_conv2d_transpose_filters_batched': (i32, [fp, i32, i64, stream_t]),
+    'dsrl_conv2d_filters_amax_segment_floats': (i32, []),
+    'dsrl_conv2d_filters_amax_batched': (i32, [fp, i64, stream_t]),
     'dsrl_conv2d_dgrad': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv2d_dgrad_stats_parts': (i32, _conv_shape),
     'dsrl_conv2d_dgrad_bnstats': (i32, [fp, i32, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, fp, i32, fp, fp, i32, fp, i32, i32, stream_t]),

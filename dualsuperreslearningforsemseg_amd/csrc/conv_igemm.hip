@@ -1027,6 +1027,29 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     }
 }
 
+// max |w| of every filter of the model in ONE streaming launch (round 3; the batched transpose in its "amax only" form walked 32 x 32 tiles through LDS
+// at 1.7 TB/s just to take a maximum): a block takes one segment {pointer, floats (<= kAmaxSegFloats), amax record} of a filter's contiguous
+// [K][R][S][C] storage and maxes it into that filter's record (zeroed by the caller).  Table: nseg rows of 3 int64.
+constexpr int kAmaxSegFloats = 8192;
+__global__ __launch_bounds__(256) void weight_amax_batched_kernel(const long long* __restrict__ table) {
+    const long long* e = table + 3ll * blockIdx.x;
+    const float* w = reinterpret_cast<const float*>(e[0]);
+    const int n = (int)e[1];
+    unsigned* rec = reinterpret_cast<unsigned*>(e[2]);
+    unsigned m = 0u;
+    if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        const int n4 = n >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            const float4 v = reinterpret_cast<const float4*>(w)[i];
+            m = abs_bits4(m, v.x, v.y, v.z, v.w);
+        }
+        for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) m = max(m, abs_bits(w[i]));
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) m = max(m, abs_bits(w[i]));
+    }
+    amax_publish(m, rec);
+}
+
 // Filters in "plane" form for the f16x3 kernels (ARITH = 2), all filters of the model in one launch, once per training step behind
 // weight_transpose_batched_kernel (which leaves every filter's amax record): for each 32 x 32 (k, c) tile of a tap, w_split [K][RS][C] and
 // wt_split [C][RS][Kp] receive, per 4 consecutive elements of the contiguous dimension, the 4 first terms f16(v * 2^e) followed by the 4
@@ -2100,6 +2123,15 @@ extern "C" int dsrl_conv2d_transpose_filters_batched(const int64_t* table, int n
     hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)ceil_div(total_tiles, (int64_t)kWtTilesPerBlock)), dim3(256), 0, st, (const long long*)table, n,
                        (long long)total_tiles);
     return launch_status("weight_transpose_batched_kernel");
+}
+
+extern "C" int dsrl_conv2d_filters_amax_segment_floats(void) { return kAmaxSegFloats; }
+extern "C" int dsrl_conv2d_filters_amax_batched(const int64_t* table, int64_t nseg, dsrl_stream_t stream) {
+    DSRL_REQUIRE(table && nseg > 0 && nseg < (1ll << 31), DSRL_E_BADARG, "conv2d_filters_amax_batched: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(weight_amax_batched_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const long long*)table);
+    return launch_status("weight_amax_batched_kernel");
 }
 
 struct DgradBn { const float* x; const float* y; const float* mean; const float* invstd; float* stats; int ldx, ldy, relu; };

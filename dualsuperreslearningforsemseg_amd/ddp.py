@@ -205,6 +205,15 @@ class FlatParams:
         amax_only = base.clone()
         amax_only[:, 1] = 0                     # no transposed fp32 copy
         self._amax_only_table = amax_only.to(self.device)
+        # the records alone, by a streaming launch over segments of every filter's contiguous storage (dsrl_conv2d_filters_amax_batched)
+        seg = int(HF.query('dsrl_conv2d_filters_amax_segment_floats'))
+        segs = []
+        for i, (w, K, Kp, RS, C, off) in enumerate(self._split_entries):
+            n, rec = w.numel(), self.w_amax.data_ptr() + 4 * HF.AMAX_WORDS * i
+            for a in range(0, n, seg):
+                segs.append([w.data_ptr() + 4 * a, min(seg, n - a), rec])
+        self._amax_seg_table = torch.tensor(segs, dtype=torch.int64, device=self.device)
+        self._amax_segs = len(segs)
 
     def refresh_transposed_filters(self):
         if self._wt_table is not None and os.environ.get('DSRL_BATCHED_TRANSPOSE', '1') != '0':
@@ -213,7 +222,10 @@ class FlatParams:
             if presplit and self._split_table is None:
                 self._build_split_filters()
             # with pre-split filters nothing reads the fp32 transposes: the first launch then only measures (amax records), the second writes both split forms
-            HF.call('dsrl_conv2d_transpose_filters_batched', (self._amax_only_table if presplit else self._wt_table).data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
+            if presplit and os.environ.get('DSRL_FILTER_AMAX_STREAM', '1') != '0':
+                HF.call('dsrl_conv2d_filters_amax_batched', self._amax_seg_table.data_ptr(), self._amax_segs, HF._stream())
+            else:
+                HF.call('dsrl_conv2d_transpose_filters_batched', (self._amax_only_table if presplit else self._wt_table).data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
             if presplit:
                 HF.call('dsrl_conv2d_split_filters_batched', self._split_table.data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
             self.wt_valid, self.wt_fp32_valid, self.split_valid = True, not presplit, presplit

@@ -74,6 +74,13 @@ int dsrl_conv2d_transpose_filter(const float* w, float* wt, int C, int K, int R,
  * (DSRL_AMAX_WORDS uint32, zeroed by the caller before the launch) into which the launch maxes the bit pattern of max |w| of that filter:
  * the filter's operand magnitude for the "f16x3" arithmetic (dsrl_amax, dsrl_conv2d_*_amax below). */
 int dsrl_conv2d_transpose_filters_batched(const int64_t* table, int n, int64_t total_tiles, dsrl_stream_t stream);
+/* The amax records of all filters in one streaming launch (what the transpose above leaves as a by-product, without the transposes: the per-step filter
+ * pass of the "f16x3" arithmetic needs only the records and the split forms below).  table: nseg rows of 3 int64 {pointer into a filter's contiguous
+ * [K][R][S][C] storage, number of floats of this segment (<= dsrl_conv2d_filters_amax_segment_floats()), amax record of that filter}; the caller
+ * zeroes the records; a filter is cut into as many segments as it needs. */
+int dsrl_conv2d_filters_amax_segment_floats(void);
+int dsrl_conv2d_filters_amax_batched(const int64_t* table, int64_t nseg, dsrl_stream_t stream);
+
 /* Filters pre-split for the "f16x3" arithmetic, all filters in one launch behind the transpose above (which leaves the amax records this
  * launch scales by): table rows {w, wt_split, K, Kp, R*S, C, first tile, ceil(C/32), amax record, w_split}; w_split [K][R][S][C] and
  * wt_split [C][R][S][Kp] (either may be 0) hold, per 4 consecutive elements of the last dimension, the 4 fp16 first terms of v * 2^e

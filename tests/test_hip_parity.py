@@ -1029,6 +1029,24 @@ def test_batched_filter_transposes_match_per_layer_path():
     assert not bad, bad
 
 
+def test_streaming_filter_amax_equals_transposing_pass(monkeypatch):
+    """The per-step filter pass of the f16x3 arithmetic measures max |w| of every filter with one streaming launch (dsrl_conv2d_filters_amax_batched);
+    its records must hold exactly the values the batched transpose leaves (the maximum over the 16 shards of a record, = max |w| of the filter)."""
+    from dualsuperreslearningforsemseg_amd.ddp import FlatParams
+    head, _ = make_head(gen.FULL, 3, 909, True)
+    flat = FlatParams(head)
+    vals = {}
+    for stream in ('1', '0'):
+        monkeypatch.setenv('DSRL_FILTER_AMAX_STREAM', stream)
+        flat.wt_valid = False
+        flat.refresh_transposed_filters()
+        torch.cuda.synchronize()
+        vals[stream] = flat.w_amax.view(-1, HF.AMAX_WORDS).max(dim=1).values.cpu().numpy().copy()
+    assert flat._amax_segs > flat._wt_rows and np.array_equal(vals['1'], vals['0'])
+    expect = np.array([np.abs(host(w)).max() for w, *_ in flat._split_entries], dtype=np.float32).view(np.int32)
+    assert np.array_equal(vals['1'].astype(np.int32), expect)
+
+
 def test_grad_slots_match_autograd_accumulation():
     """Bottleneck inputs: the residual-branch gradient and conv1's (or the downsample conv's) data gradient accumulated in one buffer
     by the dgrad epilogue (functional.GradSlot, dsrl_conv2d_dgrad_accumulate) equal autograd's separate sum on the whole backbone +
