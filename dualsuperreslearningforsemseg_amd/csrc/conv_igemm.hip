@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
 // max |w| of every filter of the model in ONE streaming launch (round 3; the batched transpose in its "amax only" form walked 32 x 32 tiles through LDS
 // at 1.7 TB/s just to take a maximum): a block takes one segment {pointer, floats (<= kAmaxSegFloats), amax record} of a filter's contiguous
 // [K][R][S][C] storage and maxes it into that filter's record (zeroed by the caller).  Table: nseg rows of 3 int64.
-constexpr int kAmaxSegFloats = 8192;
+constexpr int kAmaxSegFloats = 32768;
 __global__ __launch_bounds__(256) void weight_amax_batched_kernel(const long long* __restrict__ table) {
     const long long* e = table + 3ll * blockIdx.x;
     const float* w = reinterpret_cast<const float*>(e[0]);
