@@ -56,6 +56,12 @@ PROTOTYPES = {
     'dsrl_conv2d_fwd_amax': (i32, [fp, i32, fp, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, stream_t]),
     'dsrl_conv2d_dgrad_amax': (i32, [fp, i32, fp, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, fp, i32, fp, fp, i32, fp, i32, i32, stream_t]),
     'dsrl_conv2d_split_filters_batched': (i32, [fp, i32, i64, stream_t]),
+    'dsrl_planes_lo_offset': (sz, [i64]),
+    'dsrl_planes_bytes': (sz, [i64, i32]),
+    'dsrl_split_planes': (i32, [fp, i32, i64, i32, fp, fp, i32, stream_t]),
+    'dsrl_conv2d_filter_planes_batched': (i32, [fp, i32, i64, stream_t]),
+    'dsrl_conv2d_fwd_planes': (i32, [fp, i32, fp, fp, fp, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, stream_t]),
+    'dsrl_conv2d_dgrad_planes': (i32, [fp, i32, fp, fp, fp, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, fp, i32, fp, fp, i32, fp, i32, i32, stream_t]),
     'dsrl_conv2d_wgrad_amax': (i32, [fp, i32, fp, fp, i32, fp, fp] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv_precision': (i32, [i32]),
     'dsrl_conv2d_inbounds_macs': (i64, _conv_shape),

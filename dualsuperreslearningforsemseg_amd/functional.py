@@ -418,6 +418,31 @@ def split_filter(w):
     return rec, wsp, wtsp, wt
 
 
+def planes_of(data, ld, amax, nplanes=2):
+    """fp16 planes (include/dsrl_hip.h: dsrl_split_planes) of the pixel-major tensor `data` (N,C,H,W; pixel stride ld), scaled by the amax record
+    `amax`: a uint8 buffer holding [P][ld] fp16 first terms and, dsrl_planes_lo_offset(P * ld) bytes further, the second terms."""
+    N, Cc, H, W = data.shape
+    P = N * H * W
+    buf = torch.empty(int(cquery('dsrl_planes_bytes', P * ld, nplanes)), device=data.device, dtype=torch.uint8)
+    call('dsrl_split_planes', data.data_ptr(), ld, P, Cc, amax.data_ptr(), buf.data_ptr(), nplanes, _stream())
+    return buf
+
+
+def filter_planes(w, rec):
+    """(w_planes [K][R][S][C], wt_planes [C][R][S][K]) of one filter, scaled by its amax record `rec`: what ddp.FlatParams prepares for every
+    filter once per step (dsrl_conv2d_filter_planes_batched), here for a single tensor.  K and C must be multiples of 8."""
+    w = w_cl(w)
+    K, C, R, S = w.shape
+    RS, ct = R * S, (C + 31) // 32
+    tiles = RS * ct * ((K + 31) // 32)
+    nbytes = int(cquery('dsrl_planes_bytes', K * RS * C, 2))
+    wp = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    wtp = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    t = torch.tensor([[w.data_ptr(), wtp.data_ptr(), K, K, RS, C, 0, ct, rec.data_ptr(), wp.data_ptr()]], dtype=torch.int64, device=w.device)
+    call('dsrl_conv2d_filter_planes_batched', t.data_ptr(), 1, tiles, _stream())
+    return wp, wtp
+
+
 def _is_krsc(w):
     """Is the (K,C,R,S) filter physically [K][R][S][C]?  (torch does not call plain-strided 1x1 filters channels_last although the
     two layouts coincide for them)"""

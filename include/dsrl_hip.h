@@ -153,6 +153,29 @@ int dsrl_conv2d_dgrad_amax(const float* dy, int lddy, const uint32_t* dy_amax, c
                            void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y, int bn_ldy,
                            const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats /*nullable*/, int stats_parts, int accumulate,
                            dsrl_stream_t stream);
+/* fp16 PLANES (round 4): an operand tensor of the "f16x3" arithmetic stored as its two terms, hi = f16(v * 2^e) and lo = f16(v * 2^e - hi) with e from
+ * the tensor's amax record, each plane with the tensor's own indexing ([P][ld] fp16 for a pixel-major activation, [K][R][S][C] / [C][R][S][K] for a filter
+ * and its transpose); the second plane starts dsrl_planes_lo_offset(elements of one plane) bytes behind the first. The conv kernels then stage operands by
+ * LDS-DMA (buffer_load ... lds) without conversion. dsrl_planes_bytes: size of a plane buffer (nplanes 1 or 2).
+ * dsrl_split_planes: planes of a pixel-major fp32 tensor (C and ld multiples of 8, 16-byte aligned), scaled by `amax` (a measured record, see dsrl_amax).
+ * dsrl_conv2d_filter_planes_batched: all filters of a model in one launch; table rows of 10 int64 {w, wt_planes, K, unused, R*S, C, first tile,
+ * ceil(C/32), amax record, w_planes} with tiles counted as R*S * ceil(C/32) * ceil(K/32) per filter; K and C multiples of 8; either pointer may be 0.
+ * dsrl_conv2d_fwd_planes / _dgrad_planes: dsrl_conv2d_fwd_amax / _dgrad_amax with the plane forms passed as well (nullable); a launch that cannot
+ * use them runs exactly as the _amax call; with the same tile plan the results are bit-identical to it. */
+size_t dsrl_planes_lo_offset(int64_t elems);
+size_t dsrl_planes_bytes(int64_t elems, int nplanes);
+int dsrl_split_planes(const float* x, int ld, int64_t P, int C, const uint32_t* amax, void* planes, int nplanes, dsrl_stream_t stream);
+int dsrl_conv2d_filter_planes_batched(const int64_t* table, int n, int64_t total_tiles, dsrl_stream_t stream);
+int dsrl_conv2d_fwd_planes(const float* x, int ldx, const uint32_t* x_amax, const void* x_planes /*nullable*/, const float* w, const uint32_t* w_amax,
+                           const void* w_split /*nullable*/, const void* w_planes /*nullable*/, const float* bias /*nullable*/, float* y, int ldy,
+                           int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                           void* ws, size_t ws_bytes, float* stats /*nullable*/, int stats_parts, dsrl_stream_t stream);
+int dsrl_conv2d_dgrad_planes(const float* dy, int lddy, const uint32_t* dy_amax, const void* dy_planes /*nullable*/, const float* w, const float* wt /*nullable*/,
+                             const uint32_t* w_amax, const void* wt_split /*nullable*/, const void* wt_planes /*nullable*/, float* dx, int lddx,
+                             int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                             void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y, int bn_ldy,
+                             const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats /*nullable*/, int stats_parts, int accumulate,
+                             dsrl_stream_t stream);
 int dsrl_conv2d_wgrad_amax(const float* x, int ldx, const uint32_t* x_amax, const float* dy, int lddy, const uint32_t* dy_amax, float* dw,
                            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                            void* ws, size_t ws_bytes, dsrl_stream_t stream);
