@@ -219,6 +219,8 @@ class TrainStep:
         c.keep = HF.graph_keepalive = []          # pinned host tables the captured copies read on every replay
         HF.capture_host, HF.capture_host_off = t.empty(2 << 20, dtype=t.uint8, pin_memory=True), 0      # allocated BEFORE the capture starts
         c.keep.append(HF.capture_host)
+        if HF.f16_mode():
+            c.keep.append(HF.amax_pin(self.flat.device))      # the graph zeroes, maxes into and reads this arena on every replay: it lives as long as the graph
         c.graph_b, c.ready = None, []
         mode = os.environ.get('DSRL_GRAPH_CAPTURE_MODE', 'thread_local')
         try:

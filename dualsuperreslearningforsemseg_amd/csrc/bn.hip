@@ -1208,11 +1208,21 @@ static FusedPlan fused_plan(int64_t P, int C) {
 static std::mutex g_fused_mu;
 static hipStream_t g_fused_stream[64];
 static bool g_fused_stream_set[64] = {false};
+static unsigned long long g_fused_capture_id[64] = {0};
+static hipStream_t g_fused_capture_stream[64];
 static bool fused_stream_ok(hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) return true;   // a graph orders its own nodes
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo(st, &cs, &id) == hipSuccess && cs == hipStreamCaptureStatusActive) {
+        // A capture orders only the nodes of ONE stream: a forked capture (DSRL_GRAPH_OVERLAP=1) could place two barrier launches on parallel
+        // branches that share the word pair.  The first fused launch of a capture pins its stream for that capture; launches the same capture
+        // records on another stream take the three-kernel path.
+        std::lock_guard<std::mutex> lock(g_fused_mu);
+        if (g_fused_capture_id[dev] != id) { g_fused_capture_id[dev] = id; g_fused_capture_stream[dev] = st; }
+        return g_fused_capture_stream[dev] == st;
+    }
     std::lock_guard<std::mutex> lock(g_fused_mu);
     if (!g_fused_stream_set[dev]) { g_fused_stream[dev] = st; g_fused_stream_set[dev] = true; }
     return g_fused_stream[dev] == st;

@@ -188,9 +188,11 @@ void conv_planes_kernel(const ConvArgs a) {
         }
     };
     int nextq = q0 + grp, tap_set = -1;
-    // Every call issues the same PW pieces - past the end of the group's chunks with out-of-range offsets (zeros land in the slot): the counted
-    // waits below stay exact, and an exhausted K group multiplies zeros while the others finish.
-    auto issue = [&](int slot) {
+    // Every step issues the same PW pieces - past the end of the group's chunks with out-of-range offsets (zeros land in the slot): the counted
+    // waits below stay exact, and an exhausted K group multiplies zeros while the others finish.  prepare() advances the iterator and forms the
+    // piece offsets (scalar work + a few vector adds); piece<idx>() is one DMA instruction, so that the pieces can sit between the MFMAs.
+    unsigned va[A_IT], vb[B_IT], pbase = 0u;
+    auto prepare = [&](int slot) {
         const bool live = nextq < q1;
         if (live) {
             advance(nextq - pos);
@@ -200,19 +202,25 @@ void conv_planes_kernel(const ConvArgs a) {
         const int c = cc * 32 + unit * 8;
         const unsigned coff = (c < a.C ? (unsigned)c * 2u : kOOB) | (live ? 0u : kOOB);
         const unsigned woff = __builtin_elementwise_add_sat(coff, (unsigned)(tap * a.C) * 2u);
-        const unsigned base = ring_lds + (unsigned)(slot * SLOT);
+        pbase = ring_lds + (unsigned)(slot * SLOT);
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const unsigned v = __builtin_elementwise_add_sat(a_off[i], coff);
+        for (int i = 0; i < A_IT; ++i) va[i] = __builtin_elementwise_add_sat(a_off[i], coff);
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) lds_dma16(xr, v, pl ? a.a_lo : 0u, base + (unsigned)((pl * BM + (wave + NW * i) * 16) * ROWB));
+        for (int i = 0; i < B_IT; ++i) vb[i] = __builtin_elementwise_add_sat(b_off[i], woff);
+    };
+    auto piece = [&](int idx) {              // idx is a compile-time constant at every call site (unrolled loops)
+        if (idx < A_IT * NPL) {
+            const int i = idx / NPL, pl = idx % NPL;
+            lds_dma16(xr, va[i], pl ? a.a_lo : 0u, pbase + (unsigned)((pl * BM + (wave + NW * i) * 16) * ROWB));
+        } else {
+            const int i = (idx - A_IT * NPL) / NPL, pl = (idx - A_IT * NPL) % NPL;
+            lds_dma16(wr, vb[i], pl ? a.b_lo : 0u, pbase + (unsigned)((NPL * BM + pl * BN + (wave + NW * i) * 16) * ROWB));
         }
+    };
+    auto issue = [&](int slot) {
+        prepare(slot);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const unsigned v = __builtin_elementwise_add_sat(b_off[i], woff);
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) lds_dma16(wr, v, pl ? a.b_lo : 0u, base + (unsigned)((NPL * BM + pl * BN + (wave + NW * i) * 16) * ROWB));
-        }
+        for (int idx = 0; idx < PW; ++idx) piece(idx);
     };
 
     // ---- fragment reads: row = lane & 31 of a 32-row tile, k half = lane >> 5 of the 16-channel sub-step `sub`
@@ -222,23 +230,47 @@ void conv_planes_kernel(const ConvArgs a) {
     int u_off[2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) u_off[sub] = (((sub * 2 + (lane >> 5)) ^ swz) << 4) + fr_off;
-    auto compute = [&](int slot) {
+    // One step: the DMA pieces of the step that refills the slot freed by the last barrier go out first (spreading them between the MFMAs was
+    // measured: no gain on long K loops, a loss on short ones - the data of the next step lands later), then the fragments of both 16-channel
+    // sub-steps are requested (small tiles; large tiles: one sub-step ahead), then the MFMAs in the order a0*b1, a1*b0, a0*b0 per sub-step.
+    constexpr bool ALLFRAGS = MR * NR <= 2;                        // both sub-steps' fragments fit in registers
+    auto compute = [&](int slot, int refill) {
         const char* cur = ring + slot * SLOT;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            f16x8 fa[MR][NPL], fb[NR][NPL];
+        if (DBG != 2 && DBG != 3) prepare(refill);
+        f16x8 fa[2][MR][NPL], fb[2][NR][NPL];
+        auto rd = [&](int sub) {
             // the order the MFMAs need them: last plane of the filter fragments, first plane of the pixel fragments, then the rest
 #pragma unroll
-            for (int j = 0; j < NR; ++j) fb[j][NPL - 1] = *reinterpret_cast<const f16x8*>(cur + (NPL * BM + (NPL - 1) * BN + (wn * NR + j) * 32) * ROWB + u_off[sub]);
+            for (int j = 0; j < NR; ++j) fb[sub][j][NPL - 1] = *reinterpret_cast<const f16x8*>(cur + (NPL * BM + (NPL - 1) * BN + (wn * NR + j) * 32) * ROWB + u_off[sub]);
 #pragma unroll
-            for (int i = 0; i < MR; ++i) fa[i][0] = *reinterpret_cast<const f16x8*>(cur + ((wm * MR + i) * 32) * ROWB + u_off[sub]);
+            for (int i = 0; i < MR; ++i) fa[sub][i][0] = *reinterpret_cast<const f16x8*>(cur + ((wm * MR + i) * 32) * ROWB + u_off[sub]);
             if constexpr (NPL == 2) {
 #pragma unroll
-                for (int i = 0; i < MR; ++i) fa[i][1] = *reinterpret_cast<const f16x8*>(cur + (BM + (wm * MR + i) * 32) * ROWB + u_off[sub]);
+                for (int i = 0; i < MR; ++i) fa[sub][i][1] = *reinterpret_cast<const f16x8*>(cur + (BM + (wm * MR + i) * 32) * ROWB + u_off[sub]);
 #pragma unroll
-                for (int j = 0; j < NR; ++j) fb[j][0] = *reinterpret_cast<const f16x8*>(cur + (NPL * BM + (wn * NR + j) * 32) * ROWB + u_off[sub]);
+                for (int j = 0; j < NR; ++j) fb[sub][j][0] = *reinterpret_cast<const f16x8*>(cur + (NPL * BM + (wn * NR + j) * 32) * ROWB + u_off[sub]);
             }
-            PlaneMfma<NPL>::template run<MR, NR>(acc, fa, fb);
+        };
+        if (DBG != 2 && DBG != 3) {
+#pragma unroll
+            for (int idx = 0; idx < PW; ++idx) piece(idx);
+        }
+        if (DBG == 1 || DBG == 3) return;
+        rd(0);
+        if (ALLFRAGS) rd(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (!ALLFRAGS && sub == 0) rd(1);                       // requested under the MFMAs of sub-step 0
+#pragma unroll
+            for (int sum = NPL - 1; sum >= 0; --sum)
+#pragma unroll
+                for (int pa = 0; pa <= sum; ++pa)
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+#pragma unroll
+                        for (int j = 0; j < NR; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sub][i][pa], fb[sub][j][sum - pa], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -253,8 +285,7 @@ void conv_planes_kernel(const ConvArgs a) {
             if (q + j < nloc) {
                 s_waitcnt_vm<(R - 2) * PW>();       // my pieces of step q + j have landed (R - 2 later steps stay in flight)
                 block_barrier();                    // ... and everybody else's; every wave is done reading the slot of step q + j - 1
-                if (DBG != 2 && DBG != 3) issue((j + R - 1) % R);             // step q + j + R - 1 goes into that slot
-                if (DBG != 1 && DBG != 3) compute(j);
+                compute(j, (j + R - 1) % R);        // ... while step q + j + R - 1 is requested into that slot
             }
         }
     }

@@ -144,11 +144,11 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const float* __restrict__
         __syncthreads();
         if ((int)threadIdx.x < np) {
             const int tg = target[p0 + threadIdx.x];
-            bad_label |= tg != ignore_index && tg >= C;         // torch's CrossEntropyLoss asserts on such a target: here it poisons the loss and raises flag bit 1
+            bad_label |= tg != ignore_index && (tg < 0 || tg >= C);     // torch's CrossEntropyLoss asserts on such a target: here it poisons the loss and raises flag bit 1
             float* v = tile + threadIdx.x * C;
             float m = v[0];
             for (int c = 1; c < C; ++c) m = fmaxf(m, v[c]);
-            const float vt = v[min(tg == ignore_index ? 0 : tg, C - 1)];
+            const float vt = v[max(min(tg == ignore_index ? 0 : tg, C - 1), 0)];
             float s = 0.f;
             for (int c = 0; c < C; ++c) { const float e = expf(v[c] - m); s += e; v[c] = e; }       // the tile keeps exp(v - m): one expf per logit
             bad |= !(s == s);                   // any NaN logit poisons the sum (fmaxf alone would skip it)

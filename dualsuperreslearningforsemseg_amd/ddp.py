@@ -187,6 +187,7 @@ class FlatParams:
         # f16x3 arithmetic: every filter also in pre-split ("plane") form, forward layout and transposed (dsrl_conv2d_split_filters_batched);
         # the arenas are allocated on first use
         self._split_entries, self._split_table = entries, None
+        self.planes_valid, self._planes_table = False, None
 
     def _build_split_filters(self):
         floats_w = sum(_align(w.numel()) for w, *_ in self._split_entries)
@@ -215,6 +216,30 @@ class FlatParams:
         self._amax_seg_table = torch.tensor(segs, dtype=torch.int64, device=self.device)
         self._amax_segs = len(segs)
 
+    def _build_plane_filters(self):
+        """Every filter whose channel counts are multiples of 8 as fp16 planes, forward [K][R][S][C] and transposed [C][R][S][K]: the filter operand
+        of conv_planes_kernel (dsrl_conv2d_filter_planes_batched), scaled by the same amax records as the split forms."""
+        # 'auto': only the filters whose convs asked for planes in an earlier step (functional._Conv2d marks them: the operands that are large enough
+        # for the split pass to pay); 'all': every eligible filter
+        ents = [(i, e) for i, e in enumerate(self._split_entries) if e[1] % 8 == 0 and e[4] % 8 == 0 and
+                (HF.planes_mode == 'all' or getattr(e[0], '_dsrl_want_planes', False))]
+        self._planes_wanted = sum(1 for e in self._split_entries if getattr(e[0], '_dsrl_want_planes', False))
+        lo = lambda n: int(HF.cquery('dsrl_planes_lo_offset', n))        # noqa: E731
+        total = sum(2 * lo(w.numel()) for _, (w, *_r) in ents)
+        self.wplanes_flat = torch.empty(max(total, 256), device=self.device, dtype=torch.uint8)
+        self.wtplanes_flat = torch.empty(max(total, 256), device=self.device, dtype=torch.uint8)
+        rows, off, tiles = [], 0, 0
+        for i, (w, K, Kp, RS, C, _off) in ents:
+            nb = 2 * lo(w.numel())
+            wp, wtp = self.wplanes_flat[off:off + nb], self.wtplanes_flat[off:off + nb]
+            off += nb
+            w._dsrl_wplanes, w._dsrl_wtplanes = wp, wtp
+            ct = (C + 31) // 32
+            rows.append([w.data_ptr(), wtp.data_ptr(), K, K, RS, C, tiles, ct, self.w_amax.data_ptr() + 4 * HF.AMAX_WORDS * i, wp.data_ptr()])
+            tiles += RS * ct * ((K + 31) // 32)
+        self._planes_rows, self._planes_tiles = len(rows), tiles
+        self._planes_table = torch.tensor(rows if rows else [[0] * 10], dtype=torch.int64, device=self.device)
+
     def refresh_transposed_filters(self):
         if self._wt_table is not None and os.environ.get('DSRL_BATCHED_TRANSPOSE', '1') != '0':
             self.w_amax.zero_()
@@ -228,7 +253,14 @@ class FlatParams:
                 HF.call('dsrl_conv2d_transpose_filters_batched', (self._amax_only_table if presplit else self._wt_table).data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
             if presplit:
                 HF.call('dsrl_conv2d_split_filters_batched', self._split_table.data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
-            self.wt_valid, self.wt_fp32_valid, self.split_valid = True, not presplit, presplit
+            planes = presplit and HF.planes_mode != 'off'
+            if planes:
+                if self._planes_table is None or (HF.planes_mode != 'all' and
+                                                  self._planes_wanted != sum(1 for e in self._split_entries if getattr(e[0], '_dsrl_want_planes', False))):
+                    self._build_plane_filters()         # first use, or more filters asked for planes since the table was built
+                if self._planes_rows:
+                    HF.call('dsrl_conv2d_filter_planes_batched', self._planes_table.data_ptr(), self._planes_rows, self._planes_tiles, HF._stream())
+            self.wt_valid, self.wt_fp32_valid, self.split_valid, self.planes_valid = True, not presplit, presplit, planes
 
     def zero_grad(self):
         self.g_flat.zero_()
@@ -327,7 +359,9 @@ class FlatParams:
             HF.sgd_step_dev_(self.p_flat, self.g_flat, self.m_flat, hyper)
         else:
             HF.sgd_step_(self.p_flat, self.g_flat, self.m_flat, lr, momentum, weight_decay, 1.0 / self.world)
-        self.wt_valid = self.wt_fp32_valid = self.split_valid = False       # the filters changed: transposed / split copies and amax records are stale until the next refresh
+        if self.device.type == 'cuda':
+            HF.amax_end_step(self.device)       # records asked for between steps (validation) come from the loose arena, not from the step's
+        self.wt_valid = self.wt_fp32_valid = self.split_valid = self.planes_valid = False       # the filters changed: transposed / split copies and amax records are stale until the next refresh
 
     def _trainable_in_model_order(self):
         return [p for p in self.model.parameters() if p.requires_grad]

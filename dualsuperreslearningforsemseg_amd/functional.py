@@ -79,38 +79,106 @@ def get_conv_precision():
 # forward conv and the weight gradient (x) and the data and weight gradients (dy) share one measurement.  Slots come from an arena that
 # ddp.FlatParams.zero_grad() rewinds and zeroes at the start of every training step (one memset; static addresses under graph capture).
 _AMAX_SLOTS, AMAX_WORDS = 2048, 256          # records per arena (a stage-3 step uses ~700); include/dsrl_hip.h: DSRL_AMAX_WORDS
-_amax_arena = {}            # device -> [int32 tensor, next free slot]
+# Two kinds of arenas per device.  The STEP arena belongs to training steps: ddp.FlatParams.zero_grad() rewinds and zeroes it (amax_begin_step),
+# sgd_step() closes it (amax_end_step); a captured hipGraph bakes in its addresses (the zero fill, ~700 records the kernels max into and read), so a
+# capture PINS it (amax_pin: the graph holds the tensor, and a pinned arena is never replaced).  Everything outside an open step - evaluation
+# forwards between epochs, tools, tests - draws from a LOOSE arena that is simply replaced when it is full (views keep the old one alive for the
+# tensors that still carry its records).  Round 3 had one arena for both: ten validation batches exhausted it, the replacement freed the memory a
+# live graph kept writing to.
+_amax_arena = {}            # device -> [int32 tensor, next free slot, generation, pinned]
+_amax_loose = {}            # device -> [int32 tensor, next free slot]
+_amax_open = set()          # devices whose step arena is open
+
+
+def _new_arena(device):
+    return torch.zeros(_AMAX_SLOTS * AMAX_WORDS, dtype=torch.int32, device=device)
 
 
 def amax_begin_step(device):
-    """Rewinds the slot arena of `device` and zeroes it (stream-ordered): every slot handed out before belongs to a finished step."""
+    """Rewinds the step arena of `device` and zeroes it (stream-ordered): every record handed out of it before belongs to a finished step - the
+    generation counter invalidates the `_dsrl_amax` attributes that still point into it (amax_for re-measures such tensors)."""
     ar = _amax_arena.get(device)
     if ar is None:
-        ar = _amax_arena[device] = [torch.zeros(_AMAX_SLOTS * AMAX_WORDS, dtype=torch.int32, device=device), 0]
+        ar = _amax_arena[device] = [_new_arena(device), 0, 1, False]
     else:
         ar[0].zero_()
         ar[1] = 0
+        ar[2] += 1
+    _amax_open.add(device)
     return ar
 
 
-def amax_slot(device):
+def amax_end_step(device):
+    """The training step of `device` is over (its optimiser update has been enqueued): records asked for from here on come from the loose arena."""
+    _amax_open.discard(device)
+
+
+def amax_pin(device):
+    """The step arena of `device`, marked as referenced by a captured graph (the caller keeps the tensor with the graph): never replaced from now on."""
     ar = _amax_arena.get(device)
-    if ar is None or ar[1] >= _AMAX_SLOTS:
-        # no step context (or an exhausted arena): a fresh zeroed arena; views keep the old one alive for the kernels that still read it
-        ar = _amax_arena[device] = [torch.zeros(_AMAX_SLOTS * AMAX_WORDS, dtype=torch.int32, device=device), 0]
-    i = ar[1]
-    ar[1] = i + 1
-    return ar[0][i * AMAX_WORDS:(i + 1) * AMAX_WORDS]
+    if ar is None:
+        ar = amax_begin_step(device)
+        amax_end_step(device)
+    ar[3] = True
+    return ar[0]
+
+
+def amax_slot(device):
+    """A zeroed amax record.  The returned view carries `_dsrl_gen`: the generation of the step arena it came from (-1: loose arena, never reused)."""
+    ar = _amax_arena.get(device)
+    if ar is not None and device in _amax_open:
+        if ar[1] >= _AMAX_SLOTS:
+            if ar[3]:
+                raise DsrlHipError(f'amax arena exhausted inside a training step whose graph is captured ({_AMAX_SLOTS} records): raise functional._AMAX_SLOTS')
+            ar[0], ar[1] = _new_arena(device), 0          # an eager step that needs more: views keep the old tensor alive for its kernels
+        i = ar[1]
+        ar[1] = i + 1
+        slot = ar[0][i * AMAX_WORDS:(i + 1) * AMAX_WORDS]
+        slot._dsrl_gen = ar[2]
+        return slot
+    lo = _amax_loose.get(device)
+    if lo is None or lo[1] >= _AMAX_SLOTS:
+        lo = _amax_loose[device] = [_new_arena(device), 0]
+    i = lo[1]
+    lo[1] = i + 1
+    slot = lo[0][i * AMAX_WORDS:(i + 1) * AMAX_WORDS]
+    slot._dsrl_gen = -1
+    return slot
 
 
 def f16_mode():
     return _conv_precision_code() == 4
 
 
-def amax_for(t, data=None, ld=None):
-    """The magnitude slot of pixel-major tensor `t` (N,C,H,W): the one it carries, or a fresh measurement that it then carries.
-    `data`/`ld`: the pixel-major copy of `t` the kernels read, if the caller already has it."""
+def set_amax(t, slot):
+    """Attaches the amax record `slot` to tensor `t` together with what makes it stale: the tensor's version counter (an in-place write) and the
+    generation of the step arena the record lives in (amax_begin_step zeroes and re-issues those records)."""
+    try:
+        t._dsrl_amax = slot
+        t._dsrl_amax_meta = (t._version, getattr(slot, '_dsrl_gen', -1))
+    except Exception:           # noqa: BLE001
+        pass
+
+
+def carried_amax(t):
+    """The record `t` carries if it still describes the tensor's values, else None."""
     slot = getattr(t, '_dsrl_amax', None)
+    if slot is None:
+        return None
+    meta = getattr(t, '_dsrl_amax_meta', None)
+    if meta is None or meta[0] != t._version:
+        return None
+    if meta[1] != -1:
+        ar = _amax_arena.get(slot.device)
+        if ar is None or ar[2] != meta[1]:
+            return None
+    return slot
+
+
+def amax_for(t, data=None, ld=None):
+    """The magnitude record of pixel-major tensor `t` (N,C,H,W): the one it carries (left by its producer or by an earlier measurement, and still
+    valid: carried_amax), or a fresh measurement that it then carries.  `data`/`ld`: the pixel-major copy of `t` the kernels read, if the caller has it."""
+    slot = carried_amax(t)
     if slot is not None:
         return slot
     if data is None:
@@ -118,10 +186,7 @@ def amax_for(t, data=None, ld=None):
     N, Cc, H, W = data.shape
     slot = amax_slot(data.device)
     call('dsrl_amax', data.data_ptr(), ld, N * H * W, Cc, slot.data_ptr(), _stream())
-    try:
-        t._dsrl_amax = slot
-    except Exception:           # noqa: BLE001
-        pass
+    set_amax(t, slot)
     return slot
 
 
@@ -401,6 +466,12 @@ def _weight_split(w, attr):
     return getattr(w, attr, None) if (arena is not None and arena.split_valid) else None
 
 
+def _weight_planes(w, attr):
+    """The fp16 planes of a conv filter that ddp.FlatParams wrote in this step (attr: '_dsrl_wplanes' [K][R][S][C], '_dsrl_wtplanes' [C][R][S][K]), or None."""
+    arena = getattr(w, '_dsrl_arena', None)
+    return getattr(w, attr, None) if (arena is not None and getattr(arena, 'planes_valid', False)) else None
+
+
 def split_filter(w):
     """(amax record, w_split, wt_split) of one [K][R][S][C] filter for the f16x3 kernels: what ddp.FlatParams prepares for every filter of a
     model once per step (dsrl_conv2d_transpose_filters_batched + dsrl_conv2d_split_filters_batched), here for a single tensor."""
@@ -425,6 +496,44 @@ def planes_of(data, ld, amax, nplanes=2):
     P = N * H * W
     buf = torch.empty(int(cquery('dsrl_planes_bytes', P * ld, nplanes)), device=data.device, dtype=torch.uint8)
     call('dsrl_split_planes', data.data_ptr(), ld, P, Cc, amax.data_ptr(), buf.data_ptr(), nplanes, _stream())
+    return buf
+
+
+# fp16 planes of activation operands (round 4): 'off' = never, 'all' = a standalone split pass for every eligible operand that does not carry
+# planes yet, 'auto' (default) = the split pass only where it pays by itself (tensors of >= DSRL_PLANES_MIN_ELEMS elements: the 65536-pixel decoder
+# operands; a split launch costs ~6 us on the small ones, more than the planes kernel gains there) - producers that write planes beside their
+# fp32 output are used in every mode but 'off'
+planes_mode = os.environ.get('DSRL_PLANES_MODE', 'auto')
+planes_min_elems = int(os.environ.get('DSRL_PLANES_MIN_ELEMS', str(8 << 20)))
+
+
+def planes_wanted(data, ld, C, K, taps=9):
+    """Would a conv with this activation operand take planes if its filter had them? (planes_mode 'auto' / 'all'; both channel counts multiples of 8;
+    'auto': long K loops over large operands only - the 3x3 decoder convs)"""
+    if planes_mode == 'off' or C % 8 or K % 8 or ld % 8 or data.data_ptr() % 16:
+        return False
+    N, Cc, H, W = data.shape
+    return planes_mode == 'all' or (N * H * W * Cc >= planes_min_elems and taps >= 9)
+
+
+def planes_for(t, data, ld, amax, taps=9, split_ok=True):
+    """fp16 planes of operand tensor `t` (pixel-major copy `data`, pixel stride ld) scaled by ITS record `amax`, or None: the planes the tensor
+    carries (left by its producer or by an earlier consumer of the same tensor in this step), else a split pass when planes_mode allows one."""
+    if planes_mode == 'off' or amax is None:
+        return None
+    have = getattr(t, '_dsrl_planes', None)
+    if have is not None and have[1] == ld and have[2] == amax.data_ptr() and have[3] == data.data_ptr() and have[4] == t._version:
+        return have[0]
+    N, Cc, H, W = data.shape
+    if Cc % 8 or ld % 8 or data.data_ptr() % 16:
+        return None
+    if planes_mode != 'all' and (N * H * W * Cc < planes_min_elems or taps < 9 or not split_ok):
+        return None
+    buf = planes_of(data, ld, amax)
+    try:
+        t._dsrl_planes = (buf, ld, amax.data_ptr(), data.data_ptr(), t._version)
+    except Exception:           # noqa: BLE001
+        pass
     return buf
 
 
@@ -538,9 +647,9 @@ class _Fork(torch.autograd.Function):
 
 def fork(x):
     y = _Fork.apply(x)
-    a = getattr(x, '_dsrl_amax', None)
+    a = carried_amax(x)
     if a is not None:
-        y._dsrl_amax = a            # the alias holds the same values: it keeps the magnitude word of the tensor it aliases
+        set_amax(y, a)              # the alias holds the same values: it keeps the magnitude record of the tensor it aliases
     return y
 
 
@@ -574,8 +683,13 @@ class _Conv2d(torch.autograd.Function):
         if stats_parts > 0:         # BatchNorm partials of y from the conv epilogue (include/dsrl_hip.h: dsrl_conv2d_fwd_stats)
             stats = torch.empty(cquery('dsrl_bn_stats_floats', 3, int(stats_parts), K), device=x.device, dtype=torch.float32)
         wsp = _weight_split(w_param, '_dsrl_wsplit') if wa is not None else None        # the filter pre-split by ddp.FlatParams (same step, same record)
-        call('dsrl_conv2d_fwd_amax', x.data_ptr(), ldx, None if xa is None else xa.data_ptr(), w.data_ptr(), None if wa is None else wa.data_ptr(),
-             None if wsp is None else wsp.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), K, *shp, ws.data_ptr(), ws.numel(),
+        wpl = _weight_planes(w_param, '_dsrl_wplanes') if wa is not None else None       # ... and as fp16 planes; with planes of x the launch stages by LDS-DMA
+        if wpl is None and wa is not None and planes_wanted(x, ldx, Cc, K, R * S):
+            w_param._dsrl_want_planes = True            # ddp.FlatParams writes this filter's planes from the next step on
+        xp = planes_for(x_in, x, ldx, xa, R * S) if wpl is not None else None
+        call('dsrl_conv2d_fwd_planes', x.data_ptr(), ldx, None if xa is None else xa.data_ptr(), None if xp is None else xp.data_ptr(), w.data_ptr(),
+             None if wa is None else wa.data_ptr(), None if wsp is None else wsp.data_ptr(), None if wpl is None else wpl.data_ptr(),
+             None if bias is None else bias.data_ptr(), y.data_ptr(), K, *shp, ws.data_ptr(), ws.numel(),
              None if stats is None else stats.data_ptr(), int(stats_parts), _stream())
         ctx.save_for_backward(x, w)
         ctx.shp = shp
@@ -621,6 +735,9 @@ class _Conv2d(torch.autograd.Function):
                 wa = None                             # the filter changed since its magnitude was taken
         p_ = lambda t_: None if t_ is None else t_.data_ptr()       # noqa: E731
         wtsp = _weight_split(ctx.wparam, '_dsrl_wtsplit') if (wa is not None and ctx.wparam is not None) else None
+        wtpl = _weight_planes(ctx.wparam, '_dsrl_wtplanes') if (wa is not None and ctx.wparam is not None) else None
+        # 'auto' never pays a split pass for a gradient (measured: the data-gradient launches gain less than the pass costs); planes a producer left are used
+        dyp = planes_for(dy_in, dy, lddy, dya, R * S, split_ok=planes_mode == 'all') if (wtpl is not None and ctx.needs_input_grad[0] and stride == 1 and K % 8 == 0) else None
         if ctx.needs_input_grad[1]:
             sink = _sink(ctx.wparam) if ctx.wparam is not None and _is_krsc(ctx.wparam) else None
             if sink is not None and wgrad_queue is not None:
@@ -670,12 +787,12 @@ class _Conv2d(torch.autograd.Function):
                 # x is y = relu(bn(.)) of a BatchNorm that feeds only this conv: leave its backward partial sums with the data gradient
                 bstats = torch.empty(cquery('dsrl_bn_stats_floats', 2, parts, Cc), device=x.device, dtype=torch.float32)
                 _, bld = pm(link.x)
-                call('dsrl_conv2d_dgrad_amax', dy.data_ptr(), lddy, p_(dya), w.data_ptr(), wt_ptr, p_(wa), p_(wtsp), dx.data_ptr(), Cc, *shp, ws.data_ptr(), ws.numel(),
-                     link.x.data_ptr(), bld, x.data_ptr(), ldx, link.mean.data_ptr(), link.invstd.data_ptr(), int(link.relu),
+                call('dsrl_conv2d_dgrad_planes', dy.data_ptr(), lddy, p_(dya), p_(dyp), w.data_ptr(), wt_ptr, p_(wa), p_(wtsp), p_(wtpl), dx.data_ptr(), Cc, *shp,
+                     ws.data_ptr(), ws.numel(), link.x.data_ptr(), bld, x.data_ptr(), ldx, link.mean.data_ptr(), link.invstd.data_ptr(), int(link.relu),
                      bstats.data_ptr(), parts, int(acc), st)
                 link.stats, link.parts, link.dx_ptr = bstats, parts, dx.data_ptr()
             else:
-                call('dsrl_conv2d_dgrad_amax', dy.data_ptr(), lddy, p_(dya), w.data_ptr(), wt_ptr, p_(wa), p_(wtsp), dx.data_ptr(), Cc, *shp,
+                call('dsrl_conv2d_dgrad_planes', dy.data_ptr(), lddy, p_(dya), p_(dyp), w.data_ptr(), wt_ptr, p_(wa), p_(wtsp), p_(wtpl), dx.data_ptr(), Cc, *shp,
                      ws.data_ptr(), ws.numel(), None, 0, None, 0, None, None, 0, None, 0, int(acc), st)
             if acc:
                 dx = None                   # the contribution went into the buffer autograd already holds for this input
@@ -808,7 +925,7 @@ class _BNAct(torch.autograd.Function):
             call('dsrl_bn_apply', x.data_ptr(), ldx, y.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                  res_ptr, ldr, int(relu), float(drop_p), int(seed), int(rng_stream), ya_ptr, st)
         if ya is not None:
-            y._dsrl_amax = ya
+            set_amax(y, ya)
         ctx.save_for_backward(x, y, mean, invstd, gamma)
         if out_link is not None and drop_p == 0.0 and Cc % 32 == 0 and ldx == Cc:
             out_link.x, out_link.mean, out_link.invstd, out_link.relu, out_link.valid = x, mean, invstd, bool(relu), True
@@ -847,7 +964,7 @@ class _BNAct(torch.autograd.Function):
                  None if dres is None else dres.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                  dgamma.data_ptr(), dbeta.data_ptr(), int(relu), drop_p, int(training), ws.data_ptr(), ws.numel(), dxa_ptr, _stream())
         if dxa is not None:
-            dx._dsrl_amax = dxa
+            set_amax(dx, dxa)
         if sg is not None:
             ctx.gb[0]._dsrl_arena.written(ctx.gb[0]); dgamma = None
         if sb is not None:

@@ -65,9 +65,9 @@ class Bottleneck(t.nn.Module):
 
 def _cut(x, cut):
     d = x.detach().requires_grad_(True)
-    a = getattr(x, '_dsrl_amax', None)
+    a = HF.carried_amax(x)
     if a is not None:
-        d._dsrl_amax = a                # same values: the detached leaf keeps the operand-magnitude record of the tensor (functional.amax_for)
+        HF.set_amax(d, a)               # same values: the detached leaf keeps the operand-magnitude record of the tensor (functional.amax_for)
     cut.append((x, d))
     return d
 

@@ -185,6 +185,79 @@ def test_f16x3_presplit_filters_match_on_the_fly(shape):
     check(outs[1][0], yo, 3e-6, 'y')
 
 
+# (N, C, H, W, K, R, stride, pad, dil), forced tile configuration (DSRL_FORCE_CFG: TileCfg of conv_igemm.hip; None = the planner's), K groups
+_PLANES_CASES = [
+    ((8, 256, 16, 32, 256, 3, 1, 1, 1), None, 0),         # layer3 3x3: 64x64 tiles, 4 K groups (the planner's choice at this size)
+    ((2, 256, 16, 32, 256, 3, 1, 1, 1), 3, 2),            # 64x64, 2 K groups, ring of 4
+    ((2, 1024, 16, 32, 256, 1, 1, 0, 1), 3, 1),           # 64x64, one group, three blocks per CU
+    ((2, 304, 16, 64, 192, 3, 1, 1, 1), 0, 0),            # 128x128, channel tail (304 = 9.5 chunks), N tail (192 = 1.5 tiles)
+    ((2, 48, 16, 64, 64, 3, 1, 6, 6), 4, 2),              # 128x64 with two K groups, dilation 6 (dead taps), C = 1.5 chunks
+    ((2, 128, 16, 32, 256, 1, 2, 0, 1), 5, 1),            # 64x128, stride 2 forward (its dgrad stays on the register-staged kernel)
+    ((1, 64, 64, 128, 64, 3, 1, 1, 1), 1, 0),             # 256x64
+    ((2, 64, 64, 128, 256, 3, 1, 1, 1), 7, 0),            # 256x128, 8 waves
+    ((4, 64, 64, 128, 256, 3, 1, 1, 1), 8, 0),            # 256x256, 8 waves
+]
+
+
+@pytest.mark.parametrize('shape,cfg,kg', _PLANES_CASES)
+def test_planes_kernel_bit_identical_to_register_staged(shape, cfg, kg, monkeypatch):
+    """conv_planes_kernel (both operands as fp16 planes, staged by LDS-DMA: dsrl_conv2d_fwd_planes / _dgrad_planes) against conv_igemm_split_kernel
+    with pre-split filters under the SAME tile / K-group plan: the same terms meet the same MFMAs in the same order, so forward outputs, the
+    BatchNorm partials of the forward epilogue, data gradients (plain and accumulating) and the BatchNorm-backward sums of the dgrad epilogue are
+    BIT-identical.  The planes themselves are checked against the split the register-staged kernel performs (hi = f16(x 2^e), lo = f16(x 2^e - hi))."""
+    N, C, H, W, K, R, stride, pad, dil = shape
+    if cfg is not None:
+        monkeypatch.setenv('DSRL_FORCE_CFG', str(cfg))
+    if kg:
+        monkeypatch.setenv('DSRL_FORCE_KG', str(kg))
+    rs = np.random.RandomState(sum(shape))
+    x = dev(np.maximum(rs.standard_normal((N, C, H, W)), 0).astype(np.float32))
+    w = dev((rs.standard_normal((K, C, R, R)) / np.sqrt(C * R * R)).astype(np.float32))
+    Ho, Wo = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1, (W + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    dy = dev(rs.standard_normal((N, K, Ho, Wo)).astype(np.float32))
+    HF.set_conv_precision('f16x3')
+    rec, wsp, wtsp, wtr = HF.split_filter(w)
+    wp, wtp = HF.filter_planes(w, rec)
+    xa, dya = HF.amax_for(x), HF.amax_for(dy)
+    xp, dyp = HF.planes_of(x, C, xa), HF.planes_of(dy, K, dya)
+    # the planes are the two terms of the scaled values
+    P = N * H * W
+    ex = int((int(host(xa.view(torch.int32)).view(np.uint32).max()) >> 23) & 0xff)
+    xs = np.ldexp(host(x).transpose(0, 2, 3, 1).reshape(P, C).astype(np.float32), 14 - (ex - 127))
+    hi = xs.astype(np.float16); lo = (xs - hi.astype(np.float32)).astype(np.float16)
+    lo_off = int(HF.query('dsrl_planes_lo_offset', P * C))
+    got = xp.cpu().numpy()
+    assert np.array_equal(got[:P * C * 2].view(np.float16).reshape(P, C), hi) and np.array_equal(got[lo_off:lo_off + P * C * 2].view(np.float16).reshape(P, C), lo)
+    shp = (N, H, W, C, K, R, R, stride, pad, dil)
+    st = HF._stream()
+    parts = int(HF.query('dsrl_conv2d_fwd_stats_parts', *shp)) if K % 32 == 0 else 0
+    dparts = int(HF.query('dsrl_conv2d_dgrad_stats_parts', *shp)) if (C % 32 == 0 and stride == 1) else 0
+    mean = dev(rs.standard_normal(C).astype(np.float32) * 0.1); invstd = dev((1.0 + rs.rand(C)).astype(np.float32))
+    bnx = dev(rs.standard_normal((N, C, H, W)).astype(np.float32))
+    dx0 = dev(rs.standard_normal((N, C, H, W)).astype(np.float32))
+    outs = []
+    for planes in (False, True):
+        y = torch.empty((N, K, Ho, Wo), device=DEV).contiguous(memory_format=torch.channels_last)
+        ws = HF._ws(HF.cquery('dsrl_conv2d_dgrad_workspace_bytes', *shp) + HF.cquery('dsrl_conv2d_fwd_workspace_bytes', *shp), x)
+        stats = torch.zeros(int(HF.query('dsrl_bn_stats_floats', 3, max(parts, 1), K)), device=DEV)
+        HF.call('dsrl_conv2d_fwd_planes', x.data_ptr(), C, xa.data_ptr(), xp.data_ptr() if planes else None, w.data_ptr(), rec.data_ptr(), wsp.data_ptr(),
+                wp.data_ptr() if planes else None, None, y.data_ptr(), K, *shp, ws.data_ptr(), ws.numel(), stats.data_ptr() if parts else None, parts, st)
+        res = [host(y), host(stats[:3 * parts * K])]
+        for acc in (0, 1):
+            dx = dx0.clone()
+            bst = torch.zeros(int(HF.query('dsrl_bn_stats_floats', 2, max(dparts, 1), C)), device=DEV)
+            HF.call('dsrl_conv2d_dgrad_planes', dy.data_ptr(), K, dya.data_ptr(), dyp.data_ptr() if planes else None, w.data_ptr(), None, rec.data_ptr(), wtsp.data_ptr(),
+                    wtp.data_ptr() if planes else None, dx.data_ptr(), C, *shp, ws.data_ptr(), ws.numel(),
+                    bnx.data_ptr() if dparts else None, C, x.data_ptr() if dparts else None, C, mean.data_ptr() if dparts else None,
+                    invstd.data_ptr() if dparts else None, 1, bst.data_ptr() if dparts else None, dparts, acc, st)
+            res += [host(dx), host(bst[:2 * dparts * C])]
+        outs.append(res)
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert np.array_equal(a_, b_, equal_nan=True)
+    yo = O.conv2d(host(x).astype(np.float64), host(w).astype(np.float64), None, stride, pad, dil)
+    check(outs[1][0], yo, 3e-6, 'y')
+
+
 def test_pointwise_strided_golden(golden):
     g = golden('ops_micro')
     x = dev(g['conv_s8.x']).requires_grad_(True); w = dev(g['conv_s8.w']).requires_grad_(True)
@@ -778,7 +851,7 @@ def test_head_512x1024_golden(golden):
     assert abs(pix[0] - mean[0]) < 1e-3 and abs(pix[1] - mean[1]) < 1e-3
 
 
-@pytest.mark.parametrize('mode', ['bf16x6', 'bf16x3'])
+@pytest.mark.parametrize('mode', ['f16x3', 'bf16x6', 'bf16x3'])          # f16x3: the default arithmetic, what bench.py's config5 object times
 def test_full_size_train_step_properties_512x1024(mode):
     """Config-5 size end to end (whole model, 512x1024 -> 1024x2048, B=2, train mode with dropout), where no oracle finishes in seconds:
     size-independent properties instead.  (1) Determinism: the same step from the same state and dropout key gives bit-identical
@@ -818,6 +891,79 @@ def test_full_size_train_step_properties_512x1024(mode):
     # its direction, the per-op accuracy of the mode is pinned by test_conv_precision_modes (3e-5 per conv)
     assert cos > 0.99, (cos, rel)
     print(mode, 'losses', runs[0][0], 'gradient arena vs bf16x6: L2 difference %.2e, cosine %.5f' % (rel, cos))
+
+
+@pytest.mark.parametrize('stage', [1, 2])
+def test_train_step_stage1_stage2_b8_256x512(stage):
+    """BASELINE configs 2 and 3: TrainStep for stage 1 (SSSR only) and stage 2 (+ SISR) at batch 8, 256x512 -> 512x1024, default arithmetic.
+    The hipGraph-replayed step equals the eager launches bit for bit (losses, parameters, BatchNorm buffers), the losses are finite, and the
+    parameters a stage does not own are absent (models/DSRL.py:172-184: the SISR decoder from stage 2, the feature transformers from stage 3)."""
+    from dualsuperreslearningforsemseg_amd.command_handlers.train_or_resume import SyntheticCityscapes, TrainStep
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    from dualsuperreslearningforsemseg_amd.ddp import FlatParams
+    HF.set_conv_precision(None)
+    res = {}
+    for graph in (False, True):
+        torch.manual_seed(1234)
+        model = D.DSRL(stage, cs)
+        names = [k for k, _ in model.named_parameters()]
+        assert any(k.startswith('SSSR_decoder') for k in names)
+        assert any(k.startswith('SISR_decoder') for k in names) == (stage >= 2)
+        assert not any('feature_transformer' in k for k in names)
+        model = model.to(DEV).to(memory_format=torch.channels_last).train()
+        flat = FlatParams(model)
+        HF.set_dropout_seed(2024)
+        was = HF.overlap_wgrad
+        HF.overlap_wgrad = False
+        try:
+            step = TrainStep(model, flat, stage, 0.1, 1.0, cs.IGNORE_CLASS_LABEL, graph=graph)
+            batches = list(SyntheticCityscapes(8, (256, 512), torch.device(DEV), length=4, distinct=2))
+            hist = []
+            for (img, org), (tgt, _) in batches:
+                losses, outs = step(img, org, tgt, 0.006, 0.9, 5e-4, True)
+                hist.append(losses)
+            # unused outputs are CPU zeros(1) (DSRL.py:172-174)
+            assert outs[0].shape == (8, 19, 512, 1024) and (outs[1].numel() == 1) == (stage < 2) and outs[2].numel() == 1 and outs[3].numel() == 1
+        finally:
+            HF.overlap_wgrad = was
+        torch.cuda.synchronize()
+        if graph:
+            assert step.graph_replays == 4 - step.GRAPH_WARMUP
+        res[graph] = (hist, flat.p_flat.clone(), flat.b_flat.clone())
+        step.release()
+    assert all(np.isfinite(v) for h in res[True][0] for v in h), res[True][0]
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][2], res[True][2])
+    ms, fa = [h[1] for h in res[True][0]], [h[2] for h in res[True][0]]
+    assert all(v == 0.0 for v in fa) and (all(v == 0.0 for v in ms) if stage == 1 else all(v > 0.0 for v in ms))
+
+
+def test_amax_record_goes_stale_with_the_tensor():
+    """A magnitude record cached on a tensor (functional.amax_for) must not outlive what it describes: the step arena is rewound and zeroed by the
+    next step (a zero record would scale by 2^140: Inf / NaN), and an in-place write changes the values under the record.  The
+    same tensor convolved before and after amax_begin_step(), and after an in-place scale by 1024, gives the same / the scaled result."""
+    HF.set_conv_precision('f16x3')
+    rs = np.random.RandomState(11)
+    x = dev(rs.standard_normal((2, 64, 16, 32)).astype(np.float32))
+    w = dev((rs.standard_normal((64, 64, 3, 3)) / 24).astype(np.float32))
+    HF.amax_begin_step(x.device)
+    try:
+        y0 = host(HF.conv2d(x, w, None, 1, 1, 1))
+        rec0 = HF.carried_amax(x)
+        assert rec0 is not None and rec0._dsrl_gen > 0
+        HF.amax_begin_step(x.device)                    # the next step: the arena is zeroed, its records re-issued
+        assert HF.carried_amax(x) is None
+        y1 = host(HF.conv2d(x, w, None, 1, 1, 1))
+        assert np.array_equal(y0, y1)
+        x.mul_(1024.0)                                  # in place: same tensor object, other values
+        assert HF.carried_amax(x) is None
+        y2 = host(HF.conv2d(x, w, None, 1, 1, 1))
+        assert np.isfinite(y2).all() and np.array_equal(y2, y0 * 1024.0)       # a power of two: the split terms are the same, scaled
+    finally:
+        HF.amax_end_step(x.device)
+    x2 = dev(rs.standard_normal((2, 64, 16, 32)).astype(np.float32))
+    HF.conv2d(x2, w, None, 1, 1, 1)
+    assert HF.carried_amax(x2)._dsrl_gen == -1          # outside a step: the loose arena, never re-issued
 
 
 def test_head_train_with_dropout_vs_oracle():

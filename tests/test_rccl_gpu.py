@@ -152,6 +152,55 @@ def test_graph_replay_matches_eager_bitwise():
     # covered by the bitwise equality with the eager run, whose key advances on the host)
 
 
+def test_graph_amax_arena_outlives_evaluation_passes():
+    """The captured step bakes in the addresses of the amax arena (its zero fill, the records the kernels max into and read).  Validation runs
+    eagerly between epochs and asks for thousands of records: they must come from another arena, and the captured one must stay alive and in
+    place (it used to be replaced after ~10 validation batches, and every later replay wrote into freed memory).  Graph run ==
+    eager run bit for bit across training steps, > 2048 records of evaluation forwards, and more training steps."""
+    from dualsuperreslearningforsemseg_amd import functional as HF
+    import dualsuperreslearningforsemseg_amd as D
+    from dualsuperreslearningforsemseg_amd import ddp
+    from dualsuperreslearningforsemseg_amd.command_handlers.train_or_resume import SyntheticCityscapes, TrainStep
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    HF.set_conv_precision(None)
+    res = {}
+    for graph in (False, True):
+        torch.manual_seed(999)
+        model = D.DSRL(3, cs).to(DEV).to(memory_format=torch.channels_last).train()
+        flat = ddp.FlatParams(model)
+        HF.set_dropout_seed(5)
+        was = HF.overlap_wgrad
+        HF.overlap_wgrad = False
+        try:
+            step = TrainStep(model, flat, 3, 0.1, 1.0, cs.IGNORE_CLASS_LABEL, graph=graph)
+            batches = list(SyntheticCityscapes(2, (64, 128), torch.device(DEV), length=3, distinct=1))
+            hist = [step(img, org, tgt, 0.006, 0.9, 5e-4, True)[0] for (img, org), (tgt, _) in batches]
+            dev_ = flat.device
+            arena = HF._amax_arena[dev_][0]
+            ptr, pinned = arena.data_ptr(), HF._amax_arena[dev_][3]
+            assert pinned == graph
+            model.eval()
+            (img, org), (tgt, _) = batches[0]
+            asked = 0
+            with torch.no_grad():
+                while asked <= 2 * HF._AMAX_SLOTS:
+                    before = HF._amax_loose.get(dev_, [None, 0])[1]
+                    loose_before = HF._amax_loose.get(dev_, [None, 0])[0]
+                    model(img)
+                    lo = HF._amax_loose[dev_]
+                    asked += (lo[1] - before) if lo[0] is loose_before else lo[1] + (HF._AMAX_SLOTS - before)
+            model.train()
+            assert HF._amax_arena[dev_][0] is arena and arena.data_ptr() == ptr and HF._amax_arena[dev_][1] < HF._AMAX_SLOTS
+            hist += [step(img, org, tgt, 0.006, 0.9, 5e-4, True)[0] for (img, org), (tgt, _) in batches]
+        finally:
+            HF.overlap_wgrad = was
+        torch.cuda.synchronize()
+        res[graph] = (hist, flat.p_flat.clone())
+        step.release()
+    assert all(np.isfinite(v) for h in res[True][0] for v in h)
+    assert res[False][0] == res[True][0] and torch.equal(res[False][1], res[True][1])
+
+
 def test_failed_capture_falls_back_to_eager(monkeypatch):
     """If the hipGraph capture fails, the TrainStep keeps training with eager launches (same results as a TrainStep that never tried)."""
     from dualsuperreslearningforsemseg_amd import functional as HF

@@ -6,6 +6,9 @@ STEPS = float(sys.argv[2]) if len(sys.argv) > 2 else 14.0
 GROUPS = [
     ('conv forward (conv_igemm_split_kernel, DGRAD = false)', r'conv_igemm_split_kernel<.*?, false, \d', None),
     ('conv dgrad (conv_igemm_split_kernel, DGRAD = true)', r'conv_igemm_split_kernel<.*?, true, \d', None),
+    ('conv forward, plane operands (conv_planes_kernel, DGRAD = false)', r'conv_planes_kernel<.*?, false, \d', None),
+    ('conv dgrad, plane operands (conv_planes_kernel, DGRAD = true)', r'conv_planes_kernel<.*?, true, \d', None),
+    ('plane producers (split_planes_kernel, filter_planes_batched_kernel)', r'split_planes_kernel|filter_planes_batched', None),
     ('conv fp32 MFMA kernels', r'conv_igemm_f32_kernel|conv_wgrad_f32_kernel', None),
     ('conv wgrad grouped (conv_wgrad_group_kernel)', r'conv_wgrad_group_kernel', None),
     ('conv wgrad per layer (stem) + slab reduces', r'conv_wgrad_split_kernel|wgrad_reduce', None),
@@ -19,7 +22,7 @@ GROUPS = [
     ('ConvTranspose', r'convt2x2', None),
     ('bilinear / shuffle / pools / pointwise / dropout / colsum / copies', r'bilinear|pixel_shuffle|maxpool|gap_|pointwise|dropout_kernel|colsum|copyBufferRect|pad_image|nchw|copy2d', None),
     ('one-time set-up copies (__amd_rocclr_copyBuffer)', r'__amd_rocclr_copyBuffer$', None),
-    ('SGD + filter transposes + key advance + NaN check', r'sgd|weight_transpose|rng_advance|nan_check', None),
+    ('SGD + filter transposes + key advance + NaN check', r'sgd|weight_transpose|weight_split|weight_amax|rng_advance|nan_check', None),
     ('ATen elementwise / fills', r'at::native|fillBuffer', None),
 ]
 tot = sum(float(r['TotalDurationNs']) for r in rows) / 1e6 / STEPS
