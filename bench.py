@@ -11,13 +11,14 @@ per GPU, rendezvous on 127.0.0.1) BEFORE anything touches the GPU and exits with
 torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  `value` is measured with the DEFAULT conv arithmetic, the
-fp32-equivalent "bf16x6" split (fp32 storage, fp32 accumulation, error vs fp64 equal to exact-product fp32 MFMA); the same step
-under the reduced-precision-gradient "mixed" mode and under exact-product fp32 MFMA is timed over the same step counts and listed
-in `images_per_s_by_conv_arithmetic`.  Extra objects:
+fp32-equivalent "f16x3" split (two fp16 terms of the per-tensor scaled operands, three MFMAs per product; fp32 storage, fp32
+accumulation, error vs fp64 equal to exact-product fp32 MFMA: DESIGN.md section 3b); the same step under the other arithmetics -
+"bf16x6" (round 2's fp32-equivalent split), "mixed", exact-product "fp32" MFMA and the reduced-precision "f16x1" (one fp16 MFMA per
+product: what apex O1 / O2 compute) - is timed over the same step counts and listed in `images_per_s_by_conv_arithmetic`.  Extra objects:
   roofline       - the dominant kernel (the MFMA implicit-GEMM conv family that takes the most device time): achieved in-bounds
                    (algorithmic) TFLOP/s from HIP events recorded by the library around every launch, against the dense MFMA peak
-                   of the arithmetic that kernel runs in: 157.3 TFLOP/s for fp32 MFMA, 2516.6/3 for bf16x3 and 2516.6/6 for bf16x6
-                   (three / six bf16 MFMAs per algorithmic product - DESIGN.md section 3b); every conv kernel family is listed;
+                   of the arithmetic that kernel runs in: 157.3 TFLOP/s for fp32 MFMA, 2516.6/3 for f16x3 / bf16x3 and 2516.6/6 for bf16x6
+                   (three / six 16-bit MFMAs per algorithmic product - DESIGN.md section 3b), 2516.6 for f16x1; every conv kernel family is listed;
                    `decoder_stack`: the decoder-head conv stack (north_star's 30 % target) per pass, each conv timed on its own;
   roofline_hbm   - the memory-bound kernels of the step (CE, ConvTranspose, MSE, large BatchNorm, SGD): algorithmic bytes / time
                    against the 8 TB/s HBM peak;
@@ -38,13 +39,15 @@ sys.path.insert(0, ROOT)
 # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak 157.3 TFLOP/s, dense bf16 2516.6 TFLOP/s, HBM 8 TB/s.  A split-precision
 # conv issues 3 (bf16x3) or 6 (bf16x6) bf16 MFMAs per algorithmic product, so its MFMA roof for ALGORITHMIC flops is the bf16 peak / 3 or / 6.
 BF16_MFMA_PEAK_TFLOPS = 2516.6
-MFMA_PEAK_TFLOPS = {0: 157.3, 1: BF16_MFMA_PEAK_TFLOPS / 3, 2: BF16_MFMA_PEAK_TFLOPS / 6, 3: BF16_MFMA_PEAK_TFLOPS / 3}      # by arithmetic: fp32, bf16x3, bf16x6, f16x3
-ARITH_NAME = {0: 'fp32', 1: 'bf16x3', 2: 'bf16x6', 3: 'f16x3'}
+MFMA_PEAK_TFLOPS = {0: 157.3, 1: BF16_MFMA_PEAK_TFLOPS / 3, 2: BF16_MFMA_PEAK_TFLOPS / 6, 3: BF16_MFMA_PEAK_TFLOPS / 3, 4: BF16_MFMA_PEAK_TFLOPS}      # by arithmetic: fp32, bf16x3, bf16x6, f16x3, f16x1
+ARITH_NAME = {0: 'fp32', 1: 'bf16x3', 2: 'bf16x6', 3: 'f16x3', 4: 'f16x1'}
 HBM_PEAK_GBS = 8000.0
 ARITH_TEXT = {'fp32': 'exact-product fp32 MFMA', 'bf16x3': 'bf16x3 split, fp32 accumulate', 'bf16x6': 'bf16x6 split (fp32-equivalent), fp32 accumulate',
               'mixed': 'forward bf16x6 (fp32-equivalent), dgrad/wgrad bf16x3 (reduced-precision gradients); fp32 storage and accumulation',
               'f16x3': 'f16x3 split (two fp16 terms of the per-tensor power-of-two scaled operands, 3 MFMAs per product; fp32-equivalent: error vs fp64 '
-                       'equal to exact-product fp32 MFMA), fp32 storage and accumulation'}
+                       'equal to exact-product fp32 MFMA), fp32 storage and accumulation',
+              'f16x1': 'f16x1 (ONE fp16 term of the per-tensor scaled operands, one MFMA per product, fp32 storage and accumulation: the reduced-precision '
+                       'arithmetic of apex O1 / O2)'}
 
 
 def parse_args():
@@ -158,7 +161,7 @@ def decoder_stack_roofline(torch, HF, B, H, W, reps=10):
               ('cat_conv.0 3x3 304->256', 304, h4, w4, 256, 3, 1, 1), ('cat_conv.4 3x3 256->256', 256, h4, w4, 256, 3, 1, 1), ('cls_conv 1x1 256->19', 256, h4, w4, 19, 1, 0, 1),
               ('SISR 3x3 304->192', 304, h4, w4, 192, 3, 1, 1)]
     mode = HF.get_conv_precision()
-    arith = {'fp32': (0, 0, 0), 'bf16x3': (1, 1, 1), 'bf16x6': (2, 2, 2), 'mixed': (2, 1, 1), 'f16x3': (3, 3, 3)}[mode]       # forward, dgrad, wgrad
+    arith = {'fp32': (0, 0, 0), 'bf16x3': (1, 1, 1), 'bf16x6': (2, 2, 2), 'mixed': (2, 1, 1), 'f16x3': (3, 3, 3), 'f16x1': (4, 4, 4)}[mode]       # forward, dgrad, wgrad
     tot = {'forward': [0.0, 0.0], 'dgrad': [0.0, 0.0], 'wgrad_per_layer': [0.0, 0.0], 'wgrad': [0.0, 0.0]}
     layers, keep, keep_probs = {}, [], []
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -387,7 +390,7 @@ def main():
     if not args.no_prof:
         gb = args.batch * world
         by_arith = {default_mode: round(gb * args.steps / elapsed, 1)}
-        for mode in ('f16x3', 'bf16x6', 'mixed', 'fp32'):
+        for mode in ('f16x3', 'f16x1', 'bf16x6', 'mixed', 'fp32'):
             if mode == default_mode or (mode == 'fp32' and world > 1):        # exact-product fp32 MFMA: single-GPU figure only
                 continue
             HF.set_conv_precision(mode)
@@ -402,7 +405,7 @@ def main():
         batch_now[:] = [img5, org5, tgt5]
         config5 = {'workload': 'the same stage-3 step at 512x1024 input -> 1024x2048 logits, per-GPU batch 8 (BASELINE.json configs[4] on one GPU), 4 untimed + 8 timed steps',
                    'steps': 8, 'images_per_s_by_conv_arithmetic': {}}
-        for mode in (default_mode, 'bf16x3'):           # bf16x3: the reduced-precision ('O2') arithmetic that configuration names
+        for mode in (default_mode, 'f16x1'):            # f16x1: the reduced-precision arithmetic that configuration names ('fp16 MFMA convs' = apex O1 / O2: one fp16 MMA per product)
             HF.set_conv_precision(mode)
             el5, l5 = timed(4, 8)
             config5['images_per_s_by_conv_arithmetic'][mode] = round(args.batch * 8 / el5, 1)
@@ -415,7 +418,7 @@ def main():
 
     def read_prof(nsteps, stride=1):
         fams = []
-        for fam in range(12):                # family = 3 * arithmetic + pass (include/dsrl_hip.h)
+        for fam in range(15):                # family = 3 * arithmetic + pass (include/dsrl_hip.h)
             n = ctypes.c_int64(0); ms = ctypes.c_double(0); fl = ctypes.c_double(0)
             _lib.check(lib.dsrl_prof_read(fam, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), 'dsrl_prof_read')
             by = ctypes.c_double(0)

@@ -275,7 +275,7 @@ void conv_igemm_split_kernel(const ConvArgs a) {
     constexpr bool F16 = ARITH != 0, PREB = ARITH == 2;
     constexpr int NT = 64 * WGM * WGN, RP = NT / 4;          // threads of one K group; rows per staging pass (4 lanes per row)
     static_assert(NT == 256 || (NT == 512 && KG == 1), "4 waves per K group, or one group of 8 waves");
-    static_assert(!F16 || NPL == 2, "f16x3 carries two fp16 terms per operand");
+    static_assert(!F16 || NPL <= 2, "f16x3 carries two fp16 terms per operand, f16x1 one");
     using PT = Plane<F16>;
     using pl4 = typename PT::v4; using pl8 = typename PT::v8;
     // f16x3 operand scales: both records are requested before anything else and consumed behind the first operand loads (in-order return:
@@ -445,7 +445,7 @@ void conv_igemm_split_kernel(const ConvArgs a) {
                 const float4 x = R[v][hf];
                 char* q = nb + (NPL * BM + r0 + RP * (v - A_IT)) * ROWB + w_swz;
                 *reinterpret_cast<uint2*>(q) = make_uint2(__float_as_uint(x.x), __float_as_uint(x.y));
-                *reinterpret_cast<uint2*>(q + BN * ROWB) = make_uint2(__float_as_uint(x.z), __float_as_uint(x.w));
+                if (NPL > 1) *reinterpret_cast<uint2*>(q + BN * ROWB) = make_uint2(__float_as_uint(x.z), __float_as_uint(x.w));       // f16x1 uses the first terms only
             }
             return;
         }
@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs a) 
 // its own two LDS stages; the KG accumulator sets are summed through LDS in a fixed order - KG times fewer slabs to write and reduce.
 template <int MR, int NR, int WGM, int WGN, int NPL, int KG, bool F16 = false>
 __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int bid) {
-    static_assert(!F16 || NPL == 2, "f16x3 carries two fp16 terms per operand");
+    static_assert(!F16 || NPL <= 2, "f16x3 carries two fp16 terms per operand, f16x1 one");
     using PT = Plane<F16>;
     using pl4 = typename PT::v4; using pl8 = typename PT::v8;
     // f16x3 operand scales: records requested first, consumed behind the first operand loads (see conv_igemm_split_kernel)
@@ -1587,7 +1587,7 @@ static long long cfg_blocks(TileCfg c, long long M, int N) { return ceil_div(M, 
 static int conv_precision_mode();
 static TileCfg pick_cfg(long long M, int N) {
     const int forced = env_int("DSRL_FORCE_CFG", -1);
-    if (forced >= 0 && forced < kNumCfg && (forced < kNumCfg4 || conv_precision_mode() == 4)) return (TileCfg)forced;
+    if (forced >= 0 && forced < kNumCfg && (forced < kNumCfg4 || conv_precision_mode() >= 4)) return (TileCfg)forced;
     if (N <= 32) return cfg_blocks(T256x32, M, N) >= 3 * kNumCU ? T256x32 : T128x32;
     const int r = N % 128;
     const bool narrow = N <= 64 || (r > 0 && r <= 64);
@@ -1629,28 +1629,33 @@ static int pick_splits(long long tiles, int nq) {
 //   2  bf16x6 everywhere   (24 mantissa bits per operand: fp32-equivalent, measured error vs fp64 equal to mode 0)
 //   3  forward bf16x6, dgrad / wgrad bf16x3 (logits keep fp32 accuracy, gradients carry ~5e-6)
 //   4  f16x3 everywhere    (two fp16 terms per operand + per-tensor power-of-two scales: 22 mantissa bits, fp32-equivalent, 3 MFMAs)
+//   5  f16x1 everywhere    (ONE fp16 term of the scaled operands, one MFMA per product, fp32 accumulate: the arithmetic of apex O1 / O2 - reduced
+//                           precision, 11 mantissa bits per operand; the per-tensor scales stand in for loss scaling)
 // Returns the number of 16-bit planes per operand for the pass (0 = fp32 kernel); conv_f16(): are they fp16 (mode 4) or bf16.
 enum ConvPass { PASS_FWD, PASS_DGRAD, PASS_WGRAD };
 static int conv_precision_mode() {
     int prec = g_conv_precision.load();
     if (prec < 0) prec = env_int("DSRL_CONV_PRECISION", 4);
-    return prec < 0 ? 0 : (prec > 4 ? 4 : prec);
+    return prec < 0 ? 0 : (prec > 5 ? 5 : prec);
 }
-static bool conv_f16() { return conv_precision_mode() == 4; }
+static bool conv_f16() { return conv_precision_mode() >= 4; }
+static bool conv_f16x3() { return conv_precision_mode() == 4; }
 static int conv_planes(ConvPass pass) {
     switch (conv_precision_mode()) {
         case 0: return 0;
         case 1: return 2;
         case 2: return 3;
         case 4: return 2;
+        case 5: return 1;
         default: return pass == PASS_FWD ? 3 : 2;
     }
 }
 
-// launch-timer family = 3 * arithmetic (0 fp32, 1 bf16x3, 2 bf16x6, 3 f16x3) + pass (0 forward, 1 wgrad, 2 dgrad)
+// launch-timer family = 3 * arithmetic (0 fp32, 1 bf16x3, 2 bf16x6, 3 f16x3, 4 f16x1) + pass (0 forward, 1 wgrad, 2 dgrad)
+static int prof_arith(int npl, bool f16) { return f16 ? (npl == 1 ? 4 : 3) : (npl ? npl - 1 : 0); }
 static int prof_family(ConvPass pass) {
     const int npl = conv_planes(pass);
-    return 3 * (conv_f16() ? 3 : (npl ? npl - 1 : 0)) + (pass == PASS_FWD ? 0 : (pass == PASS_WGRAD ? 1 : 2));
+    return 3 * prof_arith(npl, conv_f16()) + (pass == PASS_FWD ? 0 : (pass == PASS_WGRAD ? 1 : 2));
 }
 
 // f16x3 operand scales the caller did not provide: measured into two zeroed words at `scratch` (kAmaxScratch bytes at the end of the
@@ -1726,7 +1731,7 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
                 (void)attr;                                                                                                            \
                 hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, NPL_, KG_, F16_, S1_>), grid, dim3(256 * KG_), lds, st, a); \
             }
-#define DSRL_KG_BY_ARITH(a_, b_, c_, d_, KG_) { if (f16 && a.w_split && s1) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 2, DGRAD) else if (f16 && a.w_split) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 2, false) else if (f16) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 1, false) else if (npl == 2) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 0, false) else DSRL_LAUNCH_KG(a_, b_, c_, d_, 3, KG_, 0, false) }
+#define DSRL_KG_BY_ARITH(a_, b_, c_, d_, KG_) { if (f16 && npl == 1 && a.w_split) DSRL_LAUNCH_KG(a_, b_, c_, d_, 1, KG_, 2, false) else if (f16 && npl == 1) DSRL_LAUNCH_KG(a_, b_, c_, d_, 1, KG_, 1, false) else if (f16 && a.w_split && s1) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 2, DGRAD) else if (f16 && a.w_split) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 2, false) else if (f16) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 1, false) else if (npl == 2) DSRL_LAUNCH_KG(a_, b_, c_, d_, 2, KG_, 0, false) else DSRL_LAUNCH_KG(a_, b_, c_, d_, 3, KG_, 0, false) }
             if (cfg == T64x64) {
                 if (kg == 4) DSRL_KG_BY_ARITH(1, 1, 2, 2, 4) else DSRL_KG_BY_ARITH(1, 1, 2, 2, 2)
             } else if (cfg == T128x64) {
@@ -1742,7 +1747,13 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
         if (cfg == T256x128 || cfg == T256x256) {               // 8 waves; f16x3 with or without pre-split filters, and bf16x6
 #define DSRL_LAUNCH_BIG(a_, b_, c_, d_)                                                                                                   \
             {                                                                                                                              \
-                if (f16 && a.w_split && s1) {                                                                                              \
+                if (f16 && npl == 1 && a.w_split) {                                                                                        \
+                    static const hipError_t at_ = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 1, 1, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); (void)at_; \
+                    hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 1, 1, 2, false>), grid, dim3(512), lds2, st, a);      \
+                } else if (f16 && npl == 1) {                                                                                              \
+                    static const hipError_t at_ = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); (void)at_; \
+                    hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 1, 1, 1>), grid, dim3(512), lds2, st, a);             \
+                } else if (f16 && a.w_split && s1) {                                                                                       \
                     static const hipError_t at_ = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2, DGRAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); (void)at_; \
                     hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2, DGRAD>), grid, dim3(512), lds2, st, a);      \
                 } else if (f16 && a.w_split) {                                                                                             \
@@ -1760,14 +1771,16 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
             return launch_status("conv_igemm_split_kernel<f16x3, 8 waves>");
         }
 #define DSRL_LAUNCH_SPLIT(a_, b_, c_, d_)                                                                                    \
-        if (f16 && a.w_split && s1) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2, DGRAD>), grid, dim3(256), lds2, st, a); \
+        if (f16 && npl == 1 && a.w_split) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 1, 1, 2, false>), grid, dim3(256), lds2, st, a); \
+        else if (f16 && npl == 1) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 1, 1, 1>), grid, dim3(256), lds2, st, a); \
+        else if (f16 && a.w_split && s1) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2, DGRAD>), grid, dim3(256), lds2, st, a); \
         else if (f16 && a.w_split) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2>), grid, dim3(256), lds2, st, a); \
         else if (f16) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 1>), grid, dim3(256), lds2, st, a); \
         else if (npl == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2>), grid, dim3(256), lds2, st, a); \
         else hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 3>), grid, dim3(256), lds2, st, a);
         DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_SPLIT)
 #undef DSRL_LAUNCH_SPLIT
-        return launch_status(f16 ? "conv_igemm_split_kernel<f16x3>" : (npl == 2 ? "conv_igemm_split_kernel<bf16x3>" : "conv_igemm_split_kernel<bf16x6>"));
+        return launch_status(f16 ? (npl == 1 ? "conv_igemm_split_kernel<f16x1>" : "conv_igemm_split_kernel<f16x3>") : (npl == 2 ? "conv_igemm_split_kernel<bf16x3>" : "conv_igemm_split_kernel<bf16x6>"));
     }
     const size_t lds1 = (size_t)(bm + bn) * LDS_LD * sizeof(float);
     const bool dbuf = env_int("DSRL_IGEMM_DBUF", 0) != 0;     // measured: no gain from the two-stage LDS variant; kept selectable
@@ -1829,7 +1842,7 @@ static int pick_kg(long long tiles, int nq, TileCfg cfg, int npl) {
 static void pick_split_plan(long long M, int N, int nq, bool dgrad, TileCfg& cfg, int& splits, int& kg) {
     const bool forced = env_int("DSRL_FORCE_CFG", -1) >= 0 || env_int("DSRL_FORCE_SPLITS", 0) > 0 || env_int("DSRL_FORCE_KG", 0) > 0;
     if (forced || N <= 32 || !env_int("DSRL_SPLIT_PLAN", 1)) return;
-    if (conv_precision_mode() == 4 && env_int("DSRL_BIG_TILES", 1) && N >= 192 && nq >= 32) {                                         // d)
+    if (conv_precision_mode() >= 4 && env_int("DSRL_BIG_TILES", 1) && N >= 192 && nq >= 32) {                                         // d)
         if (!dgrad && cfg_blocks(T256x256, M, N) >= kNumCU) { cfg = T256x256; splits = 1; kg = 1; return; }
         if (dgrad && cfg_blocks(T256x128, M, N) >= 2 * kNumCU) { cfg = T256x128; splits = 1; kg = 1; return; }
         if (!dgrad && nq >= 256 && cfg_blocks(T256x128, M, N) * 8 >= kNumCU && cfg_blocks(T128x128, M, N) < kNumCU) { cfg = T256x128; splits = 8; kg = 1; return; }
@@ -1939,7 +1952,7 @@ static int fwd_impl(const float* x, int ldx, const float* w, const float* bias, 
         }
         // both operands as fp16 planes carrying the scales of THESE records (dsrl_split_planes / dsrl_conv2d_filter_planes_batched): same tile plan,
         // same summation order, staged by LDS-DMA
-        if (x_planes != nullptr && w_planes != nullptr && x_amax != nullptr && w_amax != nullptr && planes_usable(C, ldx, x_planes, w_planes) &&
+        if (conv_f16x3() && x_planes != nullptr && w_planes != nullptr && x_amax != nullptr && w_amax != nullptr && planes_usable(C, ldx, x_planes, w_planes) &&
             planes_cfg_supported((int)p.cfg, p.kg)) {
             const long long pe = (long long)N * H * W * ldx, we = (long long)K * R * S * C;
             a.planes = 1; a.w_split = 0;
@@ -2056,7 +2069,7 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
     DSRL_REQUIRE(ws && ws_bytes >= wtb + p.ws, DSRL_E_WORKSPACE, "conv2d_dgrad: workspace %zu < %zu", ws_bytes, wtb + p.ws);
     const float* wt = wt_in;
     float* slabs = (float*)((char*)ws + wtb);
-    const bool use_planes = conv_f16() && dy_planes != nullptr && wt_planes != nullptr && dy_amax != nullptr && w_amax != nullptr && stride == 1 && K % 8 == 0 &&
+    const bool use_planes = conv_f16x3() && dy_planes != nullptr && wt_planes != nullptr && dy_amax != nullptr && w_amax != nullptr && stride == 1 && K % 8 == 0 &&
                             planes_usable(K, lddy, dy_planes, wt_planes) && planes_cfg_supported((int)p.cfg, p.kg);
     const bool use_split = conv_f16() && wt_split != nullptr && w_amax != nullptr && env_int("DSRL_PRESPLIT", 1);
     if (wt == nullptr && use_planes) wt = (const float*)wt_planes;       // replaced below; no fp32 transpose is built for it
@@ -2160,7 +2173,7 @@ static void launch_wgrad(const WgradArgs& a_in, TileCfg cfg, int bm, int bn, dim
                 (void)attr;                                                                                                          \
                 hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, NPL_, KG_, F16_>), grid, dim3(256 * KG_), lds, st, a);   \
             }
-#define DSRL_WKG_BY_NPL(a_, b_, c_, d_, KG_) { if (f16) DSRL_LAUNCH_WKG(a_, b_, c_, d_, 2, KG_, true) else if (npl == 2) DSRL_LAUNCH_WKG(a_, b_, c_, d_, 2, KG_, false) else DSRL_LAUNCH_WKG(a_, b_, c_, d_, 3, KG_, false) }
+#define DSRL_WKG_BY_NPL(a_, b_, c_, d_, KG_) { if (f16 && npl == 1) DSRL_LAUNCH_WKG(a_, b_, c_, d_, 1, KG_, true) else if (f16) DSRL_LAUNCH_WKG(a_, b_, c_, d_, 2, KG_, true) else if (npl == 2) DSRL_LAUNCH_WKG(a_, b_, c_, d_, 2, KG_, false) else DSRL_LAUNCH_WKG(a_, b_, c_, d_, 3, KG_, false) }
             if (cfg == T64x64) { if (kg == 4) DSRL_WKG_BY_NPL(1, 1, 2, 2, 4) else DSRL_WKG_BY_NPL(1, 1, 2, 2, 2) }
             else if (cfg == T128x64) { if (kg == 4) DSRL_WKG_BY_NPL(2, 1, 2, 2, 4) else DSRL_WKG_BY_NPL(2, 1, 2, 2, 2) }
             else if (cfg == T64x128) { if (kg == 4) DSRL_WKG_BY_NPL(1, 2, 2, 2, 4) else DSRL_WKG_BY_NPL(1, 2, 2, 2, 2) }
@@ -2171,7 +2184,8 @@ static void launch_wgrad(const WgradArgs& a_in, TileCfg cfg, int bm, int bn, dim
         }
         const size_t lds = stages;
 #define DSRL_LAUNCH_WGRAD(a_, b_, c_, d_)                                                                           \
-        if (f16) hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, 2, 1, true>), grid, dim3(256), lds, st, a); \
+        if (f16 && npl == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, 1, 1, true>), grid, dim3(256), lds, st, a); \
+        else if (f16) hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, 2, 1, true>), grid, dim3(256), lds, st, a); \
         else if (npl == 2) hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, 2>), grid, dim3(256), lds, st, a); \
         else hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, 3>), grid, dim3(256), lds, st, a);
         DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_WGRAD)
@@ -2429,7 +2443,7 @@ extern "C" int dsrl_conv2d_wgrad_group_plan(const dsrl_wgrad_problem* problems, 
     DSRL_REQUIRE(table_bytes >= group_table_bytes(n), DSRL_E_WORKSPACE, "conv2d_wgrad_group_plan: table %zu < %zu bytes", table_bytes, group_table_bytes(n));
     DSRL_REQUIRE(((uintptr_t)dev_table % 16) == 0 && ((uintptr_t)host_table % 16) == 0, DSRL_E_BADARG, "conv2d_wgrad_group_plan: tables must be 16-byte aligned");
     const int npl = conv_planes(PASS_WGRAD);
-    DSRL_REQUIRE(npl == 2 || npl == 3, DSRL_E_UNSUPPORTED, "conv2d_wgrad_group_plan: the grouped launch exists for the split-precision arithmetics only (dsrl_conv_precision 1..3)");
+    DSRL_REQUIRE(npl >= 1 && npl <= 3, DSRL_E_UNSUPPORTED, "conv2d_wgrad_group_plan: the grouped launch exists for the 16-bit MFMA arithmetics only (dsrl_conv_precision 1..5)");
     std::vector<GroupItem> items((size_t)n);
     size_t need_ws = 0;
     for (int i = 0; i < n; ++i) {
@@ -2496,9 +2510,10 @@ extern "C" int dsrl_conv2d_wgrad_group_launch(const void* host_table, const void
         const size_t lds = (size_t)2 * npl * 16 * ((bm * 2 + 64) + (bn * 2 + 64));
         const WgradArgs* t = dargs + L.first;
         const int* s = dstarts + L.first;
-        ProfScope prof(3 * (h->f16 ? 3 : npl - 1) + 1, L.flops, L.bytes, st);
+        ProfScope prof(3 * prof_arith(npl, h->f16 != 0) + 1, L.flops, L.bytes, st);
 #define DSRL_LAUNCH_WGROUP(a_, b_, c_, d_)                                                                                         \
-        if (h->f16) hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 2, true>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count); \
+        if (h->f16 && npl == 1) hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 1, true>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count); \
+        else if (h->f16) hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 2, true>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count); \
         else if (npl == 2) hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 2>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count); \
         else hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 3>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count);
         DSRL_CFG_SWITCH((TileCfg)L.cfg, DSRL_LAUNCH_WGROUP)
@@ -2620,7 +2635,7 @@ extern "C" int dsrl_conv2d_rowfold_wgrad(const float* x, int ldx, const float* d
 
 extern "C" int dsrl_conv_precision(int mode) {
     const int prev = g_conv_precision.load();
-    if (mode >= -1 && mode <= 4) g_conv_precision.store(mode);
+    if (mode >= -1 && mode <= 5) g_conv_precision.store(mode);
     return prev;
 }
 
@@ -2664,10 +2679,11 @@ extern "C" int dsrl_prof_read_bytes(int family, double* total_bytes) {
 }
 
 extern "C" const char* dsrl_prof_kernel_name(int family) {
-    static const char* names[12] = {
+    static const char* names[15] = {
         "conv_igemm_f32_kernel (forward)", "conv_wgrad_f32_kernel", "conv_igemm_f32_kernel (dgrad)",
         "conv_igemm_split_kernel<bf16x3> (forward)", "conv_wgrad_split_kernel<bf16x3>", "conv_igemm_split_kernel<bf16x3> (dgrad)",
         "conv_igemm_split_kernel<bf16x6> (forward)", "conv_wgrad_split_kernel<bf16x6>", "conv_igemm_split_kernel<bf16x6> (dgrad)",
-        "conv_igemm_split_kernel<f16x3> (forward)", "conv_wgrad_split_kernel<f16x3>", "conv_igemm_split_kernel<f16x3> (dgrad)"};
-    return family >= 0 && family < 12 ? names[family] : "";
+        "conv_igemm_split_kernel<f16x3> (forward)", "conv_wgrad_split_kernel<f16x3>", "conv_igemm_split_kernel<f16x3> (dgrad)",
+        "conv_igemm_split_kernel<f16x1> (forward)", "conv_wgrad_split_kernel<f16x1>", "conv_igemm_split_kernel<f16x1> (dgrad)"};
+    return family >= 0 && family < 15 ? names[family] : "";
 }

@@ -253,7 +253,7 @@ class FlatParams:
                 HF.call('dsrl_conv2d_transpose_filters_batched', (self._amax_only_table if presplit else self._wt_table).data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
             if presplit:
                 HF.call('dsrl_conv2d_split_filters_batched', self._split_table.data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
-            planes = presplit and HF.planes_mode != 'off'
+            planes = presplit and HF.planes_mode != 'off' and HF.get_conv_precision() == 'f16x3'
             if planes:
                 if self._planes_table is None or (HF.planes_mode != 'all' and
                                                   self._planes_wanted != sum(1 for e in self._split_entries if getattr(e[0], '_dsrl_want_planes', False))):

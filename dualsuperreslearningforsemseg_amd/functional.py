@@ -38,17 +38,18 @@ overlap_wgrad = os.environ.get('DSRL_OVERLAP_WGRAD', '1') != '0'     # measured:
 pretranspose_filters = os.environ.get('DSRL_PRETRANSPOSE', '0') != '0'
 
 
-CONV_PRECISION_MODES = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'mixed': 3, 'f16x3': 4}
+CONV_PRECISION_MODES = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'mixed': 3, 'f16x3': 4, 'f16x1': 5}
 DEFAULT_CONV_PRECISION = 4
 
 
 def set_conv_precision(mode):
     """Arithmetic of the conv kernels (include/dsrl_hip.h: dsrl_conv_precision): 'fp32' (exact fp32 MFMA products), 'bf16x3',
-    'bf16x6' (fp32-equivalent), 'mixed' (forward bf16x6, backward bf16x3) or 'f16x3' (two fp16 terms of the per-tensor scaled
-    operands: fp32-equivalent at half the matrix work of bf16x6; the default since round 3); None follows DSRL_CONV_PRECISION.
+    'bf16x6' (fp32-equivalent), 'mixed' (forward bf16x6, backward bf16x3), 'f16x3' (two fp16 terms of the per-tensor scaled
+    operands: fp32-equivalent at half the matrix work of bf16x6; the default since round 3) or 'f16x1' (ONE fp16 term, one MFMA per
+    product, fp32 accumulation: apex O1 / O2's arithmetic, the reduced-precision mode); None follows DSRL_CONV_PRECISION.
     Returns the previous setting as the library reported it (an int, -1 = environment)."""
     code = -1 if mode is None else (CONV_PRECISION_MODES[mode] if isinstance(mode, str) else int(mode))
-    if not -1 <= code <= 4:
+    if not -1 <= code <= 5:
         raise ValueError(f'conv precision mode {mode!r}')
     _mode_cache.clear()
     return int(_lib.load().dsrl_conv_precision(code))
@@ -62,7 +63,7 @@ def _conv_precision_code():
     if code is None:
         prev = int(_lib.load().dsrl_conv_precision(-2))          # out-of-range argument: query only
         code = prev if prev >= 0 else int(os.environ.get('DSRL_CONV_PRECISION', str(DEFAULT_CONV_PRECISION)))
-        code = _mode_cache['code'] = min(max(code, 0), 4)
+        code = _mode_cache['code'] = min(max(code, 0), 5)
     return code
 
 
@@ -147,7 +148,8 @@ def amax_slot(device):
 
 
 def f16_mode():
-    return _conv_precision_code() == 4
+    """The conv kernels scale their operands by per-tensor powers of two (amax records): 'f16x3' and 'f16x1'."""
+    return _conv_precision_code() >= 4
 
 
 def set_amax(t, slot):
@@ -510,7 +512,7 @@ planes_min_elems = int(os.environ.get('DSRL_PLANES_MIN_ELEMS', str(8 << 20)))
 def planes_wanted(data, ld, C, K, taps=9):
     """Would a conv with this activation operand take planes if its filter had them? (planes_mode 'auto' / 'all'; both channel counts multiples of 8;
     'auto': long K loops over large operands only - the 3x3 decoder convs)"""
-    if planes_mode == 'off' or C % 8 or K % 8 or ld % 8 or data.data_ptr() % 16:
+    if planes_mode == 'off' or _conv_precision_code() != 4 or C % 8 or K % 8 or ld % 8 or data.data_ptr() % 16:
         return False
     N, Cc, H, W = data.shape
     return planes_mode == 'all' or (N * H * W * Cc >= planes_min_elems and taps >= 9)
@@ -519,7 +521,7 @@ def planes_wanted(data, ld, C, K, taps=9):
 def planes_for(t, data, ld, amax, taps=9, split_ok=True):
     """fp16 planes of operand tensor `t` (pixel-major copy `data`, pixel stride ld) scaled by ITS record `amax`, or None: the planes the tensor
     carries (left by its producer or by an earlier consumer of the same tensor in this step), else a split pass when planes_mode allows one."""
-    if planes_mode == 'off' or amax is None:
+    if planes_mode == 'off' or amax is None or _conv_precision_code() != 4:
         return None
     have = getattr(t, '_dsrl_planes', None)
     if have is not None and have[1] == ld and have[2] == amax.data_ptr() and have[3] == data.data_ptr() and have[4] == t._version:
@@ -585,10 +587,10 @@ def peek_next_seed():
 
 
 def begin_forward(training=True):
-    """Called once per model forward: all Dropout modules of that pass share one key and differ by stream id.  An evaluation pass draws
-    no mask: while a DeviceRng is bound (the device derives the key per TRAINING step) it must not advance the host mirror either, or the
-    two would drift apart by one step per validation batch."""
-    if not training and DeviceRng._active:
+    """Called once per model forward: all Dropout modules of that pass share one key and differ by stream id.  An evaluation pass draws no mask
+    and does not advance the key (torch's generator is not consumed by eval-mode Dropout either): the key sequence of the training steps is the
+    same with and without validation passes in between, and the same for eager launches and for a graph whose key lives on the device."""
+    if not training:
         return _rng_state['current']
     _rng_state['step'] += 1
     _rng_state['current'] = _derive(_rng_state['step'])

@@ -27,7 +27,9 @@ VARIABLES_IN_CHECKPOINT = \
      'Avg_train_loss', 'CE_val_avg_loss', 'MSE_val_avg_loss', 'FA_val_avg_loss', 'Avg_val_loss', 'epoch', 'best_validation_dict', 'model_state_dict',
      'optimizer_state_dict', 'amp_state_dict']
 # `mixed_precision` (apex opt levels in the reference, train_or_resume.py:68-72) selects the arithmetic of the MFMA conv kernels here
-MIXED_PRECISION_TO_CONV_ARITHMETIC = {None: None, '': None, 'O0': 'f16x3', 'O1': 'mixed', 'O2': 'bf16x3', 'O3': 'bf16x3'}
+# O0 = fp32 behaviour ('f16x3': fp32-equivalent products); O1 / O2 / O3 = the reference's fp16 tensor-core arithmetic (one fp16 MMA per product, fp32
+# accumulation: 'f16x1'; the per-tensor operand scales of the kernels stand in for apex's loss scaling) - never slower than O0
+MIXED_PRECISION_TO_CONV_ARITHMETIC = {None: None, '': None, 'O0': 'f16x3', 'O1': 'f16x1', 'O2': 'f16x1', 'O3': 'f16x1'}
 STAGES = [1, 2, 3]
 MODEL_INPUT_SIZE = (256, 512)                                   # settings.py:62 (a parameter here, not a constant)
 MODEL_OUTPUT_SIZE = tuple(x * 2 for x in MODEL_INPUT_SIZE)

@@ -187,6 +187,9 @@ int dsrl_conv2d_wgrad_amax(const float* x, int ldx, const uint32_t* x_amax, cons
  *   3  "mixed": forward bf16x6, dgrad / wgrad bf16x3 (reduced-precision gradients, ~5e-6)
  *   4  "f16x3": operand = 2 fp16 terms of the per-tensor scaled value (22 mantissa bits), 3 fp16 MFMAs per product; error vs fp64 equal
  *      to modes 0 and 2 at half the matrix work of mode 2 (operand magnitudes: see dsrl_amax above); the default
+ *   5  "f16x1": operand = ONE fp16 term of the per-tensor scaled value (11 significand bits), one fp16 MFMA per product, fp32 accumulation:
+ *      the arithmetic of the reference's apex O1 / O2 runs (train_or_resume.py:68-72) - reduced precision (~5e-4 of the output range per conv);
+ *      the operand scales of mode 4 stand in for loss scaling
  *  -1  follow the environment variable DSRL_CONV_PRECISION (unset = 4)
  * Any other value changes nothing (query). Returns the previous setting. */
 int dsrl_conv_precision(int mode);

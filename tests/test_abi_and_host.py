@@ -132,8 +132,8 @@ def test_conv_precision_api_roundtrip():
     from dualsuperreslearningforsemseg_amd import functional as HF
     HF.set_conv_precision(None)
     default = HF.get_conv_precision()
-    assert default == {'0': 'fp32', '1': 'bf16x3', '2': 'bf16x6', '3': 'mixed', '4': 'f16x3'}[os.environ.get('DSRL_CONV_PRECISION', '4')]
-    for mode in ('fp32', 'bf16x3', 'bf16x6', 'mixed', 'f16x3'):
+    assert default == {'0': 'fp32', '1': 'bf16x3', '2': 'bf16x6', '3': 'mixed', '4': 'f16x3', '5': 'f16x1'}[os.environ.get('DSRL_CONV_PRECISION', '4')]
+    for mode in ('fp32', 'bf16x3', 'bf16x6', 'mixed', 'f16x3', 'f16x1'):
         HF.set_conv_precision(mode)
         assert HF.get_conv_precision() == mode
     with pytest.raises((KeyError, ValueError)):

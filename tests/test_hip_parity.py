@@ -74,13 +74,15 @@ def test_conv_bias_gradient_column_sums(K):
     check(host(bt.grad), dy.astype(np.float64).sum((0, 2, 3)), 1e-5, 'db')
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16x6', 'mixed', 'bf16x3', 'f16x3'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16x6', 'mixed', 'bf16x3', 'f16x3', 'f16x1'])
 @pytest.mark.parametrize('shape', [(2, 304, 32, 64, 192, 3, 1, 1, 1), (2, 512, 16, 32, 256, 3, 1, 6, 6), (2, 256, 33, 47, 100, 3, 2, 1, 1),
                                    (4, 1024, 16, 32, 256, 1, 1, 0, 1)])
 def test_conv_precision_modes(mode, shape):
     """The five arithmetic modes of the MFMA conv kernels against the fp64 oracle: exact-product fp32, bf16x6 and f16x3 are
     fp32-equivalent (3e-6 of the output range), bf16x3 carries 16 mantissa bits per operand (3e-5); 'mixed' = bf16x6 forward,
-    bf16x3 backward.  Every mode is far inside the 1e-3 gate."""
+    bf16x3 backward.  Every one of them is far inside the 1e-3 gate.  'f16x1' is the reduced-precision arithmetic of apex O1 / O2 (one fp16
+    term per operand = 11 significand bits, one MFMA per product, fp32 accumulation): 5e-4 of the output range on these shapes - what the
+    reference's own mixed-precision runs compute, not an fp32-equivalent mode."""
     N, C, H, W, K, R, stride, pad, dil = shape
     rs = np.random.RandomState(sum(shape) + 1)
     x = np.maximum(rs.standard_normal((N, C, H, W)), 0).astype(np.float32)
@@ -93,8 +95,8 @@ def test_conv_precision_modes(mode, shape):
     xt = dev(x).requires_grad_(True); wt = dev(w).requires_grad_(True)
     y = HF.conv2d(xt, wt, None, stride, pad, dil)
     y.backward(dev(dy))
-    tol_f = 3e-5 if mode == 'bf16x3' else 3e-6
-    tol_b = 3e-5 if mode in ('bf16x3', 'mixed') else 3e-6
+    tol_f = 5e-4 if mode == 'f16x1' else (3e-5 if mode == 'bf16x3' else 3e-6)
+    tol_b = 5e-4 if mode == 'f16x1' else (3e-5 if mode in ('bf16x3', 'mixed') else 3e-6)
     e = (check(host(y), yo, tol_f, 'y'), check(host(xt.grad), dxo, tol_b, 'dx'), check(host(wt.grad), dwo, tol_b, 'dw'))
     print(mode, shape, ['%.1e' % v for v in e])
 
@@ -222,7 +224,7 @@ def test_planes_kernel_bit_identical_to_register_staged(shape, cfg, kg, monkeypa
     xp, dyp = HF.planes_of(x, C, xa), HF.planes_of(dy, K, dya)
     # the planes are the two terms of the scaled values
     P = N * H * W
-    ex = int((int(host(xa.view(torch.int32)).view(np.uint32).max()) >> 23) & 0xff)
+    ex = int((int(xa.cpu().numpy().view(np.uint32).max()) >> 23) & 0xff)
     xs = np.ldexp(host(x).transpose(0, 2, 3, 1).reshape(P, C).astype(np.float32), 14 - (ex - 127))
     hi = xs.astype(np.float16); lo = (xs - hi.astype(np.float32)).astype(np.float16)
     lo_off = int(HF.query('dsrl_planes_lo_offset', P * C))
@@ -851,7 +853,36 @@ def test_head_512x1024_golden(golden):
     assert abs(pix[0] - mean[0]) < 1e-3 and abs(pix[1] - mean[1]) < 1e-3
 
 
-@pytest.mark.parametrize('mode', ['f16x3', 'bf16x6', 'bf16x3'])          # f16x3: the default arithmetic, what bench.py's config5 object times
+def test_f16x1_head_512x1024_against_reference(golden):
+    """The reduced-precision arithmetic of BASELINE config 5 ('fp16 MFMA convs': one fp16 MFMA per product, fp32 accumulation - 'f16x1', what apex
+    O1 / O2 select in the reference, train_or_resume.py:68-72) on that configuration's size against the imported reference's fp32 vectors: not an
+    fp32-equivalent mode, so the stated tolerance is 3e-3 of the range on logits / SISR and on the losses (measured 5e-4 / 4e-4 / 1e-4), 6e-3 on the
+    one-channel transformer maps (a 19 -> 1 projection of the logits: measured 2.9e-3 / 1.1e-3); every
+    conv is 3e-4 of its range off, test_conv_precision_modes), argmax disagreement below 0.1 % of the pixels, mIoU within 2e-3.  No loss scaling is
+    involved: every operand tensor carries its own power-of-two scale (the heavy-tailed 1e-7 gradients of test_f16x3_operand_ranges go through the
+    same scaling)."""
+    g = golden('head_512x1024')
+    HF.set_conv_precision('f16x1')
+    try:
+        head, _ = make_head(gen.FULL, 3, 707, False)
+        x16, x4, target, org = gen.make_head_inputs(808, 1, 32, 64, gen.FULL)
+        with torch.no_grad():
+            outs = head(dev(x16), dev(x4))
+            L = hip_losses(outs, dev(target), dev(org), 3)
+        sssr = host(outs[0])
+    finally:
+        HF.set_conv_precision(None)
+    T = 3e-3
+    e = [check(gen.strided_sample(sssr, 1 << 17), g['SSSR_sample'], T, 'logits'), check(gen.strided_sample(host(outs[1]), 1 << 15), g['SISR_sample'], T, 'SISR'),
+         check(host(outs[2]), g['SSSR_ft'], 2 * T), check(host(outs[3]), g['SISR_ft'], 2 * T), check(np.array([float(v) for v in L]), g['losses'], T, 'losses')]
+    am = sssr.argmax(axis=1).astype(np.uint8)
+    flips = float((am != g['SSSR_argmax']).mean())
+    pix, mean = O.miou_batch(am, target), O.miou_batch(g['SSSR_argmax'], target)
+    print('f16x1 at 512x1024 vs the fp32 reference:', ['%.1e' % v for v in e], 'argmax flips %.2e' % flips, 'mIoU', pix, mean)
+    assert flips < 1e-3 and abs(pix[0] - mean[0]) < 2e-3 and abs(pix[1] - mean[1]) < 2e-3
+
+
+@pytest.mark.parametrize('mode', ['f16x3', 'bf16x6', 'bf16x3', 'f16x1'])          # f16x3: the default arithmetic; f16x1: config 5's reduced-precision one (both timed by bench.py's config5 object)
 def test_full_size_train_step_properties_512x1024(mode):
     """Config-5 size end to end (whole model, 512x1024 -> 1024x2048, B=2, train mode with dropout), where no oracle finishes in seconds:
     size-independent properties instead.  (1) Determinism: the same step from the same state and dropout key gives bit-identical
@@ -883,13 +914,18 @@ def test_full_size_train_step_properties_512x1024(mode):
     assert all(np.isfinite(v) for v in runs[0][0]), runs[0][0]
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]), 'the step is not deterministic'
     ref = runs[2]
+    # f16x1: 11 significand bits per operand (apex O1 / O2's arithmetic), 3e-4 of the range per conv, ~100 convs deep: CE / MSE move by 1e-4, the
+    # feature-affinity loss (differences of normalised similarity matrices of the two heads) by 2 %
+    ltol = 5e-2 if mode == 'f16x1' else 2e-3
     for a, b in zip(runs[0][0], ref[0]):
-        assert abs(a - b) <= 2e-3 * max(abs(b), 1e-3), (runs[0][0], ref[0])
+        assert abs(a - b) <= ltol * max(abs(b), 1e-3), (runs[0][0], ref[0])
     rel = float((runs[0][1] - ref[1]).norm() / ref[1].norm())
     cos = float(torch.dot(runs[0][1].double(), ref[1].double()) / (runs[0][1].double().norm() * ref[1].double().norm()))
     # a random-init 101-layer net with batch-2 BatchNorm amplifies 1e-5 perturbations (ReLU flips): the whole-arena gradient is held to
     # its direction, the per-op accuracy of the mode is pinned by test_conv_precision_modes (3e-5 per conv)
-    assert cos > 0.99, (cos, rel)
+    # f16x1 (11 bits): the same amplification leaves a cosine of ~0.6 at this batch-2 random initialisation (measured 0.59) - the price of the
+    # reference's O1 / O2 arithmetic on such a net, not of this implementation: per conv it is 3e-4 of the range (test_conv_precision_modes)
+    assert cos > (0.4 if mode == 'f16x1' else 0.99), (cos, rel)
     print(mode, 'losses', runs[0][0], 'gradient arena vs bf16x6: L2 difference %.2e, cosine %.5f' % (rel, cos))
 
 
@@ -1242,7 +1278,7 @@ def test_bn_backward_statistics_from_dgrad_epilogue(shared):
     old, orig_call, old_shared = HF.bn_bwd_stats_enabled, HF.call, HF.bn_bwd_stats_shared
 
     def counting(name, *a):
-        key = 'dsrl_conv2d_dgrad_bnstats' if (name == 'dsrl_conv2d_dgrad_amax' and a[28] is not None) else name       # a[28]: the bstats argument
+        key = 'dsrl_conv2d_dgrad_bnstats' if (name == 'dsrl_conv2d_dgrad_planes' and a[30] is not None) else name       # a[30]: the bstats argument
         counts[-1][key] = counts[-1].get(key, 0) + 1
         return orig_call(name, *a)
 
