@@ -23,7 +23,8 @@ product: what apex O1 / O2 compute) - is timed over the same step counts and lis
   roofline_hbm   - the memory-bound kernels of the step (CE, ConvTranspose, MSE, large BatchNorm, SGD): algorithmic bytes / time
                    against the 8 TB/s HBM peak;
   cpu_baseline   - the same training step on this box's host cores from stock torch.nn CPU modules (what the reference's
-                   `--device cpu` path executes, oracle/torch_cpu_model.py), plus the numpy oracle as `cpu_baseline_numpy_port`.
+                   `--device cpu` path executes, oracle/torch_cpu_model.py), plus the numpy oracle as `cpu_baseline_numpy_port` and
+                   `cpu_baseline_c1`: BASELINE.json configs[0] (stage 1, batch 2, 128x256) through the same stock-torch CPU graph.
 """
 import argparse
 import ctypes
@@ -503,6 +504,10 @@ def main():
             line['config5'] = config5
         if weights0 is not None:
             line['cpu_baseline'] = cpu_baseline_torch(weights0, args.stage)
+            # BASELINE.json configs[0]: the reference's own CPU-runnable case - stage 1 (SSSR only), batch 2, 128x256 input, --device cpu
+            c1 = cpu_baseline_torch(weights0, 1, batch=2, height=128, width=256)
+            c1['config'] = 'BASELINE.json configs[0]: stage-1 SSSR, batch 2, 128x256 input, --device cpu (train_stage1_cmdline.json)'
+            line['cpu_baseline_c1'] = c1
             if args.stage == 3:
                 line['cpu_baseline_numpy_port'] = cpu_baseline_numpy(weights0)
         print(json.dumps(line), flush=True)

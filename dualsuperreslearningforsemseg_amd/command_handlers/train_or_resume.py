@@ -98,9 +98,13 @@ class TrainStep:
             # kernels keep the 128-block budget ddp.FlatParams selected: an all-reduce of the first gradient chunks runs beside the second
             # half of backward (split capture), and RCCL blocks hold CUs while they wait for peers - a 256-block barrier launch needs every CU
             flat.defer_collectives = True
-        # Two-phase backward with more than one rank (DSRL_GRAPH_SPLIT=0: off): backward stops at the layer3 / layer4 boundary, the gradient
-        # chunks complete by then (head, ASPP, layer4) are all-reduced while layers 3..1 run, the rest behind them.  One rank: one phase.
-        self.split = flat.world > 1 and flat.defer_collectives and os.environ.get('DSRL_GRAPH_SPLIT', '1') != '0'
+        # Two-phase backward with more than one rank (DSRL_GRAPH_SPLIT=1; off by default since round 4): backward stops at the layer3 / layer4
+        # boundary, the gradient chunks complete by then (head, ASPP, layer4) are all-reduced while layers 3..1 run, the rest behind them.  That
+        # schedule puts RCCL kernels beside the device-wide-barrier BatchNorm kernels of the second graph; it is bit-identical to the one-graph
+        # schedule and was rehearsed on one GPU, but it has never run with two GPUs on RCCL, so it stays opt-in until a multi-GPU run has recorded
+        # `bn_fused_barrier_timeouts` and the exposed all-reduce time with it.  Default: ONE graph, one all-reduce of the whole
+        # 239.5 MB arena behind it (round 2's schedule).
+        self.split = flat.world > 1 and flat.defer_collectives and os.environ.get('DSRL_GRAPH_SPLIT', '0') != '0'
         self.time_collectives = False           # bench.py: bracket the exposed part of the collectives with events
         self.comm_events = []                   # (broadcast start, end, replay-B end, collectives end) per step
 
@@ -204,7 +208,8 @@ class TrainStep:
         bns = [m for m in self.model.modules() if isinstance(m, t.nn.modules.batchnorm._BatchNorm)]
         before = [getattr(m, '_dsrl_batches', 0) for m in bns]
         step_before = HF._rng_state['step']
-        c.graph = t.cuda.CUDAGraph()
+        dump_dir = os.environ.get('DSRL_GRAPH_DEBUG_DUMP')          # tools/graph_memset_edges.py: keep the captured hipGraph_t and write it as a DOT file
+        c.graph = t.cuda.CUDAGraph(keep_graph=True) if dump_dir else t.cuda.CUDAGraph()
         # A forked capture (weight gradients on a side stream) replays slower than a linear one on this runtime: the graph executor
         # pays more for its cross-queue dependencies than the overlap wins (measured 24.2 vs 23.8 ms per step), so the capture is
         # linear unless DSRL_GRAPH_OVERLAP=1
@@ -230,7 +235,7 @@ class TrainStep:
                 with t.cuda.graph(c.graph, capture_error_mode=mode):
                     c.outs, c.vals, cuts = self._phase_a(c.img, c.org, c.tgt, True, True, True)
                 c.ready = self.flat.ready_chunks()
-                c.graph_b = t.cuda.CUDAGraph()
+                c.graph_b = t.cuda.CUDAGraph(keep_graph=True) if dump_dir else t.cuda.CUDAGraph()
                 with t.cuda.graph(c.graph_b, pool=c.graph.pool(), capture_error_mode=mode):
                     self._phase_b(cuts)
                 del cuts
@@ -244,6 +249,16 @@ class TrainStep:
                 HF.set_bn_fused_max_blocks(fused_was)
             HF.graph_keepalive = None
             HF.capture_host = None
+        if dump_dir:
+            import ctypes
+            os.makedirs(dump_dir, exist_ok=True)
+            hip = ctypes.CDLL('libamdhip64.so')
+            hip.hipGraphDebugDotPrint.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint]
+            for g_, name in ((c.graph, 'graph_a.dot'), (c.graph_b, 'graph_b.dot')):
+                if g_ is not None:
+                    rc = hip.hipGraphDebugDotPrint(ctypes.c_void_p(g_.raw_cuda_graph()), os.path.join(dump_dir, name).encode(), 1)      # 1 = verbose
+                    print(f'[dsrl] hipGraphDebugDotPrint({name}) -> {rc}', flush=True)
+                    g_.instantiate()
         # nothing ran during the capture: take back the host-side bookkeeping of that phantom iteration
         HF._rng_state['step'] = step_before
         c.bns = [m for m, n in zip(bns, before) if getattr(m, '_dsrl_batches', 0) != n]

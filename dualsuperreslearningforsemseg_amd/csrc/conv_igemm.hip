@@ -1667,6 +1667,10 @@ int launch_zero_fill(void* p, size_t bytes, hipStream_t st) {
         set_error("zero_fill: pointer not 16-byte aligned");
         return DSRL_E_BADARG;
     }
+    if (env_int("DSRL_ZERO_FILL_MEMSET", 0)) {      // diagnosis only (tools/graph_memset_edges.py): the memset node this function replaced in round 3
+        if (hipMemsetAsync(p, 0, bytes, st) != hipSuccess) { set_error("hipMemsetAsync failed"); return DSRL_E_LAUNCH; }
+        return DSRL_OK;
+    }
     const long long n16 = (long long)(bytes / 16);
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(ceil_div(n16, 256 * 8), 2048));
     hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(256), 0, st, (uint4*)p, n16, (unsigned char*)p + n16 * 16, (int)(bytes % 16));

@@ -271,53 +271,69 @@ __global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const unsigned char* 
 }
 
 // ---------------------------------------------------------------------------------------------- ConvTranspose2d k2 s2
-// One block = 256 consecutive output pixels of one output row; the input row segment, the two filter
-// slices of that row parity and the output tile go through LDS so that all global traffic is contiguous.
+// One block = 128 consecutive input pixels of one input row = 256 output pixels of BOTH output rows 2h, 2h+1 (round 4: the input segment is
+// read once for the two rows, every global access is a 16-byte one).  The input segment, the four filter slices and the output tile of one row
+// go through LDS so that all global traffic is contiguous; the tile is written back as float4 (the row segment starts on a 16-byte boundary when
+// W % 4 == 0: 256 * CO floats per row segment).
 template <int CI, int CO>
 __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ y, int N, int H, int W) {
     constexpr int COP = (CO + 3) & ~3;
-    __shared__ __attribute__((aligned(16))) float wsh[2][CI][COP];
-    __shared__ float xs[128 * CI];
-    __shared__ float ys[256 * CO];
+    __shared__ __attribute__((aligned(16))) float wsh[2][2][CI][COP];      // [i][j][ci][co]
+    __shared__ __attribute__((aligned(16))) float xs[128 * CI];
+    __shared__ __attribute__((aligned(16))) float ys[256 * CO];
     const int Wo = 2 * W;
-    const int row = blockIdx.y;                 // n*Ho + ho
-    const int ho = row % (2 * H), n = row / (2 * H);
-    const int i = ho & 1, h = ho >> 1;
+    const int row = blockIdx.y;                 // n*H + h
     const int wo0 = blockIdx.x * 256;
     const int npix = min(256, Wo - wo0), nin = (npix + 1) / 2;
-    for (int t = threadIdx.x; t < 2 * CI * COP; t += 256) {
-        const int co = t % COP, ci = (t / COP) % CI, j = t / (COP * CI);
-        wsh[j][ci][co] = co < CO ? w[((ci * CO + co) * 2 + i) * 2 + j] : 0.f;
+    for (int t = threadIdx.x; t < 4 * CI * COP; t += 256) {
+        const int co = t % COP, ci = (t / COP) % CI, ij = t / (COP * CI);
+        wsh[ij >> 1][ij & 1][ci][co] = co < CO ? w[(ci * CO + co) * 4 + ij] : 0.f;
     }
-    const float* xrow = x + ((long long)(n * H + h) * W + wo0 / 2) * CI;
-    for (int t = threadIdx.x; t < nin * CI; t += 256) xs[t] = xrow[t];
+    const float* xrow = x + ((long long)row * W + wo0 / 2) * CI;
+    const bool vec = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    if (vec && ((nin * CI) & 3) == 0) {
+        for (int t = threadIdx.x; t < (nin * CI) >> 2; t += 256) reinterpret_cast<float4*>(xs)[t] = reinterpret_cast<const float4*>(xrow)[t];
+    } else {
+        for (int t = threadIdx.x; t < nin * CI; t += 256) xs[t] = xrow[t];
+    }
     __syncthreads();
+    const int j = threadIdx.x & 1;
+    float xin[CI];
     if ((int)threadIdx.x < npix) {
-        const int j = threadIdx.x & 1;
-        float xin[CI];
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci) xin[ci] = xs[(threadIdx.x >> 1) * CI + ci];
-        float acc[COP];
-#pragma unroll
-        for (int co = 0; co < COP; ++co) acc[co] = (bias != nullptr && co < CO) ? bias[co] : 0.f;
-#pragma unroll
-        for (int ci = 0; ci < CI; ++ci) {
-#pragma unroll
-            for (int q = 0; q < COP / 4; ++q) {
-                const float4 wv = *reinterpret_cast<const float4*>(&wsh[j][ci][q * 4]);
-                acc[q * 4 + 0] = fmaf(xin[ci], wv.x, acc[q * 4 + 0]);
-                acc[q * 4 + 1] = fmaf(xin[ci], wv.y, acc[q * 4 + 1]);
-                acc[q * 4 + 2] = fmaf(xin[ci], wv.z, acc[q * 4 + 2]);
-                acc[q * 4 + 3] = fmaf(xin[ci], wv.w, acc[q * 4 + 3]);
-            }
-        }
-#pragma unroll
-        for (int co = 0; co < CO; ++co) ys[threadIdx.x * CO + co] = acc[co];
     }
-    __syncthreads();
-    float* yrow = y + ((long long)row * Wo + wo0) * CO;
-    for (int t = threadIdx.x; t < npix * CO; t += 256) yrow[t] = ys[t];
+    const int n = row / H, h = row - n * H;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if ((int)threadIdx.x < npix) {
+            float acc[COP];
+#pragma unroll
+            for (int co = 0; co < COP; ++co) acc[co] = (bias != nullptr && co < CO) ? bias[co] : 0.f;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) {
+#pragma unroll
+                for (int q = 0; q < COP / 4; ++q) {
+                    const float4 wv = *reinterpret_cast<const float4*>(&wsh[i][j][ci][q * 4]);
+                    acc[q * 4 + 0] = fmaf(xin[ci], wv.x, acc[q * 4 + 0]);
+                    acc[q * 4 + 1] = fmaf(xin[ci], wv.y, acc[q * 4 + 1]);
+                    acc[q * 4 + 2] = fmaf(xin[ci], wv.z, acc[q * 4 + 2]);
+                    acc[q * 4 + 3] = fmaf(xin[ci], wv.w, acc[q * 4 + 3]);
+                }
+            }
+#pragma unroll
+            for (int co = 0; co < CO; ++co) ys[threadIdx.x * CO + co] = acc[co];
+        }
+        __syncthreads();
+        float* yrow = y + ((long long)((n * 2 * H + 2 * h + i)) * Wo + wo0) * CO;
+        if (vec && ((npix * CO) & 3) == 0) {
+            for (int t = threadIdx.x; t < (npix * CO) >> 2; t += 256) reinterpret_cast<float4*>(yrow)[t] = reinterpret_cast<const float4*>(ys)[t];
+        } else {
+            for (int t = threadIdx.x; t < npix * CO; t += 256) yrow[t] = ys[t];
+        }
+        __syncthreads();
+    }
 }
 
 // dx[n,h,w,ci] = sum_{i,j,co} dy[n,2h+i,2w+j,co] * w[ci,co,i,j]: one block = 128 input pixels of one row.
@@ -821,7 +837,7 @@ extern "C" int dsrl_maxpool3x3s2_bwd(const uint8_t* argmax, const float* dy, flo
 
 extern "C" int dsrl_convt2x2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, dsrl_stream_t stream) {
     DSRL_PROLOGUE(x && w && y && N > 0 && H > 0 && W > 0, "convt2x2_fwd")
-    dim3 grid((unsigned)ceil_div(2 * W, 256), (unsigned)(N * 2 * H));
+    dim3 grid((unsigned)ceil_div(2 * W, 256), (unsigned)(N * H));          // a block writes both output rows of its input row
     DSRL_CONVT_DISPATCH(19, 19, hipLaunchKernelGGL((convt2x2_fwd_kernel<CI, CO>), grid, dim3(256), 0, st, x, w, bias, y, N, H, W); return launch_status("convt2x2_fwd_kernel");)
     DSRL_CONVT_DISPATCH(8, 8, hipLaunchKernelGGL((convt2x2_fwd_kernel<CI, CO>), grid, dim3(256), 0, st, x, w, bias, y, N, H, W); return launch_status("convt2x2_fwd_kernel");)
     set_error("convt2x2_fwd: channel counts %d->%d not instantiated (19->19, 8->8)", Cin, Cout);

@@ -149,7 +149,8 @@ def time_train_step(state_dict, batch=2, height=256, width=512, stage=3, threads
     if threads:
         torch.set_num_threads(int(threads))
     model = TorchCpuDSRL(stage).train()
-    missing, unexpected = model.load_state_dict({k: v.detach().float().cpu() for k, v in state_dict.items()}, strict=False)
+    own = set(model.state_dict().keys())           # a lower stage owns a subset of a stage-3 model's tensors (DSRL.py:172-184)
+    missing, unexpected = model.load_state_dict({k: v.detach().float().cpu() for k, v in state_dict.items() if k in own}, strict=False)
     assert not missing and not unexpected, (missing, unexpected)
     opt = torch.optim.SGD(model.parameters(), lr=0.006, momentum=0.9, weight_decay=5e-4)
     g = torch.Generator().manual_seed(1234)
