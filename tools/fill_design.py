@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Fills the measured figures of DESIGN.md section 6 from profiles/round3_bench_line.json, round3_summary.md and round3_pmc_traffic.json, so that the text
+"""Fills the measured figures of DESIGN.md section 6 from profiles/round<N>_bench_line.json, round<N>_summary.md and round<N>_pmc_traffic.json (N = argv[1], default 4), so that the text
 and the committed profiles cannot drift apart.  Fields are <!--NAME-->value<!--/NAME--> (a first run converts @@NAME@@ placeholders)."""
-import json, os, re
+import json, os, re, sys
+RN = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-d = json.loads(open(f'{R}/profiles/round3_bench_line.json').read().strip().splitlines()[-1])
-pm = json.load(open(f'{R}/profiles/round3_pmc_traffic.json'))
-summ = open(f'{R}/profiles/round3_summary.md').read()
+d = json.loads(open(f'{R}/profiles/round{RN}_bench_line.json').read().strip().splitlines()[-1])
+pm = json.load(open(f'{R}/profiles/round{RN}_pmc_traffic.json'))
+summ = open(f'{R}/profiles/round{RN}_summary.md').read()
 rf = d['roofline']; ds = rf['decoder_stack']
 F = {}
 F['VALUE'] = f"{d['value']:.1f}"

@@ -1,21 +1,24 @@
 #!/usr/bin/env python3
-"""profiles/round3_summary.md and the committed copies of a tools/profile_round.sh run (run HERE, in the build container, after gpurun merged the files back:
+"""profiles/round<N>_summary.md and the committed copies of a tools/profile_round.sh run (run HERE, in the build container, after gpurun merged the files back:
 the traffic JSON is stamped with the commit and the conv kernel source hash it was taken at, which bench.py compares with the tree it runs from).
-usage: make_summary_r3.py <gpurun_out tag>   (expects gpurun_out/<tag>_stats/p_kernel_stats.csv, <tag>_pmc_traffic.json, <tag>_bench.json)"""
+usage: make_summary_round.py <round number> <gpurun_out tag>   (expects gpurun_out/<tag>_stats/p_kernel_stats.csv, <tag>_pmc_traffic.json, <tag>_bench.json)"""
 import csv, hashlib, json, os, re, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1]
+RN = int(sys.argv[1])
+tag = sys.argv[2]
+P = f'round{RN}'
 G = os.path.join(R, 'gpurun_out')
 STEPS = 14                      # profile_round.sh: --steps 10 --warmup 4 (2 eager + capture, then replays; every step's kernels are traced)
-shutil.copy(f'{G}/{tag}_stats/p_kernel_stats.csv', f'{R}/profiles/round3_bench_kernel_stats.csv')
+shutil.copy(f'{G}/{tag}_stats/p_kernel_stats.csv', f'{R}/profiles/{P}_bench_kernel_stats.csv')
 pm = json.load(open(f'{G}/{tag}_pmc_traffic.json'))
 pm['_stamp'] = {'commit': subprocess.run(['git', '-C', R, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip(),
-                'conv_igemm_sha16': hashlib.sha256(open(f'{R}/dualsuperreslearningforsemseg_amd/csrc/conv_igemm.hip', 'rb').read()).hexdigest()[:16]}
-json.dump(pm, open(f'{R}/profiles/round3_pmc_traffic.json', 'w'), indent=1)
+                'conv_igemm_sha16': hashlib.sha256(open(f'{R}/dualsuperreslearningforsemseg_amd/csrc/conv_igemm.hip', 'rb').read()).hexdigest()[:16],
+                'conv_planes_sha16': hashlib.sha256(open(f'{R}/dualsuperreslearningforsemseg_amd/csrc/conv_planes.hip', 'rb').read()).hexdigest()[:16]}
+json.dump(pm, open(f'{R}/profiles/{P}_pmc_traffic.json', 'w'), indent=1)
 line = open(f'{G}/{tag}_bench.json').read().strip().splitlines()[-1]
-open(f'{R}/profiles/round3_bench_line.json', 'w').write(line + '\n')
+open(f'{R}/profiles/{P}_bench_line.json', 'w').write(line + '\n')
 d = json.loads(line)
-rows = list(csv.DictReader(open(f'{R}/profiles/round3_bench_kernel_stats.csv')))
+rows = list(csv.DictReader(open(f'{R}/profiles/{P}_bench_kernel_stats.csv')))
 
 
 def grp(pat, exclude=None):
@@ -28,6 +31,8 @@ tot = sum(float(r['TotalDurationNs']) for r in rows) / 1e6 / STEPS
 groups = [
     ('conv forward: conv_igemm_split_kernel<.., false, 2, .., 2> (f16x3, pre-split filters)', r'conv_igemm_split_kernel<.*?, false, \d', None),
     ('conv dgrad: conv_igemm_split_kernel<.., true, 2, .., 2> (f16x3, pre-split filters)', r'conv_igemm_split_kernel<.*?, true, \d', None),
+    ('conv forward / dgrad with fp16-plane operands staged by LDS-DMA: conv_planes_kernel (the 3x3 decoder convs)', r'conv_planes_kernel', None),
+    ('plane producers: split_planes_kernel (the decoder operands), filter_planes_batched_kernel', r'split_planes_kernel|filter_planes_batched', None),
     ('conv wgrad, grouped: conv_wgrad_group_kernel (all layers of the pass in 2 grids)', r'conv_wgrad_group_kernel', None),
     ('conv wgrad, stem (row-folded 7x7) + grouped slab reduce', r'conv_wgrad_split_kernel|wgrad_reduce', None),
     ('split-K reduces of forward / dgrad', r'splitk_reduce', None),
@@ -38,36 +43,37 @@ groups = [
     ('BatchNorm three-kernel path (large / odd-width tensors) + eval apply', r'bn_(partial|finalize|apply|bwd_partial|bwd_finalize|bwd_apply)', r'stats_apply'),
     ('fused loss pass: count_valid, ce_fused, mse_fused, fa_sim / fa_pairs / fa_bwd, finalizers, loss_mix', r'ce_fused|mse_fused|count_valid|fa_sim|fa_pairs|fa_bwd|fa_finalize|ce_finalize|mse_finalize|loss_mix', None),
     ('ConvTranspose 19->19 forward / dx / dw', r'convt2x2', None),
-    ('bilinear, pixel shuffle, pools, pointwise stride-8, dropout, colsum, concat copies', r'bilinear|pixel_shuffle|maxpool|gap_|pointwise|dropout_kernel|colsum|copyBufferRect|pad_image|nchw', None),
+    ('bilinear, pixel shuffle, pools, pointwise stride-8, dropout, colsum, concat copies', r'bilinear|pixel_shuffle|maxpool|gap_|pointwise|dropout_kernel|colsum|copyBufferRect|pad_image|nchw|copy2d', None),
     ('NOT per step: parameter upload / arena set-up copies of the process (__amd_rocclr_copyBuffer, ~1300 launches once), shown divided by the step count', r'__amd_rocclr_copyBuffer$', None),
-    ('SGD + filter pass (amax + pre-split: weight_transpose_batched / weight_split_batched) + dropout-key advance + NaN check', r'sgd|weight_transpose|weight_split|rng_advance|nan_check', None),
+    ('SGD + filter pass (amax + pre-split: weight_transpose_batched / weight_split_batched) + dropout-key advance + NaN check', r'sgd|weight_transpose|weight_split|weight_amax|rng_advance|nan_check', None),
     ('remaining ATen elementwise / fill kernels', r'at::native|fillBuffer|zero_fill_kernel', None),
 ]
 g = {name: grp(pat, ex) for name, pat, ex in groups}
+SETUP = [name for name, _, _ in groups if name.startswith('NOT per step')][0]
 known = sum(v[1] for v in g.values())
 r = d['roofline']
 ba = d.get('images_per_s_by_conv_arithmetic') or {}
-txt = f'''# Round 3 profile summary (1x MI355X, stage 3, B=8, 256x512 -> 512x1024, fp32 tensors, default 'f16x3' = fp32-equivalent conv arithmetic)
+txt = f'''# Round {RN} profile summary (1x MI355X, stage 3, B=8, 256x512 -> 512x1024, fp32 tensors, default 'f16x3' = fp32-equivalent conv arithmetic)
 
-Produced by `tools/profile_round.sh` + `tools/make_summary_r3.py` on the GPU box: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10
+Produced by `tools/profile_round.sh` + `tools/make_summary_round.py` on the GPU box: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10
 --warmup 4 --no-prof --no-cpu-baseline --no-config5` (the default step: a hipGraph replay that runs one kernel at a time, so the per-kernel durations are
 exclusive; {STEPS} steps in the trace: 2 eager, the rest replays), then two `--pmc` passes (FETCH_SIZE, WRITE_SIZE) aggregated by `tools/pmc_traffic.py`.
-Files: per-kernel table `round3_bench_kernel_stats.csv`; bench line `round3_bench_line.json`; HBM-side traffic per conv kernel family
-`round3_pmc_traffic.json`.
+Files: per-kernel table `{P}_bench_kernel_stats.csv`; bench line `{P}_bench_line.json`; HBM-side traffic per conv kernel family
+`{P}_pmc_traffic.json`.
 
 Default bench run of the same build: **{d['value']:.1f} images/s, {d['ms_per_step']:.2f} ms per step** (host enqueue {d['host_enqueue_ms_per_step']:.2f} ms per step: one
 hipGraphLaunch); the same step timed over the same {d['steps']} steps / {d['warmup']} warm-ups per arithmetic: {ba}.
 CPU baselines on the box's host cores: stock torch.nn CPU graph {d.get('cpu_baseline', {}).get('value')} images/s on {d.get('cpu_baseline', {}).get('cores')} threads; numpy oracle
 {d.get('cpu_baseline_numpy_port', {}).get('value')} images/s.
 
-Total kernel time per step: {tot:.2f} ms, of which {g[groups[12][0]][1]:.2f} ms is the one-time set-up row (per step without it: {tot - g[groups[12][0]][1]:.2f} ms)
+Total kernel time per step: {tot:.2f} ms, of which {g[SETUP][1]:.2f} ms is the one-time set-up row (per step without it: {tot - g[SETUP][1]:.2f} ms)
 
 | group | ms/step | launches/step | avg us |
 |---|---|---|---|
 ''' + '\n'.join(f'| {name} | {g[name][1]:.2f} | {g[name][0]:.0f} | {g[name][2]:.1f} |' for name, _, _ in groups) + f'''
 | not matched above | {tot - known:.2f} | | |
 
-bench.py HIP events (5 eager steps behind the timed region, every conv launch bracketed on its stream), `round3_bench_line.json`:
+bench.py HIP events (5 eager steps behind the timed region, every conv launch bracketed on its stream), `{P}_bench_line.json`:
 '''
 for k, v in r['all_mfma_kernels'].items():
     txt += f"* {k}: {v['ms_per_step']} ms/step, {v['tflops']} algorithmic TFLOP/s = {v['frac']:.3f} of {v['peak']} TF; algorithmic bytes/launch {v['algorithmic_bytes_per_launch'] / 1e6:.1f} MB\n"
@@ -85,5 +91,5 @@ if d.get('roofline_hbm'):
     txt += '\nMemory-bound kernels, each launched alone (algorithmic bytes / time vs 8 TB/s):\n'
     for row in d['roofline_hbm']:
         txt += f"* {row['kernel']}: {row['achieved']} GB/s = {row['frac']:.3f} ({row['avg_launch_ms'] * 1e3:.0f} us)\n"
-open(f'{R}/profiles/round3_summary.md', 'w').write(txt)
+open(f'{R}/profiles/{P}_summary.md', 'w').write(txt)
 print(txt)

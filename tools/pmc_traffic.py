@@ -10,10 +10,15 @@ import csv, glob, json, re, sys, collections
 
 def family(name):
     def arith(npl, f16):        # template arguments: planes, then (after the K-group count) the fp16 flag (0 / false: bf16 terms)
-        return 'f16x3' if f16 not in (None, '0', 'false') else ('bf16x3' if npl == '2' else 'bf16x6')
+        if f16 not in (None, '0', 'false'):
+            return 'f16x1' if npl == '1' else 'f16x3'
+        return 'bf16x3' if npl == '2' else 'bf16x6'
     m = re.search(r'conv_igemm_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)(?:, \d+)?(?:, (\w+))?(?:, \w+)?>', name)
     if m:
         return f"conv_igemm_split_kernel<{arith(m.group(6), m.group(7))}> ({'dgrad' if m.group(5) == 'true' else 'forward'})"
+    m = re.search(r'conv_planes_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false)', name)
+    if m:           # the same implicit GEMM with plane operands staged by LDS-DMA: the family of the arithmetic it runs (bench.py's roofline name)
+        return f"conv_igemm_split_kernel<{'f16x3' if m.group(6) == '2' else 'f16x1'}> ({'dgrad' if m.group(7) == 'true' else 'forward'})"
     m = re.search(r'conv_wgrad_split_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, \d+)?(?:, (\w+))?>', name)
     if m:
         return f"conv_wgrad_split_kernel<{arith(m.group(5), m.group(6))}>"
