@@ -188,11 +188,26 @@ def decoder_stack_roofline(torch, HF, B, H, W, reps=10):
             wslot, wsp, wtsp, wtr = HF.split_filter(wt)         # the per-step filter pass of ddp.FlatParams, for this one filter
             keep.append((wslot, wsp, wtsp, wtr))
             xa, dya, wa, wsp, wtsp = HF.amax_for(x, x, C).data_ptr(), HF.amax_for(dy, dy, Kp).data_ptr(), wslot.data_ptr(), wsp.data_ptr(), wtsp.data_ptr()
-        t_f = _time_ms(lambda: _lib.call('dsrl_conv2d_fwd_amax', x.data_ptr(), C, xa, wt.data_ptr(), wa, wsp, None, y.data_ptr(), K, *shp, wsf.data_ptr(), wsf.numel(), None, 0, st), reps, torch)
+        fwd_path = 'register-staged operands (conv_igemm_split_kernel)'
+        if mode == 'f16x3' and HF.planes_wanted(x, C, C, K, R * R):
+            # the production forward of this conv (functional._Conv2d, DSRL_PLANES_MODE=auto): both operands as fp16 planes staged by LDS-DMA.  The split pass
+            # of the activation is part of its cost; cat_conv.0 and the SISR conv read the SAME concat buffer in the step (one pass for both: charged to cat_conv.0)
+            wp_, wtp_ = HF.filter_planes(wt, wslot)
+            xa_t = HF.amax_for(x, x, C)
+            xp_ = HF.planes_of(x, C, xa_t)
+            keep.append((wp_, wtp_, xp_))
+            t_split = 0.0 if name.startswith('SISR') else _time_ms(lambda: HF.planes_of(x, C, xa_t), reps, torch)
+            t_f = t_split + _time_ms(lambda: _lib.call('dsrl_conv2d_fwd_planes', x.data_ptr(), C, xa, xp_.data_ptr(), wt.data_ptr(), wa, wsp, wp_.data_ptr(), None, y.data_ptr(), K,
+                                                       *shp, wsf.data_ptr(), wsf.numel(), None, 0, st), reps, torch)
+            fwd_path = ('fp16-plane operands staged by LDS-DMA (conv_planes_kernel)' +
+                        (f' + the split pass of its input ({t_split * 1e3:.0f} us)' if t_split else '; its input planes are the ones cat_conv.0 made (same concat buffer)'))
+        else:
+            t_f = _time_ms(lambda: _lib.call('dsrl_conv2d_fwd_amax', x.data_ptr(), C, xa, wt.data_ptr(), wa, wsp, None, y.data_ptr(), K, *shp, wsf.data_ptr(), wsf.numel(), None, 0, st), reps, torch)
         t_d = _time_ms(lambda: _lib.call('dsrl_conv2d_dgrad_amax', dy.data_ptr(), Kp, dya, wt.data_ptr(), None, wa, wtsp, dx.data_ptr(), C, *shp, wsd.data_ptr(), wsd.numel(),
                                          None, 0, None, 0, None, None, 0, None, 0, 0, st), reps, torch)
         t_w = _time_ms(lambda: _lib.call('dsrl_conv2d_wgrad_amax', x.data_ptr(), C, xa, dy.data_ptr(), Kp, dya, dw.data_ptr(), *shp, wsw.data_ptr(), wsw.numel(), st), reps, torch)
-        layers[name] = {'gflop': round(gf, 2), 'forward_tflops': round(gf / t_f, 1), 'dgrad_tflops': round(gf / t_d, 1), 'wgrad_per_layer_tflops': round(gf / t_w, 1)}
+        layers[name] = {'gflop': round(gf, 2), 'forward_tflops': round(gf / t_f, 1), 'dgrad_tflops': round(gf / t_d, 1), 'wgrad_per_layer_tflops': round(gf / t_w, 1),
+                        'forward_path': fwd_path}
         for k, t in (('forward', t_f), ('dgrad', t_d), ('wgrad_per_layer', t_w)):
             tot[k][0] += gf; tot[k][1] += t
         keep_probs.append((x, dy, dw, Kp, shp))
@@ -210,7 +225,7 @@ def decoder_stack_roofline(torch, HF, B, H, W, reps=10):
     else:
         tot['wgrad'] = list(tot['wgrad_per_layer'])
     out = {'conv_arithmetic': mode, 'layers': layers,
-           'note': 'each conv launched alone through the C ABI (dgrad includes its own filter transpose), events on the launch stream, '
+           'note': 'each conv launched alone through the C ABI, on the path the training step takes for it (dgrad includes its own filter transpose), events on the launch stream, '
                    f'{reps} launches each; achieved = in-bounds FLOP / time; peak = dense bf16 MFMA 2516.6 TF / (3 | 6 MFMAs per product) or 157.3 TF fp32'}
     all_f = all_t = 0.0
     for i, k in enumerate(('forward', 'dgrad', 'wgrad')):

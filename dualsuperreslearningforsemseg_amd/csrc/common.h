@@ -105,9 +105,12 @@ __device__ inline void amax_publish(unsigned m, unsigned* out) {
 }
 // the same measurement as a launch of its own (conv_igemm.hip)
 int launch_amax(const float* x, int ld, long long P, int C, unsigned* out, hipStream_t st);
-// Zero-fill as a KERNEL launch (conv_igemm.hip).  Not hipMemsetAsync: captured into a hipGraph that call becomes a memset node, and on
-// ROCm 7.0 / 7.2 such a node was observed to run out of order with the kernel nodes around it (the amax scratch of the stem's weight
-// gradient, zeroed AFTER the measuring kernels in ~40 % of the replays of a two-graph step: round 3) - a kernel node keeps its place.
+// Zero-fill as a KERNEL launch (conv_igemm.hip), not hipMemsetAsync.  Round 3: with the 2 KiB amax scratch of the stem's weight gradient zeroed by a
+// captured memset node, ~40 % of the replays of the two-graph step produced a NaN there, and replacing that one call by a kernel made it disappear.
+// Round 4 dumped the captured graphs of a build with the memsets restored (DSRL_ZERO_FILL_MEMSET=1, tools/graph_memset_edges.py,
+// profiles/round4_graph_memset_edges.txt): both graphs are pure chains and every memset node has its edge to the kernel that consumes the zeroed
+// words - the capture did NOT drop a dependency.  Why the replay misbehaved is therefore not established (a runtime fault in how memset nodes execute,
+// or a cause the substitution only perturbed); the kernel fill is kept because it leaves kernel nodes as the only node type of the step's graphs.
 int launch_zero_fill(void* p, size_t bytes, hipStream_t st);
 
 // Per-channel thread mapping for pixel-major [P][ld] tensors with C channels (channel group of <= 256):

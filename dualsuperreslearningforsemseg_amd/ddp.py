@@ -187,7 +187,7 @@ class FlatParams:
         # f16x3 arithmetic: every filter also in pre-split ("plane") form, forward layout and transposed (dsrl_conv2d_split_filters_batched);
         # the arenas are allocated on first use
         self._split_entries, self._split_table = entries, None
-        self.planes_valid, self._planes_table = False, None
+        self.planes_valid, self._plane_sets = False, []
 
     def _build_split_filters(self):
         floats_w = sum(_align(w.numel()) for w, *_ in self._split_entries)
@@ -217,28 +217,37 @@ class FlatParams:
         self._amax_segs = len(segs)
 
     def _build_plane_filters(self):
-        """Every filter whose channel counts are multiples of 8 as fp16 planes, forward [K][R][S][C] and transposed [C][R][S][K]: the filter operand
-        of conv_planes_kernel (dsrl_conv2d_filter_planes_batched), scaled by the same amax records as the split forms."""
-        # 'auto': only the filters whose convs asked for planes in an earlier step (functional._Conv2d marks them: the operands that are large enough
-        # for the split pass to pay); 'all': every eligible filter
-        ents = [(i, e) for i, e in enumerate(self._split_entries) if e[1] % 8 == 0 and e[4] % 8 == 0 and
+        """The filters whose convs take plane operands (channel counts multiples of 8), as fp16 planes, forward [K][R][S][C] and transposed
+        [C][R][S][K]: the filter operand of conv_planes_kernel (dsrl_conv2d_filter_planes_batched), scaled by the same amax records as the split forms.
+        'auto': only the filters whose convs asked for planes in an earlier step (functional._Conv2d marks them: operands large enough for the split pass
+        to pay); 'all': every eligible filter.  Sets are only ever ADDED: a captured graph keeps launching the table it was captured with and reading the
+        arenas of that table (another batch shape may want more filters later - they get a set of their own; nothing a graph references is replaced)."""
+        have = {id(w) for st in self._plane_sets for w in st['filters']}
+        ents = [(i, e) for i, e in enumerate(self._split_entries) if e[1] % 8 == 0 and e[4] % 8 == 0 and id(e[0]) not in have and
                 (HF.planes_mode == 'all' or getattr(e[0], '_dsrl_want_planes', False))]
-        self._planes_wanted = sum(1 for e in self._split_entries if getattr(e[0], '_dsrl_want_planes', False))
+        if not ents:
+            return
         lo = lambda n: int(HF.cquery('dsrl_planes_lo_offset', n))        # noqa: E731
         total = sum(2 * lo(w.numel()) for _, (w, *_r) in ents)
-        self.wplanes_flat = torch.empty(max(total, 256), device=self.device, dtype=torch.uint8)
-        self.wtplanes_flat = torch.empty(max(total, 256), device=self.device, dtype=torch.uint8)
+        wplanes = torch.empty(total, device=self.device, dtype=torch.uint8)
+        wtplanes = torch.empty(total, device=self.device, dtype=torch.uint8)
         rows, off, tiles = [], 0, 0
         for i, (w, K, Kp, RS, C, _off) in ents:
             nb = 2 * lo(w.numel())
-            wp, wtp = self.wplanes_flat[off:off + nb], self.wtplanes_flat[off:off + nb]
+            wp, wtp = wplanes[off:off + nb], wtplanes[off:off + nb]
             off += nb
             w._dsrl_wplanes, w._dsrl_wtplanes = wp, wtp
             ct = (C + 31) // 32
             rows.append([w.data_ptr(), wtp.data_ptr(), K, K, RS, C, tiles, ct, self.w_amax.data_ptr() + 4 * HF.AMAX_WORDS * i, wp.data_ptr()])
             tiles += RS * ct * ((K + 31) // 32)
-        self._planes_rows, self._planes_tiles = len(rows), tiles
-        self._planes_table = torch.tensor(rows if rows else [[0] * 10], dtype=torch.int64, device=self.device)
+        self._plane_sets.append({'table': torch.tensor(rows, dtype=torch.int64, device=self.device), 'rows': len(rows), 'tiles': tiles,
+                                 'arenas': (wplanes, wtplanes), 'filters': [e[0] for _, e in ents]})
+
+    def _planes_pending(self):
+        """Does a filter want planes that no set holds yet?  (host-side check, two attribute reads per filter)"""
+        have = {id(w) for st in self._plane_sets for w in st['filters']}
+        return any(e[1] % 8 == 0 and e[4] % 8 == 0 and id(e[0]) not in have and (HF.planes_mode == 'all' or getattr(e[0], '_dsrl_want_planes', False))
+                   for e in self._split_entries)
 
     def refresh_transposed_filters(self):
         if self._wt_table is not None and os.environ.get('DSRL_BATCHED_TRANSPOSE', '1') != '0':
@@ -255,11 +264,10 @@ class FlatParams:
                 HF.call('dsrl_conv2d_split_filters_batched', self._split_table.data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
             planes = presplit and HF.planes_mode != 'off' and HF.get_conv_precision() == 'f16x3'
             if planes:
-                if self._planes_table is None or (HF.planes_mode != 'all' and
-                                                  self._planes_wanted != sum(1 for e in self._split_entries if getattr(e[0], '_dsrl_want_planes', False))):
-                    self._build_plane_filters()         # first use, or more filters asked for planes since the table was built
-                if self._planes_rows:
-                    HF.call('dsrl_conv2d_filter_planes_batched', self._planes_table.data_ptr(), self._planes_rows, self._planes_tiles, HF._stream())
+                if HF.graph_keepalive is None and self._planes_pending():
+                    self._build_plane_filters()         # first use, or more filters asked for planes since the last set was built (never inside a capture)
+                for st in self._plane_sets:
+                    HF.call('dsrl_conv2d_filter_planes_batched', st['table'].data_ptr(), st['rows'], st['tiles'], HF._stream())
             self.wt_valid, self.wt_fp32_valid, self.split_valid, self.planes_valid = True, not presplit, presplit, planes
 
     def zero_grad(self):

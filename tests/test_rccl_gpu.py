@@ -153,10 +153,12 @@ def test_graph_replay_matches_eager_bitwise():
 
 
 def test_graph_amax_arena_outlives_evaluation_passes():
-    """The captured step bakes in the addresses of the amax arena (its zero fill, the records the kernels max into and read).  Validation runs
+    """What a captured step references must stay alive and in place.  (1) The captured step bakes in the addresses of the amax arena (its zero fill, the
+    records the kernels max into and read).  Validation runs
     eagerly between epochs and asks for thousands of records: they must come from another arena, and the captured one must stay alive and in
-    place (it used to be replaced after ~10 validation batches, and every later replay wrote into freed memory).  Graph run ==
-    eager run bit for bit across training steps, > 2048 records of evaluation forwards, and more training steps."""
+    place (it used to be replaced after ~10 validation batches, and every later replay wrote into freed memory).  (2) The filter-plane
+    table and arenas of the per-step filter pass: a second batch shape that wants planes for more filters adds a set, it does not rebuild the first.
+    Graph run == eager run bit for bit across training steps, > 2048 records of evaluation forwards, steps at the second shape, and more steps at the first."""
     from dualsuperreslearningforsemseg_amd import functional as HF
     import dualsuperreslearningforsemseg_amd as D
     from dualsuperreslearningforsemseg_amd import ddp
@@ -164,6 +166,8 @@ def test_graph_amax_arena_outlives_evaluation_passes():
     from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
     HF.set_conv_precision(None)
     res = {}
+    min_was, mode_was = HF.planes_min_elems, HF.planes_mode
+    HF.planes_min_elems, HF.planes_mode = 200000, 'auto'          # 64x128: the decoder 3x3 convs want planes; 128x256: layer1 and the dilated ASPP convs too
     for graph in (False, True):
         torch.manual_seed(999)
         model = D.DSRL(3, cs).to(DEV).to(memory_format=torch.channels_last).train()
@@ -191,12 +195,20 @@ def test_graph_amax_arena_outlives_evaluation_passes():
                     asked += (lo[1] - before) if lo[0] is loose_before else lo[1] + (HF._AMAX_SLOTS - before)
             model.train()
             assert HF._amax_arena[dev_][0] is arena and arena.data_ptr() == ptr and HF._amax_arena[dev_][1] < HF._AMAX_SLOTS
+            # a larger batch shape in between wants plane operands for MORE filters (threshold lowered for this test): their planes come as an additional
+            # set - the table and arenas the first graph was captured with stay where they are (ddp.FlatParams._build_plane_filters)
+            sets_before = [(st['table'].data_ptr(), st['arenas'][0].data_ptr()) for st in flat._plane_sets]
+            big = list(SyntheticCityscapes(2, (128, 256), torch.device(DEV), length=3, distinct=1))
+            hist += [step(img_, org_, tgt_, 0.006, 0.9, 5e-4, True)[0] for (img_, org_), (tgt_, _) in big]
+            assert [(st['table'].data_ptr(), st['arenas'][0].data_ptr()) for st in flat._plane_sets][:len(sets_before)] == sets_before
+            assert len(flat._plane_sets) > len(sets_before) >= 1
             hist += [step(img, org, tgt, 0.006, 0.9, 5e-4, True)[0] for (img, org), (tgt, _) in batches]
         finally:
             HF.overlap_wgrad = was
         torch.cuda.synchronize()
         res[graph] = (hist, flat.p_flat.clone())
         step.release()
+    HF.planes_min_elems, HF.planes_mode = min_was, mode_was
     assert all(np.isfinite(v) for h in res[True][0] for v in h)
     assert res[False][0] == res[True][0] and torch.equal(res[False][1], res[True][1])
 

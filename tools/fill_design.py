@@ -13,8 +13,15 @@ F['VALUE'] = f"{d['value']:.1f}"
 F['MS'] = f"{d['ms_per_step']:.2f}"
 m = d['images_per_s_by_conv_arithmetic']
 F['MODES'] = ', '.join(f"`{k}` {v}" for k, v in m.items() if k != 'f16x3') + ' images/s'
+F['F16X1'] = str(m.get('f16x1', 'n/a'))
 c5 = d['config5']
 F['C5'] = f"{c5['value']:.1f}"
+c5m = c5.get('images_per_s_by_conv_arithmetic', {})
+F['C5X1'] = str(c5m.get('f16x1', 'n/a'))
+F['F16X1LINE'] = (f"{m.get('f16x1', 'n/a')} against {d['value']:.1f} images/s at 256×512 ({100 * (m.get('f16x1', d['value']) / d['value'] - 1):+.0f} %), "
+                  f"{c5m.get('f16x1', 'n/a')} against {c5['value']:.1f} at config 5's size ({100 * (c5m.get('f16x1', c5['value']) / c5['value'] - 1):+.0f} %)")
+F['CPUC1'] = f"{d.get('cpu_baseline_c1', {}).get('value', float('nan')):.2f}"
+F['MFMABUSY'] = (f"{rf['mfma_busy']:.3f} (`{rf['kernel']}`)" if 'mfma_busy' in rf else 'not collected')
 F['CPU'] = f"{d['cpu_baseline']['value']:.2f}"
 F['CPUNP'] = f"{d['cpu_baseline_numpy_port']['value']:.2f}"
 rows = re.findall(r'^\| (.+?) \| ([\d.]+) \| (\d+) \| ([\d.]+) \|$', summ, re.M)
