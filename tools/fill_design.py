@@ -21,11 +21,13 @@ F['C5X1'] = str(c5m.get('f16x1', 'n/a'))
 F['F16X1LINE'] = (f"{m.get('f16x1', 'n/a')} against {d['value']:.1f} images/s at 256×512 ({100 * (m.get('f16x1', d['value']) / d['value'] - 1):+.0f} %), "
                   f"{c5m.get('f16x1', 'n/a')} against {c5['value']:.1f} at config 5's size ({100 * (c5m.get('f16x1', c5['value']) / c5['value'] - 1):+.0f} %)")
 F['CPUC1'] = f"{d.get('cpu_baseline_c1', {}).get('value', float('nan')):.2f}"
-F['MFMABUSY'] = (f"{rf['mfma_busy']:.3f} (`{rf['kernel']}`)" if 'mfma_busy' in rf else 'not collected')
+sqf = f'{R}/profiles/round{RN}_sq_counters_step.json'
+fams = json.load(open(sqf)).get('_families', {}) if os.path.isfile(sqf) else {}
+F['MFMABUSY'] = ('; '.join(f"`{k}` {v['mfma_busy']:.3f}" for k, v in fams.items()) + f" (dominant: `{rf['kernel']}`)") if fams else 'not collected'
 F['CPU'] = f"{d['cpu_baseline']['value']:.2f}"
 F['CPUNP'] = f"{d['cpu_baseline_numpy_port']['value']:.2f}"
 rows = re.findall(r'^\| (.+?) \| ([\d.]+) \| (\d+) \| ([\d.]+) \|$', summ, re.M)
-short = [('conv forward', 'conv forward'), ('conv dgrad', 'conv dgrad'), ('conv wgrad, grouped', 'grouped weight gradients'), ('conv wgrad, stem', 'stem weight gradient + slab reduce'),
+short = [('conv forward:', 'conv forward (register-staged)'), ('conv dgrad:', 'conv dgrad (register-staged)'), ('conv forward with fp16-plane', 'conv forward with plane operands (LDS-DMA)'), ('plane producers', 'plane producers'), ('conv wgrad, grouped', 'grouped weight gradients'), ('conv wgrad, stem', 'stem weight gradient + slab reduce'),
          ('split-K reduces', 'split-K reduces'), ('operand magnitudes', 'amax launches'), ('BatchNorm forward from', 'BatchNorm forward from conv statistics'),
          ('BatchNorm backward from', 'BatchNorm backward from dgrad sums'), ('BatchNorm single-kernel', 'BatchNorm barrier kernels'), ('BatchNorm three-kernel', 'BatchNorm large / odd tensors'),
          ('fused loss pass', 'loss pass'), ('ConvTranspose', 'ConvTranspose tail'), ('bilinear', 'bilinear / shuffle / pools / dropout / concat'), ('SGD + filter pass', 'SGD + filter pass'),

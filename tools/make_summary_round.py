@@ -31,8 +31,8 @@ tot = sum(float(r['TotalDurationNs']) for r in rows) / 1e6 / STEPS
 groups = [
     ('conv forward: conv_igemm_split_kernel<.., false, 2, .., 2> (f16x3, pre-split filters)', r'conv_igemm_split_kernel<.*?, false, \d', None),
     ('conv dgrad: conv_igemm_split_kernel<.., true, 2, .., 2> (f16x3, pre-split filters)', r'conv_igemm_split_kernel<.*?, true, \d', None),
-    ('conv forward / dgrad with fp16-plane operands staged by LDS-DMA: conv_planes_kernel (the 3x3 decoder convs)', r'conv_planes_kernel', None),
-    ('plane producers: split_planes_kernel (the decoder operands), filter_planes_batched_kernel', r'split_planes_kernel|filter_planes_batched', None),
+    ('conv forward with fp16-plane operands staged by LDS-DMA: conv_planes_kernel (the 3x3 convs over operands of >= 8 Mi elements: cat_conv.0 / cat_conv.4 / SISR, the three dilated ASPP convs)', r'conv_planes_kernel', None),
+    ('plane producers: split_planes_kernel (concat buffer, cat_conv.4 input, layer4 output), filter_planes_batched_kernel (six filters)', r'split_planes_kernel|filter_planes_batched', None),
     ('conv wgrad, grouped: conv_wgrad_group_kernel (all layers of the pass in 2 grids)', r'conv_wgrad_group_kernel', None),
     ('conv wgrad, stem (row-folded 7x7) + grouped slab reduce', r'conv_wgrad_split_kernel|wgrad_reduce', None),
     ('split-K reduces of forward / dgrad', r'splitk_reduce', None),
