@@ -52,7 +52,6 @@ PROTOTYPES = {
     'dsrl_conv2d_wgrad_group_workspace_bytes': (sz, [fp, i32]),
     'dsrl_conv2d_wgrad_group_plan': (i32, [fp, i32, fp, sz, fp, fp, sz]),
     'dsrl_conv2d_wgrad_group_launch': (i32, [fp, fp, stream_t]),
-    'dsrl_conv2d_wgrad_group_launch_persistent': (i32, [fp, fp, i32, stream_t]),
     'dsrl_amax': (i32, [fp, i32, i64, i32, fp, stream_t]),
     'dsrl_conv2d_fwd_amax': (i32, [fp, i32, fp, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, stream_t]),
     'dsrl_conv2d_dgrad_amax': (i32, [fp, i32, fp, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, fp, i32, fp, fp, i32, fp, i32, i32, stream_t]),

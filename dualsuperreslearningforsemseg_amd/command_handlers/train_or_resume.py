@@ -105,8 +105,6 @@ class TrainStep:
         # `bn_fused_barrier_timeouts` and the exposed all-reduce time with it.  Default: ONE graph, one all-reduce of the whole
         # 239.5 MB arena behind it (round 2's schedule).
         self.split = flat.world > 1 and flat.defer_collectives and os.environ.get('DSRL_GRAPH_SPLIT', '0') != '0'
-        # One rank: the same cut, used to run the first phase's weight gradients underneath the second phase (functional.shadow_blocks)
-        self.shadow = HF.shadow_blocks if (flat.world == 1 and HF.group_wgrad) else 0
         self.time_collectives = False           # bench.py: bracket the exposed part of the collectives with events
         self.comm_events = []                   # (broadcast start, end, replay-B end, collectives end) per step
 
@@ -154,9 +152,8 @@ class TrainStep:
                         total.backward()                                                   # :444
                     if split:
                         cuts = bb._dsrl_cut
-                        HF.flush_wgrad_queue(reopen=True, shadow=self.shadow)      # the weight gradients of head, ASPP and layer4 as one grouped launch set
-                        if not self.shadow:
-                            HF.join_side_streams()
+                        HF.flush_wgrad_queue(reopen=True)      # the weight gradients of head, ASPP and layer4 as one grouped launch set
+                        HF.join_side_streams()
         finally:
             if bb is not None:
                 bb._dsrl_cut = None
@@ -186,12 +183,11 @@ class TrainStep:
 
     def _body(self, input_image, input_org, target, hp, do_train, in_graph=False):
         """One whole iteration, eagerly (graph mode: the iterations before the capture, with the same order of events)."""
-        split = (self.split or self.shadow > 0) and do_train
+        split = self.split and do_train
         outs, vals, cuts = self._phase_a(input_image, input_org, target, do_train, in_graph, split)
         if do_train:
             if split:
-                if self.split:
-                    self.flat.reduce_chunks(self.flat.ready_chunks())      # runs beside the second phase
+                self.flat.reduce_chunks(self.flat.ready_chunks())      # runs beside the second phase
                 self._phase_b(cuts)
             self._finish(hp, in_graph)
         return outs, vals
@@ -245,10 +241,7 @@ class TrainStep:
                 del cuts
             else:
                 with t.cuda.graph(c.graph, capture_error_mode=mode):
-                    c.outs, c.vals, cuts = self._phase_a(c.img, c.org, c.tgt, True, True, self.shadow > 0)
-                    if cuts is not None:
-                        self._phase_b(cuts)       # shadow weight gradients: one graph, the first phase's grids on a forked branch
-                        del cuts
+                    c.outs, c.vals, _ = self._phase_a(c.img, c.org, c.tgt, True, True, False)
                     self._finish(hp, True)
         finally:
             HF.overlap_wgrad = overlap_was

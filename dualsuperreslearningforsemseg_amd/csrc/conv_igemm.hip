@@ -1458,33 +1458,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_group_kernel(const WgradArg
     wgrad_split_body<MR, NR, WGM, WGN, NPL, 1, F16>(a, local);
 }
 
-// The same grids as a background job: `gridDim.x` blocks (far fewer than the work items) stay resident and take items from eight counters, one
-// per XCD (a block on XCD x takes the items with id % 8 == x, the ids the hardware would have dealt to that XCD), until its counter runs out.
-// With about one block per CU the launch leaves room on every CU for the kernels of another graph branch: the weight gradients of one backward
-// phase then run underneath the latency-bound dgrad / BatchNorm chain of the next (DSRL_WGRAD_SHADOW).
-template <int MR, int NR, int WGM, int WGN, int NPL, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_group_persistent_kernel(const WgradArgs* __restrict__ table, const int* __restrict__ starts, int nprob,
-                                                                             int total_blocks, int* __restrict__ counters) {
-    __shared__ int s_item;
-    const int xcd = (int)(blockIdx.x & 7);
-    for (;;) {
-        if (threadIdx.x == 0) s_item = 8 * atomicAdd(&counters[xcd], 1) + xcd;
-        __syncthreads();
-        const int b = s_item;
-        __syncthreads();                            // every wave has its copy before thread 0 writes the next; the previous item's LDS tiles are dead
-        if (b >= total_blocks) return;
-        int lo = 0, hi = nprob - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (starts[mid] <= b) lo = mid; else hi = mid - 1;
-        }
-        lo = __builtin_amdgcn_readfirstlane(lo);
-        const WgradArgs& a = table[lo];
-        const int local = b - starts[lo];
-        if (local < a.nblocks) wgrad_split_body<MR, NR, WGM, WGN, NPL, 1, F16>(a, local);
-    }
-}
-
 struct TapList { int taps[64]; int n; };
 // dw[k][tap][c] = sum_z slab[z][k][tap][c] over the active taps; C % 4 == 0, one float4 per thread, slabs unrolled by 4
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int psplits, long long slab, float* __restrict__ dw,
@@ -2395,7 +2368,6 @@ struct GroupHeader {
     unsigned magic; int n, nlaunch, npl, f16;
     GroupLaunch launch[kGroupMaxLaunches];
     int rgrid;                      // blocks of the slab reduce (0: no problem is split)
-    int counters[kGroupMaxLaunches][8];     // zero; the DEVICE copy holds the work counters of the persistent launch (one set per grid, one per XCD)
     long long args_off, starts_off, rstarts_off, used_bytes;      // byte offsets inside the table
 };
 static size_t group_table_bytes(int n) {
@@ -2519,18 +2491,11 @@ extern "C" int dsrl_conv2d_wgrad_group_plan(const dsrl_wgrad_problem* problems, 
     return DSRL_OK;
 }
 
-static int group_launch_impl(const void* host_table, const void* dev_table, int max_blocks, hipStream_t st);
 extern "C" int dsrl_conv2d_wgrad_group_launch(const void* host_table, const void* dev_table, dsrl_stream_t stream) {
-    return group_launch_impl(host_table, dev_table, 0, (hipStream_t)stream);
-}
-extern "C" int dsrl_conv2d_wgrad_group_launch_persistent(const void* host_table, void* dev_table, int max_blocks, dsrl_stream_t stream) {
-    DSRL_REQUIRE(max_blocks >= 8 && max_blocks % 8 == 0, DSRL_E_BADARG, "conv2d_wgrad_group_launch_persistent: max_blocks (%d) must be a positive multiple of 8 (one work counter per XCD)", max_blocks);
-    return group_launch_impl(host_table, dev_table, max_blocks, (hipStream_t)stream);
-}
-static int group_launch_impl(const void* host_table, const void* dev_table, int max_blocks, hipStream_t st) {
     DSRL_REQUIRE(host_table && dev_table, DSRL_E_BADARG, "conv2d_wgrad_group_launch: null table");
     const GroupHeader* h = (const GroupHeader*)host_table;
     DSRL_REQUIRE(h->magic == kGroupMagic && h->n > 0 && h->nlaunch > 0 && h->nlaunch <= kGroupMaxLaunches, DSRL_E_BADARG, "conv2d_wgrad_group_launch: the host table was not written by dsrl_conv2d_wgrad_group_plan");
+    hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
     const WgradArgs* hargs = (const WgradArgs*)((const char*)host_table + h->args_off);
     const WgradArgs* dargs = (const WgradArgs*)((const char*)dev_table + h->args_off);
@@ -2550,18 +2515,6 @@ static int group_launch_impl(const void* host_table, const void* dev_table, int 
         const WgradArgs* t = dargs + L.first;
         const int* s = dstarts + L.first;
         ProfScope prof(3 * prof_arith(npl, h->f16 != 0) + 1, L.flops, L.bytes, st);
-        if (max_blocks > 0 && L.grid > max_blocks) {
-            int* ctr = (int*)((char*)const_cast<void*>(dev_table) + offsetof(GroupHeader, counters)) + 8 * l;
-#define DSRL_LAUNCH_WPERSIST(a_, b_, c_, d_)                                                                                       \
-            if (h->f16 && npl == 1) hipLaunchKernelGGL((conv_wgrad_group_persistent_kernel<a_, b_, c_, d_, 1, true>), dim3((unsigned)max_blocks), dim3(256), lds, st, t, s, L.count, L.grid, ctr); \
-            else if (h->f16) hipLaunchKernelGGL((conv_wgrad_group_persistent_kernel<a_, b_, c_, d_, 2, true>), dim3((unsigned)max_blocks), dim3(256), lds, st, t, s, L.count, L.grid, ctr); \
-            else if (npl == 2) hipLaunchKernelGGL((conv_wgrad_group_persistent_kernel<a_, b_, c_, d_, 2>), dim3((unsigned)max_blocks), dim3(256), lds, st, t, s, L.count, L.grid, ctr); \
-            else hipLaunchKernelGGL((conv_wgrad_group_persistent_kernel<a_, b_, c_, d_, 3>), dim3((unsigned)max_blocks), dim3(256), lds, st, t, s, L.count, L.grid, ctr);
-            DSRL_CFG_SWITCH((TileCfg)L.cfg, DSRL_LAUNCH_WPERSIST)
-#undef DSRL_LAUNCH_WPERSIST
-            if (int e = launch_status("conv_wgrad_group_persistent_kernel")) return e;
-            continue;
-        }
 #define DSRL_LAUNCH_WGROUP(a_, b_, c_, d_)                                                                                         \
         if (h->f16 && npl == 1) hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 1, true>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count); \
         else if (h->f16) hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 2, true>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count); \

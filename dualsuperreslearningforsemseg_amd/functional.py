@@ -218,14 +218,6 @@ def join_side_streams():
     for st in _side.values():
         if st.device == cur.device:
             cur.wait_stream(st)
-    _shadow_keep.clear()          # everything a shadow launch reads is ordered before what the current stream does from here on
-
-
-# Shadow weight gradients (DSRL_WGRAD_SHADOW=<blocks>, one rank): the grouped weight gradients of the FIRST backward phase (head, ASPP, layer4) are
-# launched on the side stream as persistent grids of <blocks> blocks (dsrl_conv2d_wgrad_group_launch_persistent) and run underneath the second
-# phase, whose dgrad / BatchNorm chain is bound by launch latency and operand delivery and leaves most MFMA / LDS time of a CU unused.
-shadow_blocks = int(os.environ.get('DSRL_WGRAD_SHADOW', '0') or 0)
-_shadow_keep = []               # operands, tables and slabs of shadow launches: alive (not handed back to the allocator) until the join
 
 
 # Deferred weight gradients: while a WgradQueue is open (ddp.FlatParams opens one per training step), a conv's backward only records
@@ -244,7 +236,7 @@ class WgradQueue:
     def add(self, x, ldx, dy, lddy, dw, shp, on_written=None, x_amax=None, dy_amax=None):
         self.items.append((x, ldx, dy, lddy, dw, shp, on_written, x_amax, dy_amax))
 
-    def flush(self, shadow=0):
+    def flush(self):
         items, self.items = self.items, []
         if not items:
             return
@@ -277,13 +269,7 @@ class WgradQueue:
         dev.copy_(host, non_blocking=True)
         if graph_keepalive is not None:
             graph_keepalive.append(host)          # a captured copy re-reads this pinned buffer on every replay
-        if shadow > 0:
-            cur, side = torch.cuda.current_stream(like.device), side_stream(like.device)
-            side.wait_stream(cur)                 # behind the table copy and every producer of x / dy (under capture: the fork)
-            _shadow_keep.append((items, probs, ws, dev, host))
-            call('dsrl_conv2d_wgrad_group_launch_persistent', host.data_ptr(), dev.data_ptr(), int(shadow), side.cuda_stream)
-        else:
-            call('dsrl_conv2d_wgrad_group_launch', host.data_ptr(), dev.data_ptr(), _stream())
+        call('dsrl_conv2d_wgrad_group_launch', host.data_ptr(), dev.data_ptr(), _stream())
         for it in items:
             if it[6] is not None:
                 it[6]()
@@ -298,13 +284,13 @@ def open_wgrad_queue():
     return wgrad_queue
 
 
-def flush_wgrad_queue(reopen=False, shadow=0):
+def flush_wgrad_queue(reopen=False):
     """Launches what the open queue holds and closes it: only a step that opened a queue (FlatParams.zero_grad) defers.  `reopen`: a new
     queue takes the weight gradients of the rest of the backward pass (two-phase backward: one grouped launch set per phase)."""
     global wgrad_queue
     q, wgrad_queue = wgrad_queue, None
     if q is not None:
-        q.flush(shadow)
+        q.flush()
         if reopen:
             wgrad_queue = WgradQueue()
 

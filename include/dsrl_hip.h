@@ -131,11 +131,6 @@ size_t dsrl_conv2d_wgrad_group_workspace_bytes(const dsrl_wgrad_problem* problem
 int dsrl_conv2d_wgrad_group_plan(const dsrl_wgrad_problem* problems, int n, void* host_table, size_t table_bytes, const void* dev_table,
                                  void* ws, size_t ws_bytes);
 int dsrl_conv2d_wgrad_group_launch(const void* host_table, const void* dev_table, dsrl_stream_t stream);
-/* Step 4 as a background job: every grid of more than max_blocks blocks is launched with max_blocks (a multiple of 8) resident blocks that take
- * the work items from counters inside dev_table (zero after step 3's copy; the launch consumes them, so the table is copied again before a
- * second launch - a captured copy node does that on every replay). With about one block per CU the grids leave room for the kernels of
- * another stream / graph branch on every CU. Same results as dsrl_conv2d_wgrad_group_launch, bit for bit (same blocks, same order inside one). */
-int dsrl_conv2d_wgrad_group_launch_persistent(const void* host_table, void* dev_table, int max_blocks, dsrl_stream_t stream);
 /* Operand magnitudes for the "f16x3" arithmetic (dsrl_conv_precision 4). That arithmetic carries every operand as two fp16 terms of
  * x * 2^e, with e chosen per TENSOR so that the tensor's largest magnitude lands in [2^14, 2^15); it therefore needs max |x| of both
  * operands of a launch, as an "amax record": DSRL_AMAX_WORDS uint32 device words (1 KiB, 64-byte aligned) of which every 16th holds the

@@ -152,42 +152,6 @@ def test_graph_replay_matches_eager_bitwise():
     # covered by the bitwise equality with the eager run, whose key advances on the host)
 
 
-def test_shadow_weight_gradients_bitwise():
-    """DSRL_WGRAD_SHADOW: the first backward phase's grouped weight gradients as persistent grids on a forked branch (eager: the side stream),
-    joined before the optimiser. Same blocks, same summation order: parameters and buffers after 6 steps equal the plain schedule bit for bit,
-    eagerly and replayed, with as few as 8 resident blocks (every grid then takes the persistent kernel)."""
-    from dualsuperreslearningforsemseg_amd import functional as HF
-    import dualsuperreslearningforsemseg_amd as D
-    from dualsuperreslearningforsemseg_amd import ddp
-    from dualsuperreslearningforsemseg_amd.command_handlers.train_or_resume import SyntheticCityscapes, TrainStep
-    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
-    res = {}
-    was_shadow = HF.shadow_blocks
-    try:
-        for shadow, graph in ((0, True), (8, False), (8, True), (256, True)):
-            HF.shadow_blocks = shadow
-            torch.manual_seed(54321)
-            model = D.DSRL(3, cs).to(DEV).to(memory_format=torch.channels_last).train()
-            flat = ddp.FlatParams(model)
-            HF.set_dropout_seed(777)
-            step = TrainStep(model, flat, 3, 0.1, 1.0, cs.IGNORE_CLASS_LABEL, graph=graph)
-            assert step.shadow == shadow
-            batches = list(SyntheticCityscapes(2, (64, 128), torch.device(DEV), length=6, distinct=2))
-            hist = [step(img, org, tgt, 0.006, 0.9, 5e-4, True)[0] for (img, org), (tgt, _) in batches]
-            torch.cuda.synchronize()
-            assert not HF._shadow_keep
-            if graph:
-                assert step.graph_replays == 6 - step.GRAPH_WARMUP
-            res[(shadow, graph)] = (hist, flat.p_flat.clone(), flat.b_flat.clone())
-            step.release()
-    finally:
-        HF.shadow_blocks = was_shadow
-    ref = res[(0, True)]
-    for key, got in res.items():
-        assert got[0] == ref[0], (key, got[0], ref[0])
-        assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), key
-
-
 def test_graph_amax_arena_outlives_evaluation_passes():
     """What a captured step references must stay alive and in place.  (1) The captured step bakes in the addresses of the amax arena (its zero fill, the
     records the kernels max into and read).  Validation runs
