@@ -124,6 +124,35 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+struct WgradArgs {
+    const float* x; const float* dy; float* dw;     // dw or slabs
+    int ldx, lddy;
+    int N, H, W, C, K, R, S, Ho, Wo, stride, pad, dil;
+    long long P;                // N*Ho*Wo
+    unsigned x_bytes, dy_bytes; // buffer extents (< 2^31)
+    int ctiles;                 // tiles along C
+    int psplits;
+    long long slab;             // floats per split slab (K*RS*C) when psplits > 1
+    int taps[64]; int ntaps;    // active filter taps (whole-tensor)
+    int xcd_remap;              // pixel-range-major block order per XCD (blocks of one pixel range share dy / x chunks)
+    int kctiles;                // ktiles * ctiles
+    unsigned mHW, sHW, mW, sW;  // magic multipliers / shifts: p / (Ho*Wo) and rem / Wo for p < 2^31 (fast_div)
+    int kg;                     // split kernel: pixel groups per block (1, 2 or 4)
+    // grouped launches (dsrl_conv2d_wgrad_group_*): blocks of this problem (the rest up to the next start are padding), where the
+    // slab reduce writes, and that reduce's block count
+    int nblocks;
+    float* dw_final;
+    int rblocks;
+    const unsigned* amax_dy; const unsigned* amax_x;        // f16x3: max |.| (bit patterns) of dy and of x
+};
+
+// conv_wgrad3.hip: 3x3 / stride-1 weight gradients with all nine taps in one block (f16x3 / f16x1; tile 128 out channels x 64 in channels).
+// WgradArgs as for conv_wgrad_split_kernel with ntaps = 9, kctiles = tiles of that size, nblocks = kctiles * psplits.
+bool wgrad3_eligible(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int npl, bool f16);
+void wgrad3_tile(int& bm, int& bn);
+int launch_wgrad3(const WgradArgs& a, int npl, hipStream_t st);
+int launch_wgrad3_group(const WgradArgs* table, const int* starts, int nprob, int grid, int npl, int dil, hipStream_t st);
+
 // conv_planes.hip: the same implicit GEMM with both operands as fp16 planes staged by LDS-DMA (a.x / a.w / a.a_lo / a.b_lo as described in ConvArgs);
 // cfg is conv_igemm.hip's TileCfg, the tile / K-group / split-K plan (and with it the summation order) is the caller's.
 bool planes_cfg_supported(int cfg, int kg);

@@ -992,27 +992,6 @@ __global__ __launch_bounds__(256) void weight_split_batched_kernel(const long lo
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
-struct WgradArgs {
-    const float* x; const float* dy; float* dw;     // dw or slabs
-    int ldx, lddy;
-    int N, H, W, C, K, R, S, Ho, Wo, stride, pad, dil;
-    long long P;                // N*Ho*Wo
-    unsigned x_bytes, dy_bytes; // buffer extents (< 2^31)
-    int ctiles;                 // tiles along C
-    int psplits;
-    long long slab;             // floats per split slab (K*RS*C) when psplits > 1
-    int taps[64]; int ntaps;    // active filter taps (whole-tensor)
-    int xcd_remap;              // pixel-range-major block order per XCD (blocks of one pixel range share dy / x chunks)
-    int kctiles;                // ktiles * ctiles
-    unsigned mHW, sHW, mW, sW;  // magic multipliers / shifts: p / (Ho*Wo) and rem / Wo for p < 2^31 (fast_div)
-    int kg;                     // split kernel: pixel groups per block (1, 2 or 4)
-    // grouped launches (dsrl_conv2d_wgrad_group_*): blocks of this problem (the rest up to the next start are padding), where the
-    // slab reduce writes, and that reduce's block count
-    int nblocks;
-    float* dw_final;
-    int rblocks;
-    const unsigned* amax_dy; const unsigned* amax_x;        // f16x3: max |.| (bit patterns) of dy and of x
-};
 
 template <int MR, int NR, int WGM, int WGN>
 __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradArgs a) {
@@ -2203,7 +2182,15 @@ static void launch_wgrad(const WgradArgs& a_in, TileCfg cfg, int bm, int bn, dim
 }
 
 namespace dsrl {
-struct WgPlan { int Ho, Wo; long long P; TileCfg cfg; int bm, bn, ktiles, ctiles, psplits; TapList tl; size_t ws; };
+struct WgPlan { int Ho, Wo; long long P; TileCfg cfg; int bm, bn, ktiles, ctiles, psplits; TapList tl; size_t ws; bool w3; };
+// pixel ranges of an all-taps 3x3 launch (conv_wgrad3.hip; one 4-wave block per CU): enough blocks for ~2 per CU, at least 8 chunks each
+static int w3_psplits(long long tiles, long long chunks) {
+    const int forced = env_int("DSRL_FORCE_PSPLITS", 0);
+    if (forced > 0) return (int)std::max<long long>(1, std::min<long long>(forced, chunks));
+    long long sp = ceil_div(env_int("DSRL_WGRAD3_TARGET_BLOCKS", 512), std::max<long long>(tiles, 1));
+    sp = std::min(sp, std::max<long long>(1, chunks / 8));
+    return (int)std::max<long long>(1, std::min<long long>(sp, 128));
+}
 static WgPlan plan_wgrad(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
     WgPlan p; p.Ho = out_size(H, R, stride, pad, dil); p.Wo = out_size(W, S, stride, pad, dil);
     p.P = (long long)N * p.Ho * p.Wo;
@@ -2215,8 +2202,16 @@ static WgPlan plan_wgrad(int N, int H, int W, int C, int K, int R, int S, int st
     for (int r = 0; r < R; ++r)
         for (int s = 0; s < S; ++s)
             if (valid_count(H, p.Ho, stride, pad, r * dil) > 0 && valid_count(W, p.Wo, stride, pad, s * dil) > 0) p.tl.taps[p.tl.n++] = r * S + s;
-    const long long tiles = (long long)p.ktiles * p.ctiles * std::max(1, p.tl.n);
     const long long chunks = ceil_div(p.P, 32);
+    p.w3 = p.tl.n == 9 && wgrad3_eligible(N, H, W, C, K, R, S, stride, pad, dil, conv_planes(PASS_WGRAD), conv_f16());
+    if (p.w3) {         // all nine taps in one block (conv_wgrad3.hip)
+        wgrad3_tile(p.bm, p.bn);
+        p.ktiles = (int)ceil_div(K, p.bm); p.ctiles = (int)ceil_div(C, p.bn);
+        p.psplits = w3_psplits((long long)p.ktiles * p.ctiles, chunks);
+        p.ws = p.psplits > 1 ? (size_t)p.psplits * K * R * S * C * sizeof(float) : 0;
+        return p;
+    }
+    const long long tiles = (long long)p.ktiles * p.ctiles * std::max(1, p.tl.n);
     p.psplits = pick_psplits(tiles, chunks);
     p.ws = p.psplits > 1 ? (size_t)p.psplits * K * R * S * C * sizeof(float) : 0;
     return p;
@@ -2258,6 +2253,24 @@ static int wgrad_impl(const float* x, int ldx, const float* dy, int lddy, float*
         OperandAmax am{dy_amax, x_amax};
         if (int e = resolve_amax(am, dy, lddy, p.P, pad4(K), x, ldx, (long long)N * H * W, C, ws, ws_bytes, p.ws, st, "conv2d_wgrad")) return e;
         a.amax_dy = am.a; a.amax_x = am.b;
+    }
+    if (p.w3) {
+        a.psplits = p.psplits; a.kg = 1;
+        a.dw = p.psplits > 1 ? (float*)ws : dw;
+        a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
+        a.nblocks = a.kctiles * a.psplits;
+        make_magic(a.Ho * a.Wo, a.mHW, a.sHW);
+        make_magic(a.Wo, a.mW, a.sW);
+        ProfScope prof(prof_family(PASS_WGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)p.P * K), st);
+        prof.shape("wgrad", N, H, W, C, K, R, stride, pad, dil);
+        if (int e = launch_wgrad3(a, conv_planes(PASS_WGRAD), st)) return e;
+        if (p.psplits > 1) {
+            const long long total = (long long)K * p.tl.n * (C / 4);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256), 0, st,
+                               (const float*)ws, p.psplits, a.slab, dw, K, RS, C, p.tl);
+            return launch_status("wgrad_reduce_kernel");
+        }
+        return DSRL_OK;
     }
     // pixel groups (split kernels): two groups of 4 waves share a block and half of the planned slabs remain.  Measured
     // (tools/wgrad_kg.py): 1x1 convs gain 5-20 %, 3x3 convs lose (each of their taps already has its own blocks), four groups always lose.
@@ -2362,7 +2375,8 @@ extern "C" int dsrl_conv2d_wgrad_amax(const float* x, int ldx, const uint32_t* x
 // per layer, no pixel splits (slab write + reduce launch) just to fill the chip, one slab reduce for the whole pass.
 namespace dsrl {
 constexpr unsigned kGroupMagic = 0x44535247u;       // "DSRG"
-constexpr int kGroupMaxProblems = 512, kGroupMaxLaunches = kNumCfg;
+constexpr int kGroupMaxProblems = 512, kGroupMaxLaunches = kNumCfg + 2;
+constexpr int kCfgW3 = kNumCfg;         // pseudo tile configurations kCfgW3 + (dilation - 1): all-taps 3x3 problems (conv_wgrad3.hip)
 struct GroupLaunch { int cfg, first, count, grid; double flops, bytes; };
 struct GroupHeader {
     unsigned magic; int n, nlaunch, npl, f16;
@@ -2379,8 +2393,14 @@ struct GroupItem { WgradArgs a; TileCfg cfg; int bm, bn; double cost, flops, byt
 // spreads the blocks of a range (taps x tiles) over all 8 XCDs, and every XCD's L2 then fetches the whole of x and dy; with 8 ranges each XCD
 // owns one and fetches an eighth. DSRL_WGRAD_XCD_SPLIT=1 takes 8 ranges where the slab traffic this adds (8 slabs written and read back)
 // is smaller than the operand re-fetches it removes.
-static int group_psplits(long long P, int K, int R, int S, int C, long long x_pixels) {
+static int group_psplits(long long P, int K, int R, int S, int C, long long x_pixels, bool w3 = false) {
     const long long chunks = ceil_div(P, 32);
+    if (w3) {       // a block takes all nine taps of its pixel range: 9 x the work per pixel
+        const int forced3 = env_int("DSRL_FORCE_PSPLITS", 0), px = std::max(256, env_int("DSRL_WGRAD3_PX", 4096));
+        long long sp3 = forced3 > 0 ? forced3 : (P + px / 2) / px;
+        sp3 = std::max<long long>(1, std::min<long long>(sp3, std::max<long long>(1, chunks / 8)));
+        return (int)std::min<long long>(sp3, 256);
+    }
     const int forced = env_int("DSRL_FORCE_PSPLITS", 0);
     long long sp = forced > 0 ? forced : (P + group_target_px() / 2) / group_target_px();
     sp = std::max<long long>(1, std::min<long long>(sp, std::max<long long>(1, chunks / 4)));
@@ -2405,9 +2425,9 @@ static int group_item(const dsrl_wgrad_problem& q, int npl, GroupItem& it) {
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db;
     a.ntaps = p.tl.n;
     for (int i = 0; i < p.tl.n; ++i) a.taps[i] = p.tl.taps[i];
-    a.psplits = group_psplits(p.P, K, R, S, C, (long long)N * H * W);
+    a.psplits = group_psplits(p.P, K, R, S, C, (long long)N * H * W, p.w3);
     a.kg = 1; a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
-    a.nblocks = a.kctiles * a.ntaps * a.psplits;
+    a.nblocks = p.w3 ? a.kctiles * a.psplits : a.kctiles * a.ntaps * a.psplits;
     a.dw_final = q.dw; a.dw = q.dw;
     a.rblocks = a.psplits > 1 ? (int)ceil_div((long long)K * a.ntaps * (C / 4), 1024) : 0;
     make_magic(a.Ho * a.Wo, a.mHW, a.sHW);
@@ -2415,7 +2435,7 @@ static int group_item(const dsrl_wgrad_problem& q, int npl, GroupItem& it) {
     DSRL_REQUIRE(!conv_f16() || (q.x_amax != nullptr && q.dy_amax != nullptr), DSRL_E_BADARG,
                  "conv2d_wgrad_group: the f16x3 arithmetic needs x_amax / dy_amax of every problem (dsrl_amax measures a tensor)");
     a.amax_x = q.x_amax; a.amax_dy = q.dy_amax;
-    it.a = a; it.cfg = p.cfg; it.bm = p.bm; it.bn = p.bn;
+    it.a = a; it.cfg = p.w3 ? (TileCfg)(kCfgW3 + dil - 1) : p.cfg; it.bm = p.bm; it.bn = p.bn;
     it.cost = (double)p.P / a.psplits * p.bm * p.bn;
     it.flops = 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil);
     it.bytes = 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)p.P * K);
@@ -2435,7 +2455,8 @@ extern "C" size_t dsrl_conv2d_wgrad_group_workspace_bytes(const dsrl_wgrad_probl
         if (q.N <= 0 || q.H <= 0 || q.W <= 0 || q.C <= 0 || q.K <= 0 || q.R <= 0 || q.S <= 0 || q.stride <= 0 || q.dil <= 0 || q.pad < 0) continue;
         if (out_size(q.H, q.R, q.stride, q.pad, q.dil) <= 0 || out_size(q.W, q.S, q.stride, q.pad, q.dil) <= 0) continue;
         const long long P = (long long)q.N * out_size(q.H, q.R, q.stride, q.pad, q.dil) * out_size(q.W, q.S, q.stride, q.pad, q.dil);
-        const int sp = dsrl::group_psplits(P, q.K, q.R, q.S, q.C, (long long)q.N * q.H * q.W);
+        const bool w3 = out_size(q.H, q.R, q.stride, q.pad, q.dil) == q.H && plan_wgrad(q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.dil).w3;
+        const int sp = dsrl::group_psplits(P, q.K, q.R, q.S, q.C, (long long)q.N * q.H * q.W, w3);
         if (sp > 1) total += align_up((size_t)sp * q.K * q.R * q.S * q.C * sizeof(float), 256);
     }
     return total;
@@ -2510,11 +2531,15 @@ extern "C" int dsrl_conv2d_wgrad_group_launch(const void* host_table, const void
     for (int l = 0; l < h->nlaunch; ++l) {
         const GroupLaunch& L = h->launch[l];
         if (L.grid <= 0) continue;
-        int bm, bn; cfg_dims((TileCfg)L.cfg, bm, bn);
-        const size_t lds = (size_t)2 * npl * 16 * ((bm * 2 + 64) + (bn * 2 + 64));
         const WgradArgs* t = dargs + L.first;
         const int* s = dstarts + L.first;
         ProfScope prof(3 * prof_arith(npl, h->f16 != 0) + 1, L.flops, L.bytes, st);
+        if (L.cfg >= kCfgW3) {
+            if (int e = launch_wgrad3_group(t, s, L.count, L.grid, npl, L.cfg - kCfgW3 + 1, st)) return e;
+            continue;
+        }
+        int bm, bn; cfg_dims((TileCfg)L.cfg, bm, bn);
+        const size_t lds = (size_t)2 * npl * 16 * ((bm * 2 + 64) + (bn * 2 + 64));
 #define DSRL_LAUNCH_WGROUP(a_, b_, c_, d_)                                                                                         \
         if (h->f16 && npl == 1) hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 1, true>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count); \
         else if (h->f16) hipLaunchKernelGGL((conv_wgrad_group_kernel<a_, b_, c_, d_, 2, true>), dim3((unsigned)L.grid), dim3(256), lds, st, t, s, L.count); \

@@ -52,6 +52,7 @@ def set_conv_precision(mode):
     if not -1 <= code <= 5:
         raise ValueError(f'conv precision mode {mode!r}')
     _mode_cache.clear()
+    _query_cache.clear()        # workspace sizes and partial counts follow the arithmetic's tile / pixel-range plans
     return int(_lib.load().dsrl_conv_precision(code))
 
 

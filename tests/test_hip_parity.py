@@ -371,6 +371,51 @@ def test_wgrad_group_vs_oracle_and_per_layer(mode):
         print(shp, '%.1e %.1e' % (e1, e2))
 
 
+_W3_CASES = [
+    (2, 64, 8, 32, 128, 1),          # one full tile pair per 64 channels
+    (1, 304, 5, 64, 192, 1),         # decoder widths: ragged tile of in channels (304 = 4.75 x 64) and of out channels (192 = 1.5 x 128 rows of 64)
+    (2, 128, 6, 32, 100, 2),         # dilation 2 (layer4), out channels no multiple of 32
+    (3, 36, 2, 96, 96, 1),           # two image rows: every chunk sees a padding row; 36 in channels
+]
+
+
+@pytest.mark.parametrize('mode', ['f16x3', 'f16x1'])
+@pytest.mark.parametrize('case', _W3_CASES)
+def test_wgrad_all_taps_kernel_matches_per_tap_kernel(case, mode, monkeypatch):
+    """conv_wgrad3_kernel (3x3 / stride 1: all nine taps of a 64 x 64 tile in one block, x rows staged once per chunk and read at nine offsets)
+    against conv_wgrad_split_kernel (one tap per block) and the fp64 oracle.  With the same pixel ranges both kernels add the same products in
+    the same order: equal values (a tap's all-padding chunks, which the per-tap kernel skips, add zeros).  Per-layer launches with 1 and 3 pixel
+    ranges (slabs + reduce) and the grouped launch."""
+    N, C, H, W, K, dil = case
+    HF.set_conv_precision(mode)
+    rs = np.random.RandomState(sum(case))
+    x = np.maximum(rs.standard_normal((N, C, H, W)), 0).astype(np.float32)
+    dy = rs.standard_normal((N, K, H, W)).astype(np.float32)
+    dwo = O.conv2d_bwd(x.astype(np.float64), np.zeros((K, C, 3, 3)), dy.astype(np.float64), 1, dil, dil, False)[1]
+    xt, ldx = HF.pm_vec4(dev(x)); dyt, lddy = HF.pm_vec4(dev(dy))
+    xa, dya = HF.amax_for(xt, xt, ldx), HF.amax_for(dyt, dyt, lddy)
+    shp = (N, H, W, C, K, 3, 3, 1, dil, dil)
+    tol = 3e-6 if mode == 'f16x3' else 2e-3
+    got = {}
+    for w3 in ('0', '1'):
+        monkeypatch.setenv('DSRL_WGRAD3', w3)
+        for sp in (1, 3):
+            monkeypatch.setenv('DSRL_FORCE_PSPLITS', str(sp))
+            dw = torch.full((K, C, 3, 3), float('nan'), device=DEV).contiguous(memory_format=torch.channels_last)
+            ws = HF._ws(int(HF.query('dsrl_conv2d_wgrad_workspace_bytes', *shp)), xt)
+            HF.call('dsrl_conv2d_wgrad_amax', xt.data_ptr(), ldx, xa.data_ptr(), dyt.data_ptr(), lddy, dya.data_ptr(), dw.data_ptr(), *shp, ws.data_ptr(), ws.numel(), HF._stream())
+            got[(w3, sp)] = host(dw)
+            check(got[(w3, sp)], dwo, tol, f'dw all-taps={w3} ranges={sp}')
+        monkeypatch.delenv('DSRL_FORCE_PSPLITS')
+        q = HF.WgradQueue()
+        dwg = torch.full((K, C, 3, 3), float('nan'), device=DEV).contiguous(memory_format=torch.channels_last)
+        q.add(xt, ldx, dyt, lddy, dwg, shp, None, xa, dya)
+        q.flush()
+        check(host(dwg), dwo, tol, f'grouped dw all-taps={w3}')
+    for sp in (1, 3):
+        assert np.array_equal(got[('0', sp)], got[('1', sp)]), (sp, float(np.abs(got[('0', sp)] - got[('1', sp)]).max()))
+
+
 def test_conv_into_and_from_channel_slices():
     """ld > C: reading a channel slice of a wider buffer (the concat layout) gives the same result."""
     rs = np.random.RandomState(5)
