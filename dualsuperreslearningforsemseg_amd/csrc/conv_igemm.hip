@@ -2183,11 +2183,11 @@ static void launch_wgrad(const WgradArgs& a_in, TileCfg cfg, int bm, int bn, dim
 
 namespace dsrl {
 struct WgPlan { int Ho, Wo; long long P; TileCfg cfg; int bm, bn, ktiles, ctiles, psplits; TapList tl; size_t ws; bool w3; };
-// pixel ranges of an all-taps 3x3 launch (conv_wgrad3.hip; one 4-wave block per CU): enough blocks for ~2 per CU, at least 8 chunks each
+// pixel ranges of an all-taps 3x3 launch (conv_wgrad3.hip; one 8-wave block per CU): as many as fit two rounds of blocks, at least 8 chunks each
 static int w3_psplits(long long tiles, long long chunks) {
     const int forced = env_int("DSRL_FORCE_PSPLITS", 0);
     if (forced > 0) return (int)std::max<long long>(1, std::min<long long>(forced, chunks));
-    long long sp = ceil_div(env_int("DSRL_WGRAD3_TARGET_BLOCKS", 512), std::max<long long>(tiles, 1));
+    long long sp = std::max<long long>(1, env_int("DSRL_WGRAD3_TARGET_BLOCKS", 2 * kNumCU) / std::max<long long>(tiles, 1));     // rounded down: the blocks fit two rounds of one per CU
     sp = std::min(sp, std::max<long long>(1, chunks / 8));
     return (int)std::max<long long>(1, std::min<long long>(sp, 128));
 }

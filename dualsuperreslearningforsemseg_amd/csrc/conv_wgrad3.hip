@@ -32,7 +32,8 @@ struct W3Geom {
     static constexpr int A_RP = NT / A_V, B_RP = NT / B_V;    // pixel rows per staging pass
     static constexpr int A_IT = 32 / A_RP, B_IT = (XR + B_RP - 1) / B_RP;
     static constexpr int SA = BM * 2 + 64, SB = BN * 2 + 64;  // LDS row strides in bytes
-    static constexpr int PLA = 32 * SA, PLB = XR * SB, OFF_B = NPL * PLA, STAGE = NPL * (PLA + PLB);
+    // the x plane has room for every row the staging passes touch (B_IT * B_RP >= XR): the passes write unconditionally, rows past XR are never read
+    static constexpr int PLA = 32 * SA, PLB = B_IT * B_RP * SB, OFF_B = NPL * PLA, STAGE = NPL * (PLA + PLB);
     static_assert(32 % A_RP == 0 && A_IT >= 1, "dy staging passes");
 };
 
@@ -129,7 +130,7 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int bid) {
         const pl4 t = PT::cvt(res);
         if (v < A_IT) {
             *reinterpret_cast<pl4*>(st + pl * PLA + wa_off + v * (A_RP * SA)) = t;
-        } else if (b_row + (v - A_IT) * B_RP < XR) {
+        } else {
             *reinterpret_cast<pl4*>(st + pl * PLB + wb_off + (v - A_IT) * (B_RP * SB)) = t;
         }
         if (pl + 1 < NPL) {
@@ -161,7 +162,6 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int bid) {
 #pragma unroll
             for (int j = 0; j < NTAP; ++j) {
                 if (j + 1 < NTAP) {
-                    constexpr int dummy = 0; (void)dummy;
                     const int r = (T0 + j + 1) / 3, s = (T0 + j + 1) % 3;
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl) fb[(j + 1) & 1][pl] = tr8(cur + pl * PLB + tr_off_b + (r * XW + 16 * h + s * HALO) * SB, SB);
@@ -270,7 +270,7 @@ bool wgrad3_eligible(int N, int H, int W, int C, int K, int R, int S, int stride
     if (!f16 || (npl != 1 && npl != 2) || !env_int("DSRL_WGRAD3", 1)) return false;
     if (R != 3 || S != 3 || stride != 1 || pad != dil || (dil != 1 && dil != 2)) return false;
     if (W % 32 != 0 || H <= dil || N <= 0) return false;                    // Ho == H, Wo == W: a 32-pixel chunk is a piece of one image row; all nine taps see pixels
-    if (C % 4 != 0 || K < env_int("DSRL_WGRAD3_MIN_K", 96) || C < 32) return false;     // the 128-row tile of out channels is at least 3/4 full
+    if (C % 4 != 0 || K < env_int("DSRL_WGRAD3_MIN_K", 64) || C < 32) return false;     // the 64-row tile of out channels is full at least once
     return (long long)N * H * W < (1ll << 31);
 }
 void wgrad3_tile(int& bm, int& bn) { bm = 32 * kW3WGM; bn = 32 * kW3WGN; }

@@ -10,7 +10,8 @@ GROUPS = [
     ('conv dgrad, plane operands (conv_planes_kernel, DGRAD = true)', r'conv_planes_kernel<.*?, true, \d', None),
     ('plane producers (split_planes_kernel, filter_planes_batched_kernel)', r'split_planes_kernel|filter_planes_batched', None),
     ('conv fp32 MFMA kernels', r'conv_igemm_f32_kernel|conv_wgrad_f32_kernel', None),
-    ('conv wgrad grouped (conv_wgrad_group_kernel)', r'conv_wgrad_group_kernel', None),
+    ('conv wgrad grouped, one tap per block (conv_wgrad_group_kernel)', r'conv_wgrad_group_kernel', None),
+    ('conv wgrad grouped, 3x3 with all taps per block (conv_wgrad3_group_kernel)', r'conv_wgrad3', None),
     ('conv wgrad per layer (stem) + slab reduces', r'conv_wgrad_split_kernel|wgrad_reduce', None),
     ('split-K reduces of forward / dgrad', r'splitk_reduce', None),
     ('operand magnitudes (amax_kernel)', r'amax_kernel', None),

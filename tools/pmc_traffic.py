@@ -25,6 +25,9 @@ def family(name):
     m = re.search(r'conv_wgrad_group_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\w+))?>', name)
     if m:           # the grouped launch of the same kernel body: same family (bench.py's roofline name)
         return f"conv_wgrad_split_kernel<{arith(m.group(5), m.group(6))}>"
+    m = re.search(r'conv_wgrad3(?:_group)?_kernel<(\d+), (\d+)>', name)
+    if m:           # all nine taps of a 3x3 weight gradient in one block (conv_wgrad3.hip): the same family, f16 arithmetics only
+        return f"conv_wgrad_split_kernel<{'f16x1' if m.group(1) == '1' else 'f16x3'}>"
     m = re.search(r'conv_igemm_f32_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)', name)
     if m:
         return f"conv_igemm_f32_kernel ({'dgrad' if m.group(5) == 'true' else 'forward'})"
