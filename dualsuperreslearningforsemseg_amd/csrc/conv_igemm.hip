@@ -2393,10 +2393,10 @@ struct GroupItem { WgradArgs a; TileCfg cfg; int bm, bn; double cost, flops, byt
 // spreads the blocks of a range (taps x tiles) over all 8 XCDs, and every XCD's L2 then fetches the whole of x and dy; with 8 ranges each XCD
 // owns one and fetches an eighth. DSRL_WGRAD_XCD_SPLIT=1 takes 8 ranges where the slab traffic this adds (8 slabs written and read back)
 // is smaller than the operand re-fetches it removes.
-static int group_psplits(long long P, int K, int R, int S, int C, long long x_pixels, bool w3 = false) {
+static int group_psplits(long long P, int K, int R, int S, int C, long long x_pixels, int w3_px = 0) {
     const long long chunks = ceil_div(P, 32);
-    if (w3) {       // a block takes all nine taps of its pixel range: 9 x the work per pixel
-        const int forced3 = env_int("DSRL_FORCE_PSPLITS", 0), px = std::max(256, env_int("DSRL_WGRAD3_PX", 4096));
+    if (w3_px > 0) {       // a block takes all nine taps of its pixel range: 9 x the work per pixel; pixels per block chosen for the whole launch (w3_group_px)
+        const int forced3 = env_int("DSRL_FORCE_PSPLITS", 0), px = w3_px;
         long long sp3 = forced3 > 0 ? forced3 : (P + px / 2) / px;
         sp3 = std::max<long long>(1, std::min<long long>(sp3, std::max<long long>(1, chunks / 8)));
         return (int)std::min<long long>(sp3, 256);
@@ -2410,7 +2410,13 @@ static int group_psplits(long long P, int K, int R, int S, int C, long long x_pi
     }
     return (int)std::min<long long>(sp, 256);
 }
-static int group_item(const dsrl_wgrad_problem& q, int npl, GroupItem& it) {
+// Pixels per block of the all-taps launches.  Their blocks run one per CU and are dealt in id order to whichever CU is free, so with equal blocks a
+// launch takes ceil(blocks / 256) rounds, and a last round that is nearly full does not fit in practice (1264 blocks of 128 chunks: six rounds, 1.25 ms;
+// 1216: five, 1.07 ms).  Measured over the step's 34 problems (tools/sweep_w3_px.sh; launch + slab reduce, ms): 1536 px 1.59, 2048 1.52, 3072 1.58,
+// 4096 1.61, 8192 1.56, 16384 1.56 - short blocks balance best and their extra slab traffic costs less than the rounding of long ones.  A list-schedule
+// simulation per problem list (block time = chunks + constant, 256 or 240 CUs, slab bytes at 4 TB/s) did not predict the measured order and was dropped.
+static int w3_group_px(const dsrl_wgrad_problem*, int, int) { return std::max(256, env_int("DSRL_WGRAD3_PX", 2048)); }
+static int group_item(const dsrl_wgrad_problem& q, int npl, GroupItem& it, const int* w3_px) {
     const int N = q.N, H = q.H, W = q.W, C = q.C, K = q.K, R = q.R, S = q.S, stride = q.stride, pad = q.pad, dil = q.dil;
     if (int e = check_conv(q.x, q.dy, q.dw, N, H, W, C, K, R, S, stride, pad, dil)) return e;
     DSRL_REQUIRE(C % 4 == 0 && q.ldx % 4 == 0 && q.lddy % 4 == 0 && q.lddy >= pad4(K) && ((uintptr_t)q.x % 16) == 0 && ((uintptr_t)q.dy % 16) == 0 && ((uintptr_t)q.dw % 16) == 0,
@@ -2425,7 +2431,7 @@ static int group_item(const dsrl_wgrad_problem& q, int npl, GroupItem& it) {
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db;
     a.ntaps = p.tl.n;
     for (int i = 0; i < p.tl.n; ++i) a.taps[i] = p.tl.taps[i];
-    a.psplits = group_psplits(p.P, K, R, S, C, (long long)N * H * W, p.w3);
+    a.psplits = group_psplits(p.P, K, R, S, C, (long long)N * H * W, p.w3 ? w3_px[dil - 1] : 0);
     a.kg = 1; a.kctiles = p.ktiles * p.ctiles; a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
     a.nblocks = p.w3 ? a.kctiles * a.psplits : a.kctiles * a.ntaps * a.psplits;
     a.dw_final = q.dw; a.dw = q.dw;
@@ -2450,13 +2456,14 @@ extern "C" size_t dsrl_conv2d_wgrad_group_table_bytes(int n) { return n > 0 ? gr
 extern "C" size_t dsrl_conv2d_wgrad_group_workspace_bytes(const dsrl_wgrad_problem* problems, int n) {
     if (!problems || n <= 0) return 0;
     size_t total = 0;
+    const int w3_px[2] = {dsrl::w3_group_px(problems, n, 1), dsrl::w3_group_px(problems, n, 2)};
     for (int i = 0; i < n; ++i) {
         const dsrl_wgrad_problem& q = problems[i];
         if (q.N <= 0 || q.H <= 0 || q.W <= 0 || q.C <= 0 || q.K <= 0 || q.R <= 0 || q.S <= 0 || q.stride <= 0 || q.dil <= 0 || q.pad < 0) continue;
         if (out_size(q.H, q.R, q.stride, q.pad, q.dil) <= 0 || out_size(q.W, q.S, q.stride, q.pad, q.dil) <= 0) continue;
         const long long P = (long long)q.N * out_size(q.H, q.R, q.stride, q.pad, q.dil) * out_size(q.W, q.S, q.stride, q.pad, q.dil);
         const bool w3 = out_size(q.H, q.R, q.stride, q.pad, q.dil) == q.H && plan_wgrad(q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.dil).w3;
-        const int sp = dsrl::group_psplits(P, q.K, q.R, q.S, q.C, (long long)q.N * q.H * q.W, w3);
+        const int sp = dsrl::group_psplits(P, q.K, q.R, q.S, q.C, (long long)q.N * q.H * q.W, w3 ? w3_px[q.dil - 1] : 0);
         if (sp > 1) total += align_up((size_t)sp * q.K * q.R * q.S * q.C * sizeof(float), 256);
     }
     return total;
@@ -2471,8 +2478,9 @@ extern "C" int dsrl_conv2d_wgrad_group_plan(const dsrl_wgrad_problem* problems, 
     DSRL_REQUIRE(npl >= 1 && npl <= 3, DSRL_E_UNSUPPORTED, "conv2d_wgrad_group_plan: the grouped launch exists for the 16-bit MFMA arithmetics only (dsrl_conv_precision 1..5)");
     std::vector<GroupItem> items((size_t)n);
     size_t need_ws = 0;
+    const int w3_px[2] = {w3_group_px(problems, n, 1), w3_group_px(problems, n, 2)};
     for (int i = 0; i < n; ++i) {
-        if (int e = group_item(problems[i], npl, items[(size_t)i])) return e;
+        if (int e = group_item(problems[i], npl, items[(size_t)i], w3_px)) return e;
         need_ws += items[(size_t)i].slab_bytes;
     }
     DSRL_REQUIRE(ws_bytes >= need_ws && (need_ws == 0 || ws), DSRL_E_WORKSPACE, "conv2d_wgrad_group_plan: workspace %zu < %zu", ws_bytes, need_ws);

@@ -33,7 +33,8 @@ groups = [
     ('conv dgrad: conv_igemm_split_kernel<.., true, 2, .., 2> (f16x3, pre-split filters)', r'conv_igemm_split_kernel<.*?, true, \d', None),
     ('conv forward with fp16-plane operands staged by LDS-DMA: conv_planes_kernel (the 3x3 convs over operands of >= 8 Mi elements: cat_conv.0 / cat_conv.4 / SISR, the three dilated ASPP convs)', r'conv_planes_kernel', None),
     ('plane producers: split_planes_kernel (concat buffer, cat_conv.4 input, layer4 output), filter_planes_batched_kernel (six filters)', r'split_planes_kernel|filter_planes_batched', None),
-    ('conv wgrad, grouped: conv_wgrad_group_kernel (all layers of the pass in 2 grids)', r'conv_wgrad_group_kernel', None),
+    ('conv wgrad, grouped, 3x3 stride 1 with all nine taps per block: conv_wgrad3_group_kernel (dilation 1 / 2)', r'conv_wgrad3', None),
+    ('conv wgrad, grouped, one tap per block: conv_wgrad_group_kernel (1x1, strided, dilated ASPP)', r'conv_wgrad_group_kernel', None),
     ('conv wgrad, stem (row-folded 7x7) + grouped slab reduce', r'conv_wgrad_split_kernel|wgrad_reduce', None),
     ('split-K reduces of forward / dgrad', r'splitk_reduce', None),
     ('operand magnitudes measured by a launch of their own (amax_kernel; the rest is left by producers)', r'amax_kernel', None),
