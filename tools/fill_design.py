@@ -27,7 +27,7 @@ F['MFMABUSY'] = ('; '.join(f"`{k}` {v['mfma_busy']:.3f}" for k, v in fams.items(
 F['CPU'] = f"{d['cpu_baseline']['value']:.2f}"
 F['CPUNP'] = f"{d['cpu_baseline_numpy_port']['value']:.2f}"
 rows = re.findall(r'^\| (.+?) \| ([\d.]+) \| (\d+) \| ([\d.]+) \|$', summ, re.M)
-short = [('conv forward:', 'conv forward (register-staged)'), ('conv dgrad:', 'conv dgrad (register-staged)'), ('conv forward with fp16-plane', 'conv forward with plane operands (LDS-DMA)'), ('plane producers', 'plane producers'), ('conv wgrad, grouped', 'grouped weight gradients'), ('conv wgrad, stem', 'stem weight gradient + slab reduce'),
+short = [('conv forward:', 'conv forward (register-staged)'), ('conv dgrad:', 'conv dgrad (register-staged)'), ('conv forward with fp16-plane', 'conv forward with plane operands (LDS-DMA)'), ('plane producers', 'plane producers'), ('conv wgrad, grouped, 3x3', 'grouped weight gradients, 3x3 with all taps per block'), ('conv wgrad, grouped, one tap', 'grouped weight gradients, one tap per block'), ('conv wgrad, stem', 'stem weight gradient + slab reduce'),
          ('split-K reduces', 'split-K reduces'), ('operand magnitudes', 'amax launches'), ('BatchNorm forward from', 'BatchNorm forward from conv statistics'),
          ('BatchNorm backward from', 'BatchNorm backward from dgrad sums'), ('BatchNorm single-kernel', 'BatchNorm barrier kernels'), ('BatchNorm three-kernel', 'BatchNorm large / odd tensors'),
          ('fused loss pass', 'loss pass'), ('ConvTranspose', 'ConvTranspose tail'), ('bilinear', 'bilinear / shuffle / pools / dropout / concat'), ('SGD + filter pass', 'SGD + filter pass'),
