@@ -485,7 +485,9 @@ def main():
                                               f"{stamp.get('commit', 'unknown')} with conv_igemm.hip sha256 {stamp.get('conv_igemm_sha16', 'unknown')}")
                     pl_now = hashlib.sha256(open(os.path.join(ROOT, 'dualsuperreslearningforsemseg_amd', 'csrc', 'conv_planes.hip'), 'rb').read()).hexdigest()[:16]
                     # false: the kernels changed since that profile (profiles before round 4 carry no stamp for conv_planes.hip)
-                    roof['traffic_kernel_source_unchanged'] = stamp.get('conv_igemm_sha16') == src_now and stamp.get('conv_planes_sha16', pl_now) == pl_now
+                    w3_now = hashlib.sha256(open(os.path.join(ROOT, 'dualsuperreslearningforsemseg_amd', 'csrc', 'conv_wgrad3.hip'), 'rb').read()).hexdigest()[:16]
+                    roof['traffic_kernel_source_unchanged'] = (stamp.get('conv_igemm_sha16') == src_now and stamp.get('conv_planes_sha16', pl_now) == pl_now
+                                                               and stamp.get('conv_wgrad3_sha16', w3_now) == w3_now)
                     break
             # matrix-pipe busy fraction of the dominant family from the committed SQ-counter pass of this command (tools/pmc_step.sh): the share of
             # SIMD cycles in which an MFMA executes - what `frac` leaves unsaid about WHY a launch is below its roof
