@@ -267,6 +267,13 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32_kernel(const ConvArg
 // LDS as they come, which removes half of the split work of a chunk - work that every one of the M / BM row tiles used to repeat.
 // WGM * WGN = 4 waves (256 threads per K group) or, round 3, 8 waves (512 threads, KG = 1: the 256x128 and 256x256 tiles - a wave still owns
 // MR x NR tiles of 32x32, but the block stages 0.75x / 0.5x the bytes of 128x128 tiles per multiply-add, through LDS and from L2).
+// Full-step LDS stages (round 4, fp16 arithmetics): a stage holds a whole 32-channel step (64-byte rows) instead of a 16-channel half, so a K group
+// crosses ONE block barrier per step and the fragment reads of the second half overlap the MFMAs of the first (profiles/round4_staging_ablation.txt:
+// with no operand staging at all the half-step loop still took 27.6 of 30.9 us).  Same MFMAs in the same order.  -DDSRL_FULLSTEP=0: half-step stages.
+#ifndef DSRL_FULLSTEP
+#define DSRL_FULLSTEP 1
+#endif
+constexpr bool kFullStep = DSRL_FULLSTEP != 0;
 template <int MR, int NR, int WGM, int WGN, bool DGRAD, int NPL, int KG = 1, int ARITH = 0, bool STR1 = false>
 __global__ __launch_bounds__(64 * WGM * WGN * KG, KG == 1 ? 2 : 1)
 void conv_igemm_split_kernel(const ConvArgs a) {
@@ -285,7 +292,8 @@ void conv_igemm_split_kernel(const ConvArgs a) {
     constexpr int BM = 32 * MR * WGM, BN = 32 * NR * WGN;
     constexpr int A_IT = (BM + RP - 1) / RP, B_IT = (BN + RP - 1) / RP;
     constexpr int NV = A_IT + B_IT;
-    constexpr int ROWB = 32;
+    constexpr bool FS = kFullStep && F16;                            // a stage = a whole 32-channel step
+    constexpr int ROWB = FS ? 64 : 32;
     constexpr int STAGE = (BM + BN) * NPL * ROWB;                     // bytes
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
@@ -434,16 +442,18 @@ void conv_igemm_split_kernel(const ConvArgs a) {
     };
 
     // ---- LDS addressing (swizzle: 16-byte half h of row r lives at half h ^ bit3(r))
-    const int w_swz = (((c4 >> 1) ^ ((r0 >> 3) & 1)) << 4) + ((c4 & 1) << 3);
+    // half-step stages: 16-byte half h of row r lives at half h ^ bit3(r).  Full-step stages: 16-byte unit u (of 4) of row r lives at unit u ^ bits 2..3
+    // of r - 16 consecutive rows then read (and write) 16 different bank groups
     const int frag_row = lane & 31;
-    const int r_swz = ((lane >> 5) ^ ((frag_row >> 3) & 1)) << 4;
+    auto wswz = [&](int hf) -> int { return FS ? (((((hf << 1) | (c4 >> 1)) ^ ((r0 >> 2) & 3)) << 4) + ((c4 & 1) << 3)) : ((((c4 >> 1) ^ ((r0 >> 3) & 1)) << 4) + ((c4 & 1) << 3)); };
+    auto rswz = [&](int hf) -> int { return FS ? ((((hf << 1) | (lane >> 5)) ^ ((frag_row >> 2) & 3)) << 4) : (((lane >> 5) ^ ((frag_row >> 3) & 1)) << 4); };
     float res[4] = {0.f, 0.f, 0.f, 0.f};
     auto cstep = [&](char* nb, float4 (*R)[2], int hf, int c) {        // plane c % NPL of staged value c / NPL
         const int v = c / NPL, pl = c % NPL;
         if (PREB && v >= A_IT) {                // filter rows arrive split: first terms in .x .y, second terms in .z .w
             if (pl == 0 && b_rows) {
                 const float4 x = R[v][hf];
-                char* q = nb + (NPL * BM + r0 + RP * (v - A_IT)) * ROWB + w_swz;
+                char* q = nb + (NPL * BM + r0 + RP * (v - A_IT)) * ROWB + wswz(hf);
                 *reinterpret_cast<uint2*>(q) = make_uint2(__float_as_uint(x.x), __float_as_uint(x.y));
                 if (NPL > 1) *reinterpret_cast<uint2*>(q + BN * ROWB) = make_uint2(__float_as_uint(x.z), __float_as_uint(x.w));       // f16x1 uses the first terms only
             }
@@ -459,9 +469,9 @@ void conv_igemm_split_kernel(const ConvArgs a) {
         }
         const pl4 t = PT::cvt(res);
         if (v < A_IT) {
-            *reinterpret_cast<pl4*>(nb + (pl * BM + r0 + RP * v) * ROWB + w_swz) = t;
+            *reinterpret_cast<pl4*>(nb + (pl * BM + r0 + RP * v) * ROWB + wswz(hf)) = t;
         } else if (b_rows) {
-            *reinterpret_cast<pl4*>(nb + (NPL * BM + pl * BN + r0 + RP * (v - A_IT)) * ROWB + w_swz) = t;
+            *reinterpret_cast<pl4*>(nb + (NPL * BM + pl * BN + r0 + RP * (v - A_IT)) * ROWB + wswz(hf)) = t;
         }
         if (pl + 1 < NPL) PT::residual(res, t);
     };
@@ -472,6 +482,7 @@ void conv_igemm_split_kernel(const ConvArgs a) {
         // in the order the MFMAs below need them (LDS reads return in order, so the first MFMA waits for two reads, not for all of them): the last
         // plane of the filter fragments, the first plane of the pixel fragments, then the rest
         pl8 fa[MR][NPL], fb[NR][NPL];
+        const int r_swz = rswz(0);
         auto rd_a = [&](int i, int pl) { fa[i][pl] = *reinterpret_cast<const pl8*>(cur + (pl * BM + (wm * MR + i) * 32 + frag_row) * ROWB + r_swz); };
         auto rd_b = [&](int j, int pl) { fb[j][pl] = *reinterpret_cast<const pl8*>(cur + (NPL * BM + pl * BN + (wn * NR + j) * 32 + frag_row) * ROWB + r_swz); };
 #pragma unroll
@@ -506,6 +517,51 @@ void conv_igemm_split_kernel(const ConvArgs a) {
         for (int c = (NMFMA + MPS - 1) / MPS; c < CSTEPS; ++c) cstep(nxt, R, hf, c);
     };
 
+    // full-step stages: the MFMAs of BOTH halves of the step in `cur`, the split of both halves of register set R (the next step) into `nxt` between them.
+    // Small tiles read the fragments of both halves up front; tiles with four 32x32 pieces per wave read the second half's behind the first half's MFMAs.
+    auto pipe_full = [&](const char* cur, char* nxt, float4 (*R)[2]) {
+        constexpr bool BOTH = MR * NR <= 2;
+        pl8 fa[BOTH ? 2 : 1][MR][NPL], fb[BOTH ? 2 : 1][NR][NPL];
+        auto rd = [&](int h) {
+            const int sw = rswz(h), s_ = BOTH ? h : 0;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) fb[s_][j][NPL - 1] = *reinterpret_cast<const pl8*>(cur + (NPL * BM + (NPL - 1) * BN + (wn * NR + j) * 32 + frag_row) * ROWB + sw);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                for (int i = 0; i < MR; ++i) fa[s_][i][pl] = *reinterpret_cast<const pl8*>(cur + (pl * BM + (wm * MR + i) * 32 + frag_row) * ROWB + sw);
+#pragma unroll
+            for (int pl = NPL - 2; pl >= 0; --pl)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) fb[s_][j][pl] = *reinterpret_cast<const pl8*>(cur + (NPL * BM + pl * BN + (wn * NR + j) * 32 + frag_row) * ROWB + sw);
+        };
+        constexpr int NM2 = 2 * NMFMA, CS2 = 2 * CSTEPS, MPS2 = NM2 / CS2 > 0 ? NM2 / CS2 : 1;
+        rd(0);
+        if (BOTH) rd(1);
+        __builtin_amdgcn_sched_barrier(0);
+        int m = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!BOTH && h == 1) { rd(1); __builtin_amdgcn_sched_barrier(0); }
+            const int s_ = BOTH ? h : 0;
+#pragma unroll
+            for (int sum = NPL - 1; sum >= 0; --sum)
+#pragma unroll
+                for (int pa = 0; pa <= sum; ++pa)
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+#pragma unroll
+                        for (int j = 0; j < NR; ++j) {
+                            acc[i][j] = PT::mfma(fa[s_][i][pa], fb[s_][j][sum - pa], acc[i][j]);
+                            if (m % MPS2 == 0 && m / MPS2 < CS2) cstep(nxt, R, (m / MPS2) / CSTEPS, (m / MPS2) % CSTEPS);
+                            __builtin_amdgcn_sched_barrier(0);
+                            ++m;
+                        }
+        }
+#pragma unroll
+        for (int c = (NM2 + MPS2 - 1) / MPS2; c < CS2; ++c) cstep(nxt, R, c / CSTEPS, c % CSTEPS);
+    };
+
     const int nloc = (q1 - q0 + KG - 1) / KG;   // pipeline iterations: the same for every group (barriers are block-wide)
     if (q0 < q1) {
         issue(R0);
@@ -515,6 +571,25 @@ void conv_igemm_split_kernel(const ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         sh_a = amax_shift_of(am_a); sh_b = amax_shift_of(am_b);
     }
+    if constexpr (FS) {
+        // S0 / S1 hold whole steps.  Phase q: the set whose step sits in `cur` is free - it is requested again (step q + 2) first; the other set
+        // (step q + 1, requested one phase ago) is split into the other stage between the MFMAs of step q; one barrier.
+        if (q0 < q1) {
+#pragma unroll
+            for (int c = 0; c < 2 * CSTEPS; ++c) cstep(S0, R0, c / CSTEPS, c % CSTEPS);
+            __syncthreads();
+        }
+        for (int q = 0; q < nloc; q += 2) {
+            issue(R0);                      // local step q + 2
+            pipe_full(S0, S1, R1);          // MFMAs of step q, split of step q + 1 (past the end: zeros)
+            __syncthreads();
+            if (q + 1 < nloc) {
+                issue(R1);                  // local step q + 3
+                pipe_full(S1, S0, R0);
+                __syncthreads();
+            }
+        }
+    } else {
     if (q0 < q1) {
 #pragma unroll
         for (int c = 0; c < CSTEPS; ++c) cstep(S0, R0, 0, c);
@@ -533,6 +608,7 @@ void conv_igemm_split_kernel(const ConvArgs a) {
             pipe(S1, S0, R0, 0);
             __syncthreads();
         }
+    }
     }
     constexpr int EPG = 16 / KG;                // accumulator registers per 32x32 tile that one K group stores in the epilogue
     if constexpr (KG > 1) {
@@ -1701,7 +1777,7 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
     const bool s1 = DGRAD && a.stride == 1 && a.par == 0 && env_int("DSRL_DGRAD_S1", 1);
     if (npl) {
         const int kg = a.kg > 1 ? a.kg : 1;
-        const size_t stages = (size_t)2 * (bm + bn) * npl * 32;      // two stages of 32-byte rows per K group: <= 60 KiB for every tile
+        const size_t stages = (size_t)2 * (bm + bn) * npl * ((kFullStep && f16) ? 64 : 32);      // two stages per K group: 32-byte rows (a 16-channel half-step), or 64-byte rows (a whole step: fp16 arithmetics)
         if (kg > 1) {
             // K groups (64x64 tiles: 2 or 4 groups, 128x64 / 64x128: 2): block of 256*kg threads, LDS = kg stage pairs or the (kg-1)
             // accumulator sets of the final reduction (all kg of them: every group sums, every group stores a share), whichever is larger (up to 72 KiB)
@@ -1753,16 +1829,20 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
 #undef DSRL_LAUNCH_BIG
             return launch_status("conv_igemm_split_kernel<f16x3, 8 waves>");
         }
+#define DSRL_SPLIT_ONE(...)                                                                                                  \
+        { static const hipError_t at_ = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); (void)at_; \
+          hipLaunchKernelGGL((conv_igemm_split_kernel<__VA_ARGS__>), grid, dim3(256), lds2, st, a); }
 #define DSRL_LAUNCH_SPLIT(a_, b_, c_, d_)                                                                                    \
-        if (f16 && npl == 1 && a.w_split) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 1, 1, 2, false>), grid, dim3(256), lds2, st, a); \
-        else if (f16 && npl == 1) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 1, 1, 1>), grid, dim3(256), lds2, st, a); \
-        else if (f16 && a.w_split && s1) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2, DGRAD>), grid, dim3(256), lds2, st, a); \
-        else if (f16 && a.w_split) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 2>), grid, dim3(256), lds2, st, a); \
-        else if (f16) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2, 1, 1>), grid, dim3(256), lds2, st, a); \
+        if (f16 && npl == 1 && a.w_split) DSRL_SPLIT_ONE(a_, b_, c_, d_, DGRAD, 1, 1, 2, false)                               \
+        else if (f16 && npl == 1) DSRL_SPLIT_ONE(a_, b_, c_, d_, DGRAD, 1, 1, 1)                                              \
+        else if (f16 && a.w_split && s1) DSRL_SPLIT_ONE(a_, b_, c_, d_, DGRAD, 2, 1, 2, DGRAD)                                \
+        else if (f16 && a.w_split) DSRL_SPLIT_ONE(a_, b_, c_, d_, DGRAD, 2, 1, 2)                                             \
+        else if (f16) DSRL_SPLIT_ONE(a_, b_, c_, d_, DGRAD, 2, 1, 1)                                                          \
         else if (npl == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 2>), grid, dim3(256), lds2, st, a); \
         else hipLaunchKernelGGL((conv_igemm_split_kernel<a_, b_, c_, d_, DGRAD, 3>), grid, dim3(256), lds2, st, a);
         DSRL_CFG_SWITCH(cfg, DSRL_LAUNCH_SPLIT)
 #undef DSRL_LAUNCH_SPLIT
+#undef DSRL_SPLIT_ONE
         return launch_status(f16 ? (npl == 1 ? "conv_igemm_split_kernel<f16x1>" : "conv_igemm_split_kernel<f16x3>") : (npl == 2 ? "conv_igemm_split_kernel<bf16x3>" : "conv_igemm_split_kernel<bf16x6>"));
     }
     const size_t lds1 = (size_t)(bm + bn) * LDS_LD * sizeof(float);
