@@ -2,12 +2,15 @@
 //
 // conv_wgrad_split_kernel (conv_igemm.hip) gives every filter tap its own blocks: a 32-pixel chunk of dy is fetched, split into fp16 terms and
 // written to LDS by 9 x (tiles along C) blocks, a chunk of x by 9 x (tiles along K) blocks - 13.7 vector instructions per MFMA and 3.5 x the
-// algorithmic HBM traffic (profiles/round3_*), with the matrix pipe a third busy.  Here a block owns a (128 out-channel x 64 in-channel) tile of
-// dw for all nine taps (4 waves, each a 64 x 32 piece of the tile for all taps: 288 accumulator registers, the MFMAs of a wave run on 18
-// independent chains): per chunk of 32 consecutive output pixels of ONE image row it stages the dy rows once and the three input rows
+// algorithmic HBM traffic (profiles/round3_*), with the matrix pipe a third busy.  Here a block owns a (64 out-channel x 64 in-channel) tile of
+// dw for all nine taps: per chunk of 32 consecutive output pixels of ONE image row it stages the dy rows once and the three input rows
 // ho-d, ho, ho+d once, each 32 + 2d pixels wide (d = dilation = padding), and the tap (r, s) reads its x operand from row r at a pixel offset of
-// s*d - the nine shifted windows are nine LDS addresses, not nine trips through the memory pipeline.  Per 32-pixel chunk a wave issues
-// 2 x 9 x 3 MFMAs (32x32x16 f16) on nine independent accumulators against one ninth of the conversions and loads per MFMA.
+// s*d - the nine shifted windows are nine LDS addresses, not nine trips through the memory pipeline.
+// 8 waves = 2 x 2 positions of a 32 x 32 piece x 2 tap groups (taps 0..4 and 5..8; waves w and w + 4 share a SIMD, so every SIMD carries nine taps):
+// 80 accumulator registers per lane, 230 VGPRs, two waves per SIMD.  Per 32-pixel chunk a wave issues 2 x 5 (4) x 3 MFMAs (32x32x16 f16) on
+// independent accumulators against 0.16 KB of staged operands per MFMA (0.5 KB in the per-tap kernel).  What did not survive register allocation:
+// 4 waves with all nine taps each (144 accumulators in AGPRs: one wave per SIMD is issue-bound; 288: shuffled between AGPRs and VGPRs) and 64 x 32
+// wave pieces (160 accumulators + staging: 350 spills) - profiles/round4_wgrad3.txt.
 //
 // Staging mirrors wgrad_split_body: pixel-major fp16 planes in LDS (row stride + 64 B), operands gathered with ds_read_b64_tr_b16, two LDS
 // stages of one whole chunk each, ONE block-wide barrier per chunk; the split of chunk i+1 is interleaved with the MFMAs of chunk i and every
