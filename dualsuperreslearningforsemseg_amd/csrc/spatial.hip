@@ -648,6 +648,160 @@ __global__ __launch_bounds__(256, 4) void convt2x2_bwd_fused_kernel(const float*
     }
 }
 
+// The same backward on the matrix pipe (round 4).  Per input pixel the VALU kernel above issues 2 x 1444 multiply-adds and sits at 0.28 of the HBM rate
+// (191 us for 478 MB).  Both halves are small GEMMs with the pixels as the long dimension:
+//   dx [px x CI]        = G [px x 4*CO] . Wt [4*CO x CI]      G = the pixel's four output gradients, column (tap, co)
+//   dw [CI (+1) x 4*CO] = X^T [CI (+1) x px] . G [px x 4*CO]  row CI of X^T is all ones: its row of the product is db per tap
+// and v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate - the arithmetic class of the VALU kernel) runs them at 4096 flop per 64 cycles and
+// SIMD.  A block walks row segments of 128 input pixels (grid-stride, next segment's loads in flight); each of its four waves owns 32 pixels: 38 MFMAs
+// for their dx tile (the transposed filter stays in 38 registers) and 16 x 3 for its share of dw, accumulated over all segments of the block.
+using f32x16_t = __attribute__((ext_vector_type(16))) float;
+template <int CI, int CO>
+__global__ __launch_bounds__(256, 2) void convt2x2_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+                                                                 float* __restrict__ dx, float* __restrict__ part, int N, int H, int W,
+                                                                 int nseg_per_row, int nseg) {
+    constexpr int TP = 128, COLS = 4 * CO, GS = COLS + 1, XS = CI + 1, NK = COLS / 2, NJ = (COLS + 31) / 32;
+    static_assert(CI < 32 && COLS % 2 == 0 && NJ <= 3 && (TP * CI) % 4 == 0 && (2 * TP * CO) % 4 == 0, "tile does not fit");
+    constexpr int NOUT = CI * COLS;
+    constexpr int XV = TP * CI / 4, DV = 2 * TP * CO / 4;                   // float4 per x segment / per dy row segment
+    constexpr int XR = (XV + 255) / 256, DR = (DV + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float buf[TP * GS];            // gradients [px][tap][co], row stride 77: the 32 rows of a column read 32 banks
+    __shared__ __attribute__((aligned(16))) float xa[TP * XS];             // inputs [px][ci], slot ci = CI holds 1.0
+    static_assert(3 * NJ * 16 * 64 <= TP * GS, "the final merge of the waves' dw tiles reuses buf");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int t = tid; t < TP * XS; t += 256) xa[t] = (t % XS) == CI ? 1.f : 0.f;
+    // transposed filter as the B operand of the dx GEMM: k = tap * CO + co (two per MFMA), n = ci
+    float wreg[NK];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        const int k = 2 * kk + lh, tap = k / CO, co = k - tap * CO;
+        wreg[kk] = l31 < CI ? w[(l31 * CO + co) * 4 + tap] : 0.f;
+    }
+    // LDS word of element t of the x segment / of a gradient row segment (formed when stored)
+    auto xword = [](int t) -> int { const int px = t / CI; return px * XS + (t - px * CI); };
+    auto dword = [](int t) -> int { const int px = t / (2 * CO); return px * GS + (t - px * (2 * CO)); };
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+    float4 RX[XR], RD[2][DR];
+    auto ld4 = [](__amdgpu_buffer_rsrc_t r, unsigned off) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    auto gload = [&](int seg) {
+        const int row = seg / nseg_per_row;                                  // n*H + h
+        const int w0 = (seg - row * nseg_per_row) * TP, npx = min(TP, W - w0);
+        const int n = row / H, h = row - n * H;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(x + ((long long)row * W + w0) * CI), 0, npx * CI * 4, 0x00020000);
+        const float* d = dy + (((long long)(n * 2 * H + 2 * h)) * (2 * W) + 2 * w0) * CO;
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)d, 0, 2 * npx * CO * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(d + 2ll * W * CO), 0, 2 * npx * CO * 4, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < XR; ++k) RX[k] = ld4(xr, tid + 256 * k < XV ? (unsigned)(tid + 256 * k) * 16u : 0x80000000u);
+#pragma unroll
+        for (int k = 0; k < DR; ++k) { const unsigned off = tid + 256 * k < DV ? (unsigned)(tid + 256 * k) * 16u : 0x80000000u; RD[0][k] = ld4(r0, off); RD[1][k] = ld4(r1, off); }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int k = 0; k < XR; ++k)
+            if (tid + 256 * k < XV) { const int t = 4 * (tid + 256 * k); xa[xword(t)] = RX[k].x; xa[xword(t + 1)] = RX[k].y; xa[xword(t + 2)] = RX[k].z; xa[xword(t + 3)] = RX[k].w; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < DR; ++k)
+                if (tid + 256 * k < DV) {
+                    float* b = buf + i * 2 * CO;
+                    const int t = 4 * (tid + 256 * k);
+                    b[dword(t)] = RD[i][k].x; b[dword(t + 1)] = RD[i][k].y; b[dword(t + 2)] = RD[i][k].z; b[dword(t + 3)] = RD[i][k].w;
+                }
+    };
+    f32x16_t accw[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accw[j][e] = 0.f;
+    const int px0 = 32 * wv;
+
+    int seg = (int)blockIdx.x;
+    if (seg < nseg) gload(seg);
+    for (; seg < nseg; seg += (int)gridDim.x) {
+        const int row = seg / nseg_per_row;
+        const int w0 = (seg - row * nseg_per_row) * TP, npx = min(TP, W - w0);
+        __syncthreads();                        // the previous segment's readers are done
+        lstore();
+        __syncthreads();
+        if (seg + (int)gridDim.x < nseg) gload(seg + (int)gridDim.x);
+        // ---- dx tile of the wave's 32 pixels: A = gradients (row = pixel, two k per MFMA), B = transposed filter
+        {
+            f32x16_t acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            const float* g = buf + (px0 + l31) * GS + lh;
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g[2 * kk], wreg[kk], acc, 0, 0, 0);
+            if (l31 < CI) {
+                float* o = dx + ((long long)row * W + w0) * CI + l31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int px = px0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (px < npx) o[(long long)px * CI] = acc[e];
+                }
+            }
+        }
+        // ---- dw (+ db through the ones row): A = inputs transposed (row = ci, k = pixel), B = gradients (k = pixel, column = (tap, co))
+#pragma unroll 4
+        for (int sp = 0; sp < 16; ++sp) {
+            const int px = px0 + 2 * sp + lh;
+            const float av = l31 <= CI ? xa[px * XS + l31] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int col = 32 * j + l31;
+                const float bv = col < COLS ? buf[px * GS + col] : 0.f;
+                accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accw[j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- merge the four waves' dw tiles (fixed order) and leave the block's partials in the layout convt2x2_dw_finalize_kernel merges
+    __syncthreads();
+    if (wv > 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) buf[(((wv - 1) * NJ + j) * 16 + e) * 64 + lane] = accw[j][e];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) accw[j][e] += buf[((u * NJ + j) * 16 + e) * 64 + lane];
+    }
+    __syncthreads();
+    if (wv == 0) {                              // D[row = ci][col = (tap, co)] -> LDS as a dense [CI + 1][COLS] matrix
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ci = (e & 3) + 8 * (e >> 2) + 4 * lh, col = 32 * j + l31;
+                if (ci <= CI && col < COLS) xa[ci * COLS + col] = accw[j][e];
+            }
+    }
+    static_assert((CI + 1) * COLS <= TP * XS, "the dw matrix is staged in xa");
+    __syncthreads();
+    float* po = part + (long long)blockIdx.x * (NOUT + CO);
+    for (int o = tid; o < NOUT + CO; o += 256) {
+        float sum;
+        if (o < NOUT) sum = xa[o];
+        else {
+            sum = 0.f;
+#pragma unroll
+            for (int ij = 0; ij < 4; ++ij) sum += xa[CI * COLS + ij * CO + (o - NOUT)];
+        }
+        po[o] = sum;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- PixelShuffle
 __global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H, int W, int c, int r, int inverse) {
     // forward: dst (N,H*r,W*r,c) <- src (N,H,W,c*r*r); inverse: dst (N,H,W,c*r*r) <- src (N,H*r,W*r,c)
@@ -857,7 +1011,19 @@ extern "C" int dsrl_convt2x2_bwd(const float* x, const float* w, const float* dy
     const long long nseg = (long long)N * H * nseg_per_row;
     dim3 gdx((unsigned)ceil_div(W, 128), (unsigned)(N * H));
     const bool fused = W % 4 == 0 && nseg < (1ll << 31) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && env_flag_convt_fused();
+    const char* mv = getenv("DSRL_CONVT_MFMA");
+    const bool mfma = fused && (!mv || atoi(mv) != 0);                      // the same pass on the matrix pipe (segments of 128 pixels)
+    const int nseg_per_row2 = (int)ceil_div(W, 128);
+    const long long nseg2 = (long long)N * H * nseg_per_row2;
+    const int nb2 = (int)std::min<long long>(nb, nseg2);
 #define DSRL_CONVT_BWD_BODY                                                                                                         \
+    if (mfma) {                                                                                                                     \
+        hipLaunchKernelGGL((convt2x2_bwd_mfma_kernel<CI, CO>), dim3(nb2), dim3(256), 0, st, x, w, dy, dx, (float*)ws, N, H, W, nseg_per_row2, (int)nseg2); \
+        if (int e = launch_status("convt2x2_bwd_mfma_kernel")) return e;                                                            \
+        hipLaunchKernelGGL((convt2x2_dw_finalize_kernel<CI, CO>), dim3((unsigned)ceil_div(CI * CO * 4 + CO, 32)), dim3(256), 0, st, \
+                           (const float*)ws, nb2, dw, dbias);                                                                       \
+        return launch_status("convt2x2_dw_finalize_kernel");                                                                        \
+    }                                                                                                                               \
     if (fused) {                                                                                                                    \
         hipLaunchKernelGGL((convt2x2_bwd_fused_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, x, w, dy, dx, (float*)ws, N, H, W, nseg_per_row, (int)nseg); \
         if (int e = launch_status("convt2x2_bwd_fused_kernel")) return e;                                                           \
