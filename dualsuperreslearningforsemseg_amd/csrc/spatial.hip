@@ -336,6 +336,89 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const float* __restri
     }
 }
 
+// The same forward on the matrix pipe (round 4): y [px x 4*CO] = X [px x (CI + 1)] . W' [(CI + 1) x 4*CO] with column (tap, co), the extra row of W' holding
+// the bias against a column of ones in X - v_mfma_f32_32x32x2_f32 (exact fp32 products).  A block walks row segments of 128 input pixels (grid-stride, the
+// next segment's input in flight); a wave forms the [32 px x 4*CO] tile of its pixels in 3 x 10 MFMAs (CI = CO = 19; the filter sits in 30 registers),
+// the tile goes through LDS in the [px][tap][co] order in which BOTH output rows are contiguous, and leaves as 16-byte stores.
+using f32x16_f = __attribute__((ext_vector_type(16))) float;
+template <int CI, int CO>
+__global__ __launch_bounds__(256, 2) void convt2x2_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 float* __restrict__ y, int N, int H, int W, int nseg_per_row, int nseg) {
+    constexpr int TP = 128, COLS = 4 * CO, GS = COLS + 1, NK = (CI + 2) / 2, XS = 2 * NK, NJ = (COLS + 31) / 32;
+    static_assert(CI + 1 <= XS && NJ <= 3 && (TP * CI) % 4 == 0 && (2 * TP * CO) % 4 == 0, "tile does not fit");
+    constexpr int XV = TP * CI / 4, DV = 2 * TP * CO / 4;                   // float4 per x segment / per output row segment
+    constexpr int XR = (XV + 255) / 256, DR = (DV + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float buf[TP * GS];            // outputs [px][tap][co], row stride 77
+    __shared__ __attribute__((aligned(16))) float xa[TP * XS];             // inputs [px][ci], slot ci = CI holds 1.0 (bias row), the rest of the pad 0
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int t = tid; t < TP * XS; t += 256) xa[t] = (t % XS) == CI ? 1.f : 0.f;
+    float wreg[NJ][NK];                                                     // B operand: k = ci (CI: bias), n = column (tap, co)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const int k = 2 * kk + lh, col = 32 * j + l31, tap = col / CO, co = col - tap * CO;
+            wreg[j][kk] = col < COLS ? (k < CI ? w[(k * CO + co) * 4 + tap] : (k == CI && bias != nullptr ? bias[co] : 0.f)) : 0.f;
+        }
+    auto xword = [](int t) -> int { const int px = t / CI; return px * XS + (t - px * CI); };
+    auto dword = [](int t) -> int { const int px = t / (2 * CO); return px * GS + (t - px * (2 * CO)); };
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+    float4 RX[XR];
+    auto gload = [&](int seg) {
+        const int row = seg / nseg_per_row;
+        const int w0 = (seg - row * nseg_per_row) * TP, npx = min(TP, W - w0);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(x + ((long long)row * W + w0) * CI), 0, npx * CI * 4, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < XR; ++k) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(tid + 256 * k < XV ? (unsigned)(tid + 256 * k) * 16u : 0x80000000u), 0, 0);
+            RX[k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+    };
+    const int px0 = 32 * wv;
+    int seg = (int)blockIdx.x;
+    if (seg < nseg) gload(seg);
+    for (; seg < nseg; seg += (int)gridDim.x) {
+        const int row = seg / nseg_per_row;
+        const int w0 = (seg - row * nseg_per_row) * TP, npx = min(TP, W - w0);
+        const int n = row / H, h = row - n * H;
+        __syncthreads();                        // the previous segment's stores have read buf
+#pragma unroll
+        for (int k = 0; k < XR; ++k)
+            if (tid + 256 * k < XV) { const int t = 4 * (tid + 256 * k); xa[xword(t)] = RX[k].x; xa[xword(t + 1)] = RX[k].y; xa[xword(t + 2)] = RX[k].z; xa[xword(t + 3)] = RX[k].w; }
+        __syncthreads();
+        if (seg + (int)gridDim.x < nseg) gload(seg + (int)gridDim.x);
+        const float* xp = xa + (px0 + l31) * XS + lh;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            f32x16_f acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[2 * kk], wreg[j][kk], acc, 0, 0, 0);
+            const int col = 32 * j + l31;
+            if (col < COLS) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) buf[(px0 + (e & 3) + 8 * (e >> 2) + 4 * lh) * GS + col] = acc[e];
+            }
+        }
+        __syncthreads();
+        float* d = y + (((long long)(n * 2 * H + 2 * h)) * (2 * W) + 2 * w0) * CO;
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)d, 0, 2 * npx * CO * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(d + 2ll * W * CO), 0, 2 * npx * CO * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < DR; ++k)
+                if (tid + 256 * k < DV) {
+                    const float* b = buf + i * 2 * CO;
+                    const int t = 4 * (tid + 256 * k);
+                    const u32x4 v = {__float_as_uint(b[dword(t)]), __float_as_uint(b[dword(t + 1)]), __float_as_uint(b[dword(t + 2)]), __float_as_uint(b[dword(t + 3)])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, i == 0 ? r0 : r1, (int)((unsigned)(tid + 256 * k) * 16u), 0, 0);     // past a ragged segment's end: dropped
+                }
+    }
+}
+
 // dx[n,h,w,ci] = sum_{i,j,co} dy[n,2h+i,2w+j,co] * w[ci,co,i,j]: one block = 128 input pixels of one row.
 template <int CI, int CO>
 __global__ __launch_bounds__(256) void convt2x2_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
@@ -992,6 +1075,16 @@ extern "C" int dsrl_maxpool3x3s2_bwd(const uint8_t* argmax, const float* dy, flo
 extern "C" int dsrl_convt2x2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, dsrl_stream_t stream) {
     DSRL_PROLOGUE(x && w && y && N > 0 && H > 0 && W > 0, "convt2x2_fwd")
     dim3 grid((unsigned)ceil_div(2 * W, 256), (unsigned)(N * H));          // a block writes both output rows of its input row
+    {
+        const char* mv = getenv("DSRL_CONVT_MFMA");
+        const int nseg_per_row = (int)ceil_div(W, 128);
+        const long long nseg = (long long)N * H * nseg_per_row;
+        if ((!mv || atoi(mv) != 0) && W % 4 == 0 && nseg < (1ll << 31) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0) {
+            const int nb = (int)std::min<long long>(nseg, 4 * 512);
+            DSRL_CONVT_DISPATCH(19, 19, hipLaunchKernelGGL((convt2x2_fwd_mfma_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, x, w, bias, y, N, H, W, nseg_per_row, (int)nseg); return launch_status("convt2x2_fwd_mfma_kernel");)
+            DSRL_CONVT_DISPATCH(8, 8, hipLaunchKernelGGL((convt2x2_fwd_mfma_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, x, w, bias, y, N, H, W, nseg_per_row, (int)nseg); return launch_status("convt2x2_fwd_mfma_kernel");)
+        }
+    }
     DSRL_CONVT_DISPATCH(19, 19, hipLaunchKernelGGL((convt2x2_fwd_kernel<CI, CO>), grid, dim3(256), 0, st, x, w, bias, y, N, H, W); return launch_status("convt2x2_fwd_kernel");)
     DSRL_CONVT_DISPATCH(8, 8, hipLaunchKernelGGL((convt2x2_fwd_kernel<CI, CO>), grid, dim3(256), 0, st, x, w, bias, y, N, H, W); return launch_status("convt2x2_fwd_kernel");)
     set_error("convt2x2_fwd: channel counts %d->%d not instantiated (19->19, 8->8)", Cin, Cout);
