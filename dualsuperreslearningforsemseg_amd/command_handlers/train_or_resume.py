@@ -184,12 +184,20 @@ class TrainStep:
     def _body(self, input_image, input_org, target, hp, do_train, in_graph=False):
         """One whole iteration, eagerly (graph mode: the iterations before the capture, with the same order of events)."""
         split = self.split and do_train
-        outs, vals, cuts = self._phase_a(input_image, input_org, target, do_train, in_graph, split)
-        if do_train:
-            if split:
-                self.flat.reduce_chunks(self.flat.ready_chunks())      # runs beside the second phase
-                self._phase_b(cuts)
-            self._finish(hp, in_graph)
+        try:
+            outs, vals, cuts = self._phase_a(input_image, input_org, target, do_train, in_graph, split)
+            if do_train:
+                if split:
+                    self.flat.reduce_chunks(self.flat.ready_chunks())      # runs beside the second phase
+                    self._phase_b(cuts)
+                self._finish(hp, in_graph)
+        except BaseException:
+            # a step that aborts between zero_grad() and sgd_step() (an exception in forward / backward, an allocation failure) must not leave the step
+            # arena open: the validation forwards that follow would draw records from it, and an arena a graph has pinned cannot grow (ADVICE round 4)
+            if do_train and self.flat.device.type == 'cuda':
+                HF.amax_end_step(self.flat.device)
+                HF.wgrad_queue = None
+            raise
         return outs, vals
 
     def _set_hyper(self, hp):

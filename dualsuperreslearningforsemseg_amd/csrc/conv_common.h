@@ -146,7 +146,7 @@ struct WgradArgs {
     const unsigned* amax_dy; const unsigned* amax_x;        // f16x3: max |.| (bit patterns) of dy and of x
 };
 
-// conv_wgrad3.hip: 3x3 / stride-1 weight gradients with all nine taps in one block (f16x3 / f16x1; tile 128 out channels x 64 in channels).
+// conv_wgrad3.hip: 3x3 / stride-1 weight gradients with all nine taps in one block (f16x3 / f16x1; tile 64 out channels x 64 in channels: wgrad3_tile()).
 // WgradArgs as for conv_wgrad_split_kernel with ntaps = 9, kctiles = tiles of that size, nblocks = kctiles * psplits.
 bool wgrad3_eligible(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int npl, bool f16);
 void wgrad3_tile(int& bm, int& bn);

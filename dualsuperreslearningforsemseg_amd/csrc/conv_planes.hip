@@ -23,6 +23,9 @@ namespace dsrl {
 // One LDS-DMA piece: 64 lanes x 16 bytes, global address = descriptor base + voff (bounds-checked) + soff (unchecked), LDS address = lds + 16 * lane.
 // Issued from inline asm: hipcc tracks a builtin LDS-DMA as an LDS store and makes every later ds_read wait for it (vmcnt(0) in front of the fragment
 // reads of the OTHER slot); the waits are placed by hand instead (s_waitcnt_vm below).
+// M0 is written inside the asm without being declared: hipcc rejects "m0" as a clobber ("reserved register ... undefined behaviour"), and nothing the
+// compiler generates for this translation unit uses M0 (no movrel indexing, builtin LDS-DMA, sendmsg or GWS) - tests/test_abi_and_host.py disassembles
+// conv_planes.o and fails the build check if any instruction other than these s_mov_b32 ever reads or writes m0.
 __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
@@ -591,9 +594,10 @@ template <bool DGRAD>
 static int launch_planes_t(const ConvArgs& a, int cfg, hipStream_t st) {
     const dim3 grid((unsigned)(a.mtiles * a.ntiles), 1u, (unsigned)(a.kg > 1 ? 1 : a.splits));
     const int kg = a.kg > 1 ? a.kg : 1;
-    const int r = env_int("DSRL_PLANES_R", 0);
+    static const int r = env_int("DSRL_PLANES_R", 0);       // ring depth override (tools/planes_bench.py), read once
     switch (cfg) {
         case 3:     // 64x64
+#ifdef DSRL_PLANES_ABLATION      // timing-only builds (wrong results): make CXXFLAGS+=-DDSRL_PLANES_ABLATION, profiles/round4_planes_kernel_ab.txt
             if (const int dbg = env_int("DSRL_PLANES_DBG", 0)) {         // timing-only ablations (wrong results): 1 = no MFMA / fragment reads, 2 = no DMA, 3 = neither
                 if constexpr (!DGRAD) {
                     constexpr size_t lds = 128 * 1024;
@@ -621,6 +625,7 @@ static int launch_planes_t(const ConvArgs& a, int cfg, hipStream_t st) {
                     }
                 }
             }
+#endif
             if (kg == 4) DSRL_PLANES_LAUNCH(1, 1, 2, 2, 4, 2)
             if (kg == 2) { if (r == 2) DSRL_PLANES_LAUNCH(1, 1, 2, 2, 2, 2) else if (r == 3) DSRL_PLANES_LAUNCH(1, 1, 2, 2, 2, 3) else DSRL_PLANES_LAUNCH(1, 1, 2, 2, 2, 4) }
             if (r == 2) DSRL_PLANES_LAUNCH(1, 1, 2, 2, 1, 2) else DSRL_PLANES_LAUNCH(1, 1, 2, 2, 1, 3)

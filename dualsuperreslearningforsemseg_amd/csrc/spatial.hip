@@ -1072,6 +1072,9 @@ extern "C" int dsrl_maxpool3x3s2_bwd(const uint8_t* argmax, const float* dy, flo
 #define DSRL_CONVT_DISPATCH(CI_, CO_, BODY)                         \
     if (Cin == CI_ && Cout == CO_) { constexpr int CI = CI_, CO = CO_; BODY }
 
+// DSRL_CONVT_MAX_BLOCKS: test knob - fewer blocks than segments, so that small shapes exercise the grid-stride loop of the segment kernels
+// (prefetch registers and LDS buffers reused across segments)
+static int convt_block_cap(int dflt) { const char* v = getenv("DSRL_CONVT_MAX_BLOCKS"); const int n = v ? atoi(v) : 0; return n > 0 ? std::min(n, dflt) : dflt; }
 extern "C" int dsrl_convt2x2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, dsrl_stream_t stream) {
     DSRL_PROLOGUE(x && w && y && N > 0 && H > 0 && W > 0, "convt2x2_fwd")
     dim3 grid((unsigned)ceil_div(2 * W, 256), (unsigned)(N * H));          // a block writes both output rows of its input row
@@ -1080,7 +1083,7 @@ extern "C" int dsrl_convt2x2_fwd(const float* x, const float* w, const float* bi
         const int nseg_per_row = (int)ceil_div(W, 128);
         const long long nseg = (long long)N * H * nseg_per_row;
         if ((!mv || atoi(mv) != 0) && W % 4 == 0 && nseg < (1ll << 31) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0) {
-            const int nb = (int)std::min<long long>(nseg, 4 * 512);
+            const int nb = (int)std::min<long long>(nseg, convt_block_cap(4 * 512));
             DSRL_CONVT_DISPATCH(19, 19, hipLaunchKernelGGL((convt2x2_fwd_mfma_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, x, w, bias, y, N, H, W, nseg_per_row, (int)nseg); return launch_status("convt2x2_fwd_mfma_kernel");)
             DSRL_CONVT_DISPATCH(8, 8, hipLaunchKernelGGL((convt2x2_fwd_mfma_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, x, w, bias, y, N, H, W, nseg_per_row, (int)nseg); return launch_status("convt2x2_fwd_mfma_kernel");)
         }
@@ -1091,7 +1094,7 @@ extern "C" int dsrl_convt2x2_fwd(const float* x, const float* w, const float* bi
     return DSRL_E_UNSUPPORTED;
 }
 static bool env_flag_convt_fused() { const char* v = getenv("DSRL_CONVT_FUSED_BWD"); return !v || atoi(v) != 0; }   // 0: the separate dx / dw kernels
-static int convt_dw_blocks(int N, int H, int W) { return (int)std::min<long long>(1024, (long long)N * H * ceil_div(W, 64)); }
+static int convt_dw_blocks(int N, int H, int W) { return (int)std::min<long long>(convt_block_cap(1024), (long long)N * H * ceil_div(W, 64)); }
 extern "C" size_t dsrl_convt2x2_bwd_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
     return (size_t)convt_dw_blocks(N, H, W) * (Cin * Cout * 4 + Cout) * sizeof(float);
 }

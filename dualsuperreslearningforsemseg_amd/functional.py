@@ -5,6 +5,7 @@ Tensors keep the reference's logical NCHW shapes; physically they are torch.chan
 raises if its tensors are not on a HIP device: there is no CPU / stock-ATen fallback in this package.
 """
 import os
+import weakref
 
 import torch
 
@@ -111,8 +112,10 @@ def amax_begin_step(device):
 
 
 def amax_end_step(device):
-    """The training step of `device` is over (its optimiser update has been enqueued): records asked for from here on come from the loose arena."""
+    """The training step of `device` is over (its optimiser update has been enqueued, or it was abandoned): records asked for from here on come from
+    the loose arena, and the fp16 planes cached on this step's operand tensors are released."""
     _amax_open.discard(device)
+    drop_planes()
 
 
 def amax_pin(device):
@@ -524,8 +527,9 @@ def planes_for(t, data, ld, amax, taps=9, split_ok=True):
     carries (left by its producer or by an earlier consumer of the same tensor in this step), else a split pass when planes_mode allows one."""
     if planes_mode == 'off' or amax is None or _conv_precision_code() != 4:
         return None
+    gen = getattr(amax, '_dsrl_gen', -1)          # a step-arena record is re-issued (same address) by the next step: its generation is part of the key
     have = getattr(t, '_dsrl_planes', None)
-    if have is not None and have[1] == ld and have[2] == amax.data_ptr() and have[3] == data.data_ptr() and have[4] == t._version:
+    if have is not None and have[1] == ld and have[2] == amax.data_ptr() and have[3] == data.data_ptr() and have[4] == t._version and have[5] == gen:
         return have[0]
     N, Cc, H, W = data.shape
     if Cc % 8 or ld % 8 or data.data_ptr() % 16:
@@ -534,10 +538,29 @@ def planes_for(t, data, ld, amax, taps=9, split_ok=True):
         return None
     buf = planes_of(data, ld, amax)
     try:
-        t._dsrl_planes = (buf, ld, amax.data_ptr(), data.data_ptr(), t._version)
+        t._dsrl_planes = (buf, ld, amax.data_ptr(), data.data_ptr(), t._version, gen)
+        _planes_holders.append(weakref.ref(t))
     except Exception:           # noqa: BLE001
         pass
     return buf
+
+
+# Tensors that carry cached planes.  The planes are as large as the fp32 tensor, the tensor is saved for backward, and in 'auto' mode no backward
+# kernel reads x planes (weight gradients read fp32 x): without a release every large decoder operand would keep a dead full-size copy until its
+# backward node ran (~1.3 GB for the 304-channel concat at 512x1024, B=8: ADVICE round 4).  drop_planes() runs when the forward consumers are
+# done - at the root of backward (fused_losses_backward) and at the end of the step.
+_planes_holders = []
+
+
+def drop_planes():
+    for r in _planes_holders:
+        t = r()
+        if t is not None and hasattr(t, '_dsrl_planes'):
+            try:
+                del t._dsrl_planes
+            except Exception:           # noqa: BLE001
+                pass
+    _planes_holders.clear()
 
 
 def filter_planes(w, rec):
@@ -1434,6 +1457,7 @@ def _const1(value, device):
 def fused_losses_backward(vals):
     """vals[3].backward() without autograd's select / ones / zeros launches at the root of the pass: the unit gradient of element 3 is a
     cached constant."""
+    drop_planes()               # every forward consumer of this step's plane operands has been enqueued
     key = ('e3', vals.device)
     e3 = _const_cache.get(key)
     if e3 is None:

@@ -436,8 +436,11 @@ def golden_pipeline_and_metrics():
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     rgb = rs.randint(0, 256, (2, 37, 53, 3)).astype(np.uint8); lab = rs.randint(0, 34, (2, 37, 53)).astype(np.uint8)
     mean, std = (0.28690, 0.32513, 0.28389), (0.17614, 0.18099, 0.17772)
-    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    # the label table of the REFERENCE (datasets/Cityscapes/settings.py:9-17: pure constants, `from consts import *` resolves through REF on sys.path),
+    # loaded by file path because the top-level name `datasets` is taken by the HuggingFace package
+    cspec = importlib.util.spec_from_file_location('ref_cityscapes_settings', os.path.join(REF, 'datasets', 'Cityscapes', 'settings.py'))
+    cs = importlib.util.module_from_spec(cspec); cspec.loader.exec_module(cs)
+    mean, std = cs.MEAN, cs.STD
     lut = np.full(256, 255, np.uint8)
     for k, v in cs.LABEL_MAPPING_DICT.items():
         if 0 <= k < 256:

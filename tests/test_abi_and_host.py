@@ -150,3 +150,23 @@ def test_bn_fused_block_budget_roundtrip():
     assert HF.set_bn_fused_max_blocks(256) == 0
     assert HF.set_bn_fused_max_blocks(None) == 256
     assert HF.set_bn_fused_max_blocks(first if first >= 0 else None) == -1
+
+
+def test_lds_dma_inline_asm_is_the_only_m0_user(tmp_path):
+    """conv_planes.hip sets M0 inside inline asm without declaring it (hipcc refuses "m0" as a clobber: reserved register).  That is sound only while
+    nothing else in that code object touches M0: disassemble it and require every instruction that names m0 to be one of those s_mov_b32."""
+    import shutil, subprocess
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    obj = os.path.join(ROOT, 'dualsuperreslearningforsemseg_amd', 'csrc', 'conv_planes.o')
+    if not (os.path.isfile(objdump) and os.path.isfile(obj)):
+        pytest.skip('needs llvm-objdump and the in-tree object file')
+    local = tmp_path / 'conv_planes.o'
+    shutil.copy(obj, local)
+    subprocess.run([objdump, '--offloading', str(local)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp_path)
+    dev = [p for p in os.listdir(tmp_path) if 'gfx950' in p]
+    assert len(dev) == 1, os.listdir(tmp_path)
+    asm = subprocess.run([objdump, '-d', str(tmp_path / dev[0])], check=True, capture_output=True, text=True).stdout
+    users = [ln.split('//')[0].split() for ln in asm.splitlines() if re.search(r'\bm0\b', ln.split('//')[0])]
+    assert len(users) > 100                                   # the DMA pieces are there
+    odd = [u for u in users if not (u[0] == 's_mov_b32' and u[1] == 'm0,' and re.fullmatch(r's\d+', u[2]))]
+    assert not odd, odd[:5]

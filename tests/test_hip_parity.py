@@ -435,12 +435,19 @@ def test_convT_golden(golden):
     check(host(x.grad), g['convT.dx'], 1e-5); check(host(w.grad), g['convT.dw'], 1e-5); check(host(b.grad), g['convT.db'], 1e-5)
 
 
-@pytest.mark.parametrize('shape', [(2, 19, 5, 150), (2, 19, 7, 200), (1, 19, 3, 64), (3, 19, 4, 12), (2, 8, 6, 72)])
-def test_convT_vs_oracle_ragged(shape, monkeypatch):
-    # W = 150: the two-kernel backward (segments not 16-byte aligned); W % 4 == 0: the fused backward (dy read once), with a ragged
-    # last segment (200 = 3 * 64 + 8, 72, 12) and with exactly one (64); 8 -> 8 channels: the second instantiation
+@pytest.mark.parametrize('mfma', ['1', '0'])
+@pytest.mark.parametrize('shape', [(2, 19, 5, 150), (2, 19, 7, 200), (1, 19, 3, 64), (3, 19, 4, 12), (2, 8, 6, 72), (2, 19, 9, 328)])
+def test_convT_vs_oracle_ragged(shape, mfma, monkeypatch):
+    # mfma = 1: the fp32-MFMA segment kernels (default for W % 4 == 0; segments of 128 pixels), 0: the VALU kernels (both-rows forward with its
+    # 16-byte path, fused backward over 64-pixel segments).  W = 150: the two-kernel backward (segments not 16-byte aligned); W % 4 == 0 with a
+    # ragged last segment (200, 72, 12, 328 = 2 * 128 + 72) and with exactly one (64); 8 -> 8 channels: the second instantiation.
+    # (2, 19, 9, 328) runs with at most 5 blocks for 54 (MFMA) / 108 (VALU) segments: every block walks several segments, the last one ragged,
+    # so the cross-segment reuse of the prefetch registers and LDS buffers is checked against the fp64 oracle.
     rs = np.random.RandomState(9)
     C = shape[1]
+    monkeypatch.setenv('DSRL_CONVT_MFMA', mfma)
+    if shape[3] == 328:
+        monkeypatch.setenv('DSRL_CONVT_MAX_BLOCKS', '5')
     x = rs.standard_normal(shape).astype(np.float32); w = rs.standard_normal((C, C, 2, 2)).astype(np.float32); b = rs.standard_normal(C).astype(np.float32)
     yo = O.conv_transpose2d_k2s2(x.astype(np.float64), w.astype(np.float64)) + b.astype(np.float64)[None, :, None, None]
     dy = rs.standard_normal(yo.shape).astype(np.float32)
