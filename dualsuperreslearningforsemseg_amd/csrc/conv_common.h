@@ -102,7 +102,17 @@ struct ConvArgs {
     // extent of one plane); the second plane lies a_lo / b_lo bytes behind it (unused with one plane)
     unsigned a_lo, b_lo;
     int planes;                                         // host side: route the launch to conv_planes_kernel
+    // split-K ACROSS workgroups with the reduction inside the launch (conv_sk.hip, template COOP): the `splits` blocks of a tile (blockIdx.z) publish
+    // their partial tiles in coop_slab [z][tile][...], take a ticket, and the block whose ticket is the last one adds them in the order z = 0 .. splits-1
+    // and runs the whole epilogue (bias, accumulate, BatchNorm partials) on y.  tickets: one zeroed word per tile, left zero by the last arriver.
+    float* coop_slab; unsigned* tickets;
 };
+// Arrival tickets of the cooperative split-K launches live in the words of the ACTIVATION operand's amax record that carry no shard: a record is
+// kAmaxWords words of which every kAmaxShardStride-th holds a partial maximum; the other 240 are zero whenever the record is (arena fill, scratch
+// fill) and nothing else touches them.  Ticket t < kCoopMaxTiles sits at word 16 * (t / 15) + 1 + t % 15.  The launches of a stream run one after the
+// other and each leaves its tickets zero, so the convs that share an input tensor share its tickets.
+constexpr int kCoopMaxTiles = (kAmaxShardStride - 1) * kAmaxShards;
+__host__ __device__ inline int coop_ticket_word(int t) { return kAmaxShardStride * (t / (kAmaxShardStride - 1)) + 1 + t % (kAmaxShardStride - 1); }
 __device__ __forceinline__ int dgrad_pix(const ConvArgs& a, int m) {        // row of the parity-ordered GEMM -> pixel index (n*Ho + h)*Wo + w
     const int t = m / a.pbm, p2 = a.par * a.par, c = t % p2, j = (t / p2) * a.pbm + (m - t * a.pbm);
     const int hw = a.Hh * a.Wh, n = j / hw, r = j - n * hw, hh = r / a.Wh, wh = r - hh * a.Wh;
@@ -157,6 +167,10 @@ int launch_wgrad3_group(const WgradArgs* table, const int* starts, int nprob, in
 // cfg is conv_igemm.hip's TileCfg, the tile / K-group / split-K plan (and with it the summation order) is the caller's.
 bool planes_cfg_supported(int cfg, int kg);
 int launch_planes_igemm(const ConvArgs& a, int cfg, bool dgrad, hipStream_t st);
+// conv_sk.hip: 128x128 tiles, two K groups (8 waves), f16x3 / f16x1 with pre-split filters; a.splits > 1 with a.tickets set = cooperative split-K
+bool sk_supported(int cfg, int kg, int npl, bool f16, bool w_split);
+size_t sk_lds_bytes();
+int launch_sk_igemm(const ConvArgs& a, bool dgrad, bool str1, int npl, hipStream_t st);
 __host__ __device__ inline long long planes_lo_offset(long long elems) { return (elems * 2 + 255) / 256 * 256; }      // bytes from the first to the second plane
 
 }  // namespace dsrl
