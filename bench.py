@@ -384,12 +384,35 @@ def main():
         # all collectives complete); plus the ADVICE check that no fused BatchNorm launch gave up at its device-wide barrier beside RCCL
         evs = list(step.comm_events)
         step.time_collectives = False
+        section = sum(e[2].elapsed_time(e[3]) for e in evs) / max(len(evs), 1)
         comm = {'rccl_world_size': dist.get_world_size(), 'backend': dist.get_backend(),
                 'broadcast_ms_per_step': round(sum(e[0].elapsed_time(e[1]) for e in evs) / max(len(evs), 1), 4),
-                'allreduce_exposed_ms_per_step': round(sum(e[2].elapsed_time(e[3]) for e in evs) / max(len(evs), 1), 4),
-                'steps_bracketed': len(evs), 'gradient_bytes_per_step': int(flat.numel * 4),
-                'schedule': ('two hipGraphs per step: the all-reduce of the chunks complete after the first (head, ASPP, layer4) runs beside the second (layers 3..1), '
-                             'the rest behind it' if step.split else 'one hipGraph per step, one all-reduce of the whole arena behind it')}
+                'steps_bracketed': len(evs), 'gradient_bytes_per_step': int(flat.numel * 4)}
+        if step.split:
+            comm['allreduce_exposed_ms_per_step'] = round(section, 4)
+            comm['schedule'] = ('two hipGraphs per step: the all-reduce of the chunks complete after the first (head, ASPP, layer4) runs beside the second (layers 3..1), '
+                                'the rest behind it')
+        else:
+            # one-graph schedule: the bracket holds the chunked all-reduce AND the SGD kernels that run under it; the optimiser pass alone is timed on
+            # scratch arenas of the same size, and what the exchange adds to the step is the difference
+            scratch = [torch.zeros(flat.numel, device=dev) for _ in range(3)]
+            hyp = torch.tensor([0.0, 0.9, 5e-4, 1.0], device=dev)
+            for _ in range(3):
+                HF.sgd_step_dev_(scratch[0], scratch[1], scratch[2], hyp)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                HF.sgd_step_dev_(scratch[0], scratch[1], scratch[2], hyp)
+            e1.record(); torch.cuda.synchronize()
+            sgd_ms = e0.elapsed_time(e1) / 10
+            del scratch
+            exposed = max(section - sgd_ms, 1e-6)
+            comm.update({'exchange_and_update_ms_per_step': round(section, 4), 'sgd_alone_ms': round(sgd_ms, 4),
+                         'allreduce_exposed_ms_per_step': round(exposed, 4),
+                         'allreduce_algorithm_bandwidth_GBps': round(flat.numel * 4 / exposed / 1e6, 1),
+                         'reduce_chunks': int(os.environ.get('DSRL_REDUCE_CHUNKS', '4')),
+                         'schedule': 'one hipGraph per step; behind it the gradient arena is all-reduced in `reduce_chunks` ranges and the SGD kernel of a range runs under '
+                                     'the all-reduce of the next ones'})
         stuck = HF.bn_fused_barrier_timeouts()
         assert stuck == 0, f'{stuck} fused BatchNorm blocks timed out at their device-wide barrier while RCCL shared the device'
         comm['bn_fused_barrier_timeouts'] = stuck

@@ -106,7 +106,7 @@ class TrainStep:
         # 239.5 MB arena behind it (round 2's schedule).
         self.split = flat.world > 1 and flat.defer_collectives and os.environ.get('DSRL_GRAPH_SPLIT', '0') != '0'
         self.time_collectives = False           # bench.py: bracket the exposed part of the collectives with events
-        self.comm_events = []                   # (broadcast start, end, replay-B end, collectives end) per step
+        self.comm_events = []                   # (broadcast start, end, replay end, end of exchange [+ update: one-graph schedule]) per step
 
     def losses(self, outs, input_org, target):
         SSSR, SISR, SSSR_ft, SISR_ft = outs
@@ -176,8 +176,11 @@ class TrainStep:
             HF.join_side_streams()
             if in_graph:
                 return                            # the collectives and the update follow the replay (_replay)
-            flat.reduce_rest() if self.split else flat.reduce_all()
-            flat.sgd_step(hp[0], hp[1], hp[2], hyper=hyper, reduce=False)
+            if self.split:
+                flat.reduce_rest()
+                flat.sgd_step(hp[0], hp[1], hp[2], hyper=hyper, reduce=False)
+            else:
+                flat.reduce_chunked_and_step(hyper=hyper, hp=hp)      # the all-reduce in a few ranges, the update of each range under the next one's exchange
         else:
             flat.sgd_step(hp[0], hp[1], hp[2], hyper=hyper)                                # :445 (eager, world > 1: hook-launched chunk all-reduces overlap)
 
@@ -325,11 +328,17 @@ class TrainStep:
         if flat.world > 1:
             if ev:
                 ev[2].record()
-            flat.reduce_rest() if c.graph_b is not None else flat.reduce_all()
+            if c.graph_b is not None:
+                flat.reduce_rest()
+                if ev:
+                    ev[3].record()
+                flat.sgd_step(0.0, 0.0, 0.0, hyper=self.hyper, reduce=False)
+            else:
+                flat.reduce_chunked_and_step(hyper=self.hyper)       # exchange + update: SGD of range k under the all-reduce of range k + 1
+                if ev:
+                    ev[3].record()
             if ev:
-                ev[3].record()
                 self.comm_events.append(ev)
-            flat.sgd_step(0.0, 0.0, 0.0, hyper=self.hyper, reduce=False)
         self.graph_replays += 1
         return c.outs, c.vals
 

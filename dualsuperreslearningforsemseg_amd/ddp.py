@@ -352,6 +352,32 @@ class FlatParams:
         for w in works:
             w.wait()
 
+    def reduce_chunked_and_step(self, hyper=None, hp=None, nchunks=None):
+        """The default exchange behind a replayed (or deferred eager) backward pass with more than one rank: the gradient arena is cut into
+        `nchunks` contiguous ranges (DSRL_REDUCE_CHUNKS, default 4), every range's all-reduce is launched at once on the collective stream, and the
+        SGD kernel of range k runs on the compute stream as soon as ITS all-reduce is done - under the all-reduces of ranges k+1 .. (round 5; the
+        single 239.5 MB call of round 4 exposed the whole optimiser pass behind the exchange).  Only element-wise kernels touch the ranges, so they
+        need no parameter alignment beyond 16 bytes; no barrier kernel is co-resident with RCCL here - those are all inside the graph that has
+        finished.  Bit-identical to reduce_all() + one SGD launch (same element-wise arithmetic).  Returns the chunk ranges (tests)."""
+        n = max(1, int(os.environ.get('DSRL_REDUCE_CHUNKS', '4')) if nchunks is None else int(nchunks))
+        per = _align(-(-self.numel // n), 1024)
+        ranges = [(a, min(a + per, self.numel)) for a in range(0, self.numel, per)]
+        works = []
+        if self.world > 1:
+            works = [dist.all_reduce(self.g_flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for a, b in ranges]
+        for i, (a, b) in enumerate(ranges):
+            if works:
+                works[i].wait()             # stream-ordered for RCCL: the compute stream waits for this range only
+            if hyper is not None:
+                HF.sgd_step_dev_(self.p_flat[a:b], self.g_flat[a:b], self.m_flat[a:b], hyper)
+            else:
+                HF.sgd_step_(self.p_flat[a:b], self.g_flat[a:b], self.m_flat[a:b], hp[0], hp[1], hp[2], 1.0 / self.world)
+        self._pending = [0] * len(self.chunks)
+        if self.device.type == 'cuda':
+            HF.amax_end_step(self.device)
+        self.wt_valid = self.wt_fp32_valid = self.split_valid = self.planes_valid = False
+        return ranges
+
     def sync_buffers(self):
         if self.world > 1 and self.broadcast_buffers_enabled:
             dist.broadcast(self.b_flat, 0, group=self.pg)

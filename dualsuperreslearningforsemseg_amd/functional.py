@@ -218,6 +218,8 @@ def side_stream(device):
 
 
 def join_side_streams():
+    if not _side:                   # no side stream was ever made (also: a host-only schedule test on CPU)
+        return
     cur = torch.cuda.current_stream()
     for st in _side.values():
         if st.device == cur.device:

@@ -96,6 +96,82 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _sgd_reference(p, g, buf, lr, momentum, weight_decay, grad_scale=1.0):
+    """torch.optim.SGD's update on flat arenas: the CPU stand-in of dsrl_sgd_step (which has no CPU path) for the schedule test below"""
+    with torch.no_grad():
+        d = g * grad_scale + weight_decay * p
+        buf.mul_(momentum).add_(d)
+        p.sub_(lr * buf)
+
+
+def _worker_trainstep(rank, world, port, q):
+    """TrainStep's exchange-and-update section (`_finish`, the one-graph schedule of more than one rank) with two real gloo ranks: the gradient
+    arena travels in DSRL_REDUCE_CHUNKS ranges, each range's SGD kernel follows ITS all-reduce.  The device kernel is replaced by the torch formula
+    (the schedule, the ranges and the collectives are the product's); both ranks must end with identical parameters, equal to one torch.optim.SGD step on
+    the mean gradient, for every chunk count including one that does not divide the arena."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from dualsuperreslearningforsemseg_amd import ddp, functional as HF
+        from dualsuperreslearningforsemseg_amd.command_handlers.train_or_resume import TrainStep
+        HF.sgd_step_ = _sgd_reference
+        calls = {'n': 0}
+        real_ar = ddp.dist.all_reduce
+
+        def counted(*a, **k):
+            calls['n'] += 1
+            return real_ar(*a, **k)
+        ddp.dist.all_reduce = counted
+        for nch in (1, 3, 4):
+            os.environ['DSRL_REDUCE_CHUNKS'] = str(nch)
+            torch.manual_seed(5)
+            mk = lambda: torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(16, 16, 3, padding=1), torch.nn.ReLU(),      # noqa: E731
+                                             torch.nn.Conv2d(16, 5, 1))
+            model, ref = mk(), mk()
+            ref.load_state_dict(model.state_dict())
+            flat = ddp.FlatParams(model, chunk_bytes=256)
+            step = TrainStep(model, flat, 1, 0.1, 1.0, 255, graph=False)
+            flat.defer_collectives = True               # what TrainStep selects for a replayed step with more than one rank
+            assert not step.split
+            opt = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+            torch.manual_seed(11)
+            xs = torch.randn(3, world, 2, 3, 8, 8)
+            for it in range(3):
+                flat.zero_grad()
+                model(xs[it, rank]).square().mean().backward()
+                assert len(flat._works) == 0
+                calls['n'] = 0
+                step._finish((0.05, 0.9, 5e-4), False)
+                assert calls['n'] == len(range(0, flat.numel, ddp._align(-(-flat.numel // nch), 1024))), (calls, nch)
+                opt.zero_grad()
+                ref(xs[it].reshape(world * 2, 3, 8, 8)).square().mean().backward()         # mean over both ranks' samples = mean of the per-rank means
+                opt.step()
+            gathered = [torch.zeros_like(flat.p_flat) for _ in range(world)]
+            dist.all_gather(gathered, flat.p_flat)
+            assert torch.equal(gathered[0], gathered[1]), 'ranks diverged'
+            for (n, p), (_, r) in zip(model.named_parameters(), ref.named_parameters()):
+                assert torch.allclose(p, r, rtol=2e-5, atol=1e-6), (nch, n, float((p - r).abs().max()))
+        q.put((rank, 'ok'))
+    except Exception:      # noqa: BLE001
+        import traceback; q.put((rank, traceback.format_exc()[-900:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_trainstep_chunked_exchange_and_update_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_trainstep, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == {0: 'ok', 1: 'ok'}, res
+
+
 @pytest.mark.timeout(300)
 def test_flat_arena_allreduce_world2_gloo():
     ctx = mp.get_context('spawn')

@@ -260,6 +260,77 @@ def test_planes_kernel_bit_identical_to_register_staged(shape, cfg, kg, monkeypa
     check(outs[1][0], yo, 3e-6, 'y')
 
 
+@pytest.mark.parametrize('shape,splits', [((8, 256, 16, 32, 256, 3, 1, 1, 1), 4), ((8, 1024, 16, 32, 256, 1, 1, 0, 1), 4), ((4, 512, 16, 32, 512, 3, 1, 2, 2), 2),
+                                          ((3, 200, 9, 20, 136, 3, 1, 1, 1), 3), ((8, 256, 16, 32, 256, 3, 1, 1, 1), 1)])
+@pytest.mark.parametrize('mode', ['f16x3', 'f16x1'])
+def test_cooperative_splitk_matches_slabs_and_oracle(shape, splits, mode, monkeypatch):
+    """conv_sk.hip (round 5): 128x128 tiles, two K groups, split-K across workgroups with the reduction INSIDE the launch (arrival tickets in the spare
+    words of the activation's amax record, last arriver sums in the order z = 0 .. splits-1) against the same plan with slabs + splitk_reduce_kernel:
+    forward and data gradient (plain and accumulating) are BIT-identical; both match the fp64 oracle; the BatchNorm partials of the forward epilogue
+    and the BatchNorm-backward sums of the dgrad epilogue - which only the cooperative launch can produce under split-K - reproduce the statistics of
+    the tensors the launch wrote; the tickets are left zero (two launches in a row through the same record).  Ragged case: M, N and C off the tile sizes."""
+    N, C, H, W, K, R, stride, pad, dil = shape
+    monkeypatch.setenv('DSRL_FORCE_CFG', '0'); monkeypatch.setenv('DSRL_FORCE_KG', '2'); monkeypatch.setenv('DSRL_FORCE_SPLITS', str(splits))
+    rs = np.random.RandomState(sum(shape) + splits)
+    x = dev(np.maximum(rs.standard_normal((N, C, H, W)), 0).astype(np.float32))
+    w = dev((rs.standard_normal((K, C, R, R)) / np.sqrt(C * R * R)).astype(np.float32))
+    Ho, Wo = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1, (W + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    dy = dev(rs.standard_normal((N, K, Ho, Wo)).astype(np.float32))
+    HF.set_conv_precision(mode)
+    try:
+        rec, wsp, wtsp, wtr = HF.split_filter(w)
+        xa, dya = HF.amax_for(x), HF.amax_for(dy)
+        shp = (N, H, W, C, K, R, R, stride, pad, dil)
+        st = HF._stream()
+        mean = dev(rs.standard_normal(C).astype(np.float32) * 0.1); invstd = dev((1.0 + rs.rand(C)).astype(np.float32))
+        bnx = dev(rs.standard_normal((N, C, H, W)).astype(np.float32))
+        dx0 = dev(rs.standard_normal((N, C, H, W)).astype(np.float32))
+        outs = {}
+        for coop in ('1', '0'):
+            monkeypatch.setenv('DSRL_SK_COOP', coop)
+            HF._query_cache.clear()
+            parts = int(HF.query('dsrl_conv2d_fwd_stats_parts', *shp)) if (K % 32 == 0 and coop == '1') else 0
+            dparts = int(HF.query('dsrl_conv2d_dgrad_stats_parts', *shp)) if (C % 32 == 0 and coop == '1') else 0
+            ws = torch.empty(int(HF.query('dsrl_conv2d_dgrad_workspace_bytes', *shp)) + int(HF.query('dsrl_conv2d_fwd_workspace_bytes', *shp)) + 4096, device=DEV, dtype=torch.uint8)
+            res = []
+            for rep in range(2):                        # twice: the second launch finds the tickets the first one left
+                y = torch.full((N, K, Ho, Wo), 7.0, device=DEV).contiguous(memory_format=torch.channels_last)
+                stats = torch.zeros(int(HF.query('dsrl_bn_stats_floats', 3, max(parts, 1), K)), device=DEV)
+                HF.call('dsrl_conv2d_fwd_planes', x.data_ptr(), C, xa.data_ptr(), None, w.data_ptr(), rec.data_ptr(), wsp.data_ptr(), None, None, y.data_ptr(), K, *shp,
+                        ws.data_ptr(), ws.numel(), stats.data_ptr() if parts else None, parts, st)
+            res += [host(y)]
+            if parts:
+                pt = host(stats[:3 * parts * K]).reshape(3, parts, K).astype(np.float64)
+                n = pt[0].sum(0); mu = (pt[0] * pt[1]).sum(0) / n
+                m2 = (pt[2] + pt[0] * (pt[1] - mu) ** 2).sum(0)
+                yy = host(y).astype(np.float64).transpose(0, 2, 3, 1).reshape(-1, K)
+                assert np.all(n == yy.shape[0])
+                check(mu, yy.mean(0), 1e-5, 'mean from the partials'); check(m2 / n, yy.var(0), 1e-4, 'variance from the partials')
+            for acc in (0, 1):
+                dx = dx0.clone()
+                bst = torch.zeros(int(HF.query('dsrl_bn_stats_floats', 2, max(dparts, 1), C)), device=DEV)
+                HF.call('dsrl_conv2d_dgrad_planes', dy.data_ptr(), K, dya.data_ptr(), None, w.data_ptr(), None, rec.data_ptr(), wtsp.data_ptr(), None, dx.data_ptr(), C, *shp,
+                        ws.data_ptr(), ws.numel(), bnx.data_ptr() if dparts else None, C, x.data_ptr() if dparts else None, C, mean.data_ptr() if dparts else None,
+                        invstd.data_ptr() if dparts else None, 1, bst.data_ptr() if dparts else None, dparts, acc, st)
+                res += [host(dx)]
+                if dparts:
+                    b2 = host(bst[:2 * dparts * C]).reshape(2, dparts, C).astype(np.float64).sum(1)
+                    g = host(dx).astype(np.float64) * (host(x) > 0)
+                    xh = (host(bnx).astype(np.float64) - host(mean)[None, :, None, None]) * host(invstd)[None, :, None, None]
+                    check(b2[0], g.sum((0, 2, 3)), 2e-5, 'sum g'); check(b2[1], (g * xh).sum((0, 2, 3)), 2e-5, 'sum g xhat')
+            outs[coop] = res
+            assert int(xa.cpu().numpy().view(np.uint32).reshape(16, 16)[:, 1:].max()) == 0 and int(dya.cpu().numpy().view(np.uint32).reshape(16, 16)[:, 1:].max()) == 0, 'tickets left behind'
+        for a_, b_ in zip(outs['1'], outs['0']):
+            assert np.array_equal(a_, b_, equal_nan=True)
+        tol = 1e-3 if mode == 'f16x1' else 3e-6          # f16x1: one 11-bit term per operand (2^-11 = 4.9e-4 per product term)
+        check(outs['1'][0], O.conv2d(host(x).astype(np.float64), host(w).astype(np.float64), None, stride, pad, dil), tol, 'y')
+        dxo = O.conv2d_bwd(host(x).astype(np.float64), host(w).astype(np.float64), host(dy).astype(np.float64), stride, pad, dil, has_bias=False)[0]
+        check(outs['1'][1], dxo, tol, 'dx'); check(outs['1'][2], dxo + host(dx0), tol, 'dx accumulated')
+    finally:
+        HF.set_conv_precision(None)
+        HF._query_cache.clear()
+
+
 def test_pointwise_strided_golden(golden):
     g = golden('ops_micro')
     x = dev(g['conv_s8.x']).requires_grad_(True); w = dev(g['conv_s8.w']).requires_grad_(True)
@@ -976,7 +1047,9 @@ def test_full_size_train_step_properties_512x1024(mode):
     # a random-init 101-layer net with batch-2 BatchNorm amplifies 1e-5 perturbations (ReLU flips): the whole-arena gradient is held to
     # its direction, the per-op accuracy of the mode is pinned by test_conv_precision_modes (3e-5 per conv)
     # f16x1 (11 bits): the same amplification leaves a cosine of ~0.6 at this batch-2 random initialisation (measured 0.59) - the price of the
-    # reference's O1 / O2 arithmetic on such a net, not of this implementation: per conv it is 3e-4 of the range (test_conv_precision_modes)
+    # reference's O1 / O2 arithmetic on such a net, not of this implementation: per conv it is 3e-4 of the range (test_conv_precision_modes), and
+    # every gradient TENSOR of the whole model is pinned at fixed bounds where that amplification is absent
+    # (test_full_model_frozen_bn_every_gradient_vs_stock_torch_fp64[f16x1], round 5)
     assert cos > (0.4 if mode == 'f16x1' else 0.99), (cos, rel)
     print(mode, 'losses', runs[0][0], 'gradient arena vs bf16x6: L2 difference %.2e, cosine %.5f' % (rel, cos))
 
@@ -1534,8 +1607,16 @@ def test_full_model_vs_stock_torch_fp64():
     assert rep['all gradients (L2)'] <= ARENA_GRAD_BOUND, rep
 
 
-def test_full_model_frozen_bn_every_gradient_vs_stock_torch_fp64():
-    """The well-conditioned whole-model pin (round 3): BatchNorm frozen as train_or_resume.py:379-382 does with --freeze-batch-norm (every BN
+@pytest.mark.parametrize('mode', ['f16x3', 'f16x1'])
+def test_full_model_frozen_bn_every_gradient_vs_stock_torch_fp64(mode):
+    """mode 'f16x1' (round 5): the arithmetic of apex O1 / O2 - ONE fp16 term per operand, 11 significand bits - held per
+    gradient TENSOR in the same well-conditioned setting, instead of by the whole-arena cosine of the batch-statistics test above (which a wrong-sign
+    weight gradient of a single layer would pass).  Bounds from the operand error: a conv output carries 2^-11 relative operand rounding averaged over its
+    K-term dot product, measured 3e-4 of the output range per conv (test_conv_precision_modes); forward and backward each stack ~100 such layers with
+    independent errors (x sqrt(100)), so a gradient tensor may sit at a few 1e-3 .. 1e-2 of its range: every tensor within 4e-2, 95 % within 1.5e-2,
+    logits within 1e-2 (a sign error or a dropped term in one layer is an error of order 1 in that layer's tensor and of >= 1e-1 in everything behind it).
+
+    The well-conditioned whole-model pin (round 3): BatchNorm frozen as train_or_resume.py:379-382 does with --freeze-batch-norm (every BN
     module in eval: running statistics, no batch-statistics terms in the backward pass), 128x256 input, B=2, stage 3.  Without the 2-image batch
     statistics of a random-init net the assembled 101-layer backward is no longer ill-conditioned, so EVERY gradient tensor is held to a FIXED
     bound against the fp64 stock-torch graph: 5e-3 of its own range, 95 % of the tensors 2e-3 (the self-calibrating bounds of
@@ -1565,27 +1646,44 @@ def test_full_model_frozen_bn_every_gradient_vs_stock_torch_fp64():
     x = rs.standard_normal((2, 3, 128, 256)).astype(np.float32)
     tg = rs.randint(0, 19, (2, 256, 512)).astype(np.uint8); tg[rs.uniform(size=tg.shape) < 0.1] = 255
     org = rs.standard_normal((2, 3, 256, 512)).astype(np.float32)
-    outs = model(dev(x, cl=False))
-    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
-    vals = HF.fused_losses(outs, dev(tg), dev(org), 255, 0.1, 1.0, 3, flag)
-    vals[3].backward()
+    x1 = mode == 'f16x1'
+    HF.set_conv_precision(mode)
+    try:
+        outs = model(dev(x, cl=False))
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        vals = HF.fused_losses(outs, dev(tg), dev(org), 255, 0.1, 1.0, 3, flag)
+        vals[3].backward()
+        torch.cuda.synchronize()
+    finally:
+        HF.set_conv_precision(None)
     r_outs = ref(torch.from_numpy(x).double())
     r_L = total_loss(r_outs, torch.from_numpy(tg), torch.from_numpy(org).double(), 3)
     r_L[3].backward()
-    check(host(vals[:4]), np.array([float(v.detach()) for v in r_L]), 1e-4, 'losses (CE, MSE, FA, total)')
-    check(host(outs[0]), r_outs[0].detach().numpy(), 1e-3, 'logits'); check_elementwise(host(outs[0]), r_outs[0].detach().numpy(), 1e-3, name='logits')
-    assert (host(outs[0]).argmax(1) == r_outs[0].detach().numpy().argmax(1)).mean() > 0.9999
+    # the feature-affinity term (differences of normalised similarity matrices of two one-channel maps) amplifies the 11-bit error most: 5e-2 for it
+    check(host(vals[:4]), np.array([float(v.detach()) for v in r_L]), 5e-2 if x1 else 1e-4, 'losses (CE, MSE, FA, total)')
+    check(host(vals[:2]), np.array([float(v.detach()) for v in r_L[:2]]), 3e-3 if x1 else 1e-4, 'losses (CE, MSE)')
+    check(host(outs[0]), r_outs[0].detach().numpy(), 1e-2 if x1 else 1e-3, 'logits')
+    if not x1:
+        check_elementwise(host(outs[0]), r_outs[0].detach().numpy(), 1e-3, name='logits')
+    assert (host(outs[0]).argmax(1) == r_outs[0].detach().numpy().argmax(1)).mean() > (0.995 if x1 else 0.9999)
     P, R = dict(model.named_parameters()), dict(ref.named_parameters())
     errs = {k: rel_err(host(P[k].grad), R[k].grad.numpy()) for k in P if P[k].grad is not None and R[k].grad is not None}
     assert len(errs) >= 350, len(errs)
-    bad = {k: '%.1e' % v for k, v in errs.items() if v > 5e-3}
+    every, most = (4e-2, 1.5e-2) if x1 else (5e-3, 2e-3)
+    bad = {k: '%.1e' % v for k, v in errs.items() if v > every}
     worst = max(errs.items(), key=lambda kv: kv[1])
     vs = np.sort(np.array(list(errs.values())))
-    print('gradient tensors', len(errs), 'worst', worst, 'median %.1e 95%% %.1e above 2e-3: %d' % (vs[len(vs) // 2], vs[int(0.95 * len(vs))], int((vs > 2e-3).sum())))
-    # fixed bounds: every one of the 350+ tensors within 5e-3 of its range, 95 % of them within 2e-3 (measured: 2 tensors above 2e-3, worst 4.1e-3 -
-    # one fp32 pass through 101 layers against float64)
+    print(mode, 'gradient tensors', len(errs), 'worst', worst, 'median %.1e 95%% %.1e above %.0e: %d' % (vs[len(vs) // 2], vs[int(0.95 * len(vs))], most, int((vs > most).sum())))
+    # fixed bounds.  f16x3: every one of the 350+ tensors within 5e-3 of its range, 95 % of them within 2e-3 (measured: 2 tensors above 2e-3, worst 4.1e-3 -
+    # one fp32 pass through 101 layers against float64); f16x1: 4e-2 / 1.5e-2 (docstring)
     assert not bad, bad
-    assert vs[int(0.95 * len(vs))] <= 2e-3, vs[int(0.95 * len(vs))]
+    assert vs[int(0.95 * len(vs))] <= most, vs[int(0.95 * len(vs))]
+    if x1:
+        # direction per tensor: a flipped sign or a missing term shows as a cosine far from 1 in exactly that tensor
+        cos = {k: float(np.dot(host(P[k].grad).ravel().astype(np.float64), R[k].grad.numpy().ravel()) /
+                        max(np.linalg.norm(host(P[k].grad).ravel().astype(np.float64)) * np.linalg.norm(R[k].grad.numpy().ravel()), 1e-300)) for k in errs}
+        low = {k: '%.4f' % v for k, v in cos.items() if v < 0.995 and np.linalg.norm(R[k].grad.numpy().ravel()) > 0}
+        assert not low, low
 
 
 def test_train_or_resume_end_to_end(tmp_path):

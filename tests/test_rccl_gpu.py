@@ -86,7 +86,8 @@ def test_rccl_reduction_paths_match_half_lr_single_process():
             # every step reduces the whole gradient arena exactly once - chunk by chunk from the gradient-ready notifications in the eager
             # path; in the graph path as TWO collectives: the chunks complete at the layer3 / layer4 cut between the two graphs of a step
             # (beside the second one), the rest behind it - and broadcasts the BN buffers once (+2 at construction)
-            assert calls['all_reduce'] == STEPS * ((2 if split == '1' else 1) if graph else len(flat.chunks)), (calls, len(flat.chunks))
+            # (one-graph schedule, round 5: the arena travels as DSRL_REDUCE_CHUNKS = 4 ranges whose SGD kernels run under the later ranges' all-reduces)
+            assert calls['all_reduce'] == STEPS * ((2 if split == '1' else 4) if graph else len(flat.chunks)), (calls, len(flat.chunks))
             finals[(graph, split)] = flat.p_flat.clone()
             if graph and split == '1':
                 c = next(iter(step._graphs.values()))
