@@ -120,6 +120,7 @@ PROTOTYPES = {
     'dsrl_prepare_batch': (i32, [fp, fp, fp, C.POINTER(f32), C.POINTER(f32), fp, fp, fp, i32, i32, i32, i32, i32, stream_t]),
     'dsrl_sgd_step': (i32, [fp, fp, fp, i64, f32, f32, f32, f32, stream_t]),
     'dsrl_sgd_step_dev': (i32, [fp, fp, fp, i64, fp, stream_t]),
+    'dsrl_sgd_step_dev_segments': (i32, [fp, fp, fp, fp, i64, fp, stream_t]),
     'dsrl_nan_check': (i32, [fp, i64, fp, stream_t]),
     'dsrl_rng_bind_device_key': (i32, [fp]),
     'dsrl_rng_advance_key': (i32, [fp, stream_t]),

@@ -317,6 +317,7 @@ class TrainStep:
             if ev:
                 ev[1].record()
             flat._reduced, flat._works = set(), []      # no hook fires during a replay: the chunk bookkeeping of the step starts here
+        flat.ensure_filter_amax()           # the graph may rely on the filter magnitudes the previous optimiser pass left (ddp.FlatParams._sgd_range)
         c.graph.replay()
         if c.graph_b is not None:
             flat.reduce_chunks(c.ready)         # head / ASPP / layer4 chunks: their all-reduce runs beside the second graph

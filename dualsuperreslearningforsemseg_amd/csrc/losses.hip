@@ -521,6 +521,30 @@ __global__ __launch_bounds__(256) void sgd_dev_kernel(float* __restrict__ p, con
         buf[e] = bv; p[e] -= lr * bv;
     }
 }
+// The same update over a SEGMENT table that covers the arena (round 5): row {first float, floats (multiple of 4, first float 16-byte aligned), address of an
+// amax record or 0}.  A segment lies inside ONE parameter; for the conv filters the block also leaves max |p| of the values it has just written in the
+// filter's record (bit patterns, atomicMax: order-independent, so the record equals what dsrl_conv2d_filters_amax_batched measures) - the per-step filter pass
+// then starts with the split instead of another 232 MB sweep over the parameters the optimiser wrote a moment ago.  One block per segment.
+__global__ __launch_bounds__(256) void sgd_dev_segments_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                                const long long* __restrict__ table, const float* __restrict__ hyper) {
+    const float lr = hyper[0], mom = hyper[1], wd = hyper[2], gscale = hyper[3];
+    const long long* row = table + 3ll * blockIdx.x;
+    const long long off = row[0];
+    const int n4 = (int)(row[1] >> 2);
+    unsigned* rec = reinterpret_cast<unsigned*>(row[2]);
+    float4* p4 = reinterpret_cast<float4*>(p + off); const float4* g4 = reinterpret_cast<const float4*>(g + off); float4* b4 = reinterpret_cast<float4*>(buf + off);
+    unsigned m = 0u;
+    for (int e = threadIdx.x; e < n4; e += 256) {
+        float4 pv = p4[e]; const float4 gv = g4[e]; float4 bv = b4[e];
+        bv.x = mom * bv.x + fmaf(wd, pv.x, gv.x * gscale); pv.x -= lr * bv.x;
+        bv.y = mom * bv.y + fmaf(wd, pv.y, gv.y * gscale); pv.y -= lr * bv.y;
+        bv.z = mom * bv.z + fmaf(wd, pv.z, gv.z * gscale); pv.z -= lr * bv.z;
+        bv.w = mom * bv.w + fmaf(wd, pv.w, gv.w * gscale); pv.w -= lr * bv.w;
+        p4[e] = pv; b4[e] = bv;
+        m = abs_bits4(m, pv.x, pv.y, pv.z, pv.w);
+    }
+    amax_publish(m, rec);           // every thread of the block reaches it; a null record publishes nothing
+}
 __global__ __launch_bounds__(256) void nan_check_kernel(const float* __restrict__ x, long long n, int* __restrict__ flag) {
     bool bad = false;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) bad |= (x[e] != x[e]);
@@ -741,6 +765,14 @@ extern "C" int dsrl_sgd_step_dev(float* p, const float* g, float* buf, int64_t n
     if (int e = bind_stream_device(st)) return e;
     hipLaunchKernelGGL(sgd_dev_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 1024), 4096)), dim3(256), 0, st, p, g, buf, (long long)n, hyper);
     return launch_status("sgd_dev_kernel");
+}
+extern "C" int dsrl_sgd_step_dev_segments(float* p, const float* g, float* buf, const int64_t* table, int64_t nseg, const float* hyper, dsrl_stream_t stream) {
+    DSRL_REQUIRE(p && g && buf && table && hyper && nseg > 0 && nseg < (1ll << 31), DSRL_E_BADARG, "sgd_step_dev_segments: bad arguments");
+    DSRL_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)buf % 16) == 0, DSRL_E_BADARG, "sgd_step_dev_segments: arenas must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = bind_stream_device(st)) return e;
+    hipLaunchKernelGGL(sgd_dev_segments_kernel, dim3((unsigned)nseg), dim3(256), 0, st, p, g, buf, (const long long*)table, hyper);
+    return launch_status("sgd_dev_segments_kernel");
 }
 extern "C" int dsrl_nan_check(const float* x, int64_t n, int* flag, dsrl_stream_t stream) {
     DSRL_REQUIRE(x && flag && n > 0, DSRL_E_BADARG, "nan_check: bad arguments");

@@ -154,6 +154,7 @@ class FlatParams:
         launch per training step (dsrl_conv2d_transpose_filters_batched) instead of one launch inside every dgrad call."""
         from .nn_modules import HipConv2d
         self.wt_valid, self.wt_fp32_valid, self.split_valid, self._wt_table, self._wt_tiles = False, False, False, None, 0
+        self._split_entries, self._split_table, self._seg_tables, self._amax_key = [], None, {}, None
         if self.device.type != 'cuda':
             return
         mine = {id(p) for p in self.params}
@@ -188,6 +189,7 @@ class FlatParams:
         # the arenas are allocated on first use
         self._split_entries, self._split_table = entries, None
         self.planes_valid, self._plane_sets = False, []
+        self._seg_tables, self._amax_key = {}, None        # segment tables of the optimiser pass by arena range; key under which its filter magnitudes are valid
 
     def _build_split_filters(self):
         floats_w = sum(_align(w.numel()) for w, *_ in self._split_entries)
@@ -215,6 +217,55 @@ class FlatParams:
                 segs.append([w.data_ptr() + 4 * a, min(seg, n - a), rec])
         self._amax_seg_table = torch.tensor(segs, dtype=torch.int64, device=self.device)
         self._amax_segs = len(segs)
+
+    # ------------------------------------------------------------------ optimiser pass that also measures the filters (round 5)
+    def _params_key(self):
+        """Changes whenever torch code writes a filter or the arena (load_state_dict, copy_, fill_ ...): the magnitudes the optimiser kernel left are
+        trusted only while it is unchanged - the kernels themselves write through raw pointers and do not move it."""
+        return (self.p_flat._version, sum(e[0]._version for e in self._split_entries))
+
+    def _segments(self, a, b):
+        """Device table {first float, floats, amax record address or 0} covering arena range [a, b) (multiples of 4) with segments of at most 32768
+        floats, each inside one parameter; the filters of _split_entries carry their record (dsrl_sgd_step_dev_segments)."""
+        key = (a, b)
+        tab = self._seg_tables.get(key)
+        if tab is not None:
+            return tab
+        seg = int(HF.query('dsrl_conv2d_filters_amax_segment_floats'))
+        rec_of = {id(w): self.w_amax.data_ptr() + 4 * HF.AMAX_WORDS * i for i, (w, *_r) in enumerate(self._split_entries)}
+        rows = []
+        for p_, o in zip(self.params, self.offsets):
+            lo, hi = max(o, a), min(o + _align(p_.numel()), b)
+            rec = rec_of.get(id(p_), 0)
+            x = lo
+            while x < hi:
+                n = min(seg, hi - x)
+                rows.append([x, n, rec])
+                x += n
+        tab = self._seg_tables[key] = (torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows))
+        return tab
+
+    def _sgd_range(self, a, b, hyper, hp):
+        """SGD on arena range [a, b): with device-resident hyper-parameters and the f16 arithmetics, by the segment kernel that also measures the filters."""
+        if hyper is not None and self._fold_amax():
+            tab, n = self._segments(a, b)
+            HF.call('dsrl_sgd_step_dev_segments', self.p_flat.data_ptr(), self.g_flat.data_ptr(), self.m_flat.data_ptr(), tab.data_ptr(), n, hyper.data_ptr(), HF._stream())
+        elif hyper is not None:
+            HF.sgd_step_dev_(self.p_flat[a:b], self.g_flat[a:b], self.m_flat[a:b], hyper)
+        else:
+            HF.sgd_step_(self.p_flat[a:b], self.g_flat[a:b], self.m_flat[a:b], hp[0], hp[1], hp[2], 1.0 / self.world)
+
+    def ensure_filter_amax(self):
+        """In front of a REPLAYED step: a graph captured while the optimiser's magnitudes were valid contains no measuring sweep and relies on the
+        previous replay's optimiser pass.  If torch code wrote parameters since (a restored state, load_state_dict), measure eagerly once."""
+        if self._fold_amax() and self._amax_key != self._params_key():
+            self.w_amax.zero_()
+            HF.call('dsrl_conv2d_filters_amax_batched', self._amax_seg_table.data_ptr(), self._amax_segs, HF._stream())
+            self._amax_key = self._params_key()
+
+    def _fold_amax(self):
+        return (self.device.type == 'cuda' and self._wt_table is not None and HF.f16_mode() and os.environ.get('DSRL_PRESPLIT', '1') != '0' and
+                os.environ.get('DSRL_FILTER_AMAX_STREAM', '1') != '0' and os.environ.get('DSRL_SGD_AMAX', '1') != '0' and self._split_table is not None)
 
     def _build_plane_filters(self):
         """The filters whose convs take plane operands (channel counts multiples of 8), as fp16 planes, forward [K][R][S][C] and transposed
@@ -251,14 +302,17 @@ class FlatParams:
 
     def refresh_transposed_filters(self):
         if self._wt_table is not None and os.environ.get('DSRL_BATCHED_TRANSPOSE', '1') != '0':
-            self.w_amax.zero_()
             presplit = HF.f16_mode() and os.environ.get('DSRL_PRESPLIT', '1') != '0'
             if presplit and self._split_table is None:
                 self._build_split_filters()
             # with pre-split filters nothing reads the fp32 transposes: the first launch then only measures (amax records), the second writes both split forms
-            if presplit and os.environ.get('DSRL_FILTER_AMAX_STREAM', '1') != '0':
+            if presplit and self._amax_key is not None and self._amax_key == self._params_key() and self._fold_amax():
+                pass            # round 5: the optimiser pass of the previous step left max |w| of every filter it wrote (dsrl_sgd_step_dev_segments)
+            elif presplit and os.environ.get('DSRL_FILTER_AMAX_STREAM', '1') != '0':
+                self.w_amax.zero_()
                 HF.call('dsrl_conv2d_filters_amax_batched', self._amax_seg_table.data_ptr(), self._amax_segs, HF._stream())
             else:
+                self.w_amax.zero_()
                 HF.call('dsrl_conv2d_transpose_filters_batched', (self._amax_only_table if presplit else self._wt_table).data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
             if presplit:
                 HF.call('dsrl_conv2d_split_filters_batched', self._split_table.data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
@@ -365,13 +419,14 @@ class FlatParams:
         works = []
         if self.world > 1:
             works = [dist.all_reduce(self.g_flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for a, b in ranges]
+        fold = hyper is not None and self._fold_amax()
+        if fold:
+            self.w_amax.zero_()
         for i, (a, b) in enumerate(ranges):
             if works:
                 works[i].wait()             # stream-ordered for RCCL: the compute stream waits for this range only
-            if hyper is not None:
-                HF.sgd_step_dev_(self.p_flat[a:b], self.g_flat[a:b], self.m_flat[a:b], hyper)
-            else:
-                HF.sgd_step_(self.p_flat[a:b], self.g_flat[a:b], self.m_flat[a:b], hp[0], hp[1], hp[2], 1.0 / self.world)
+            self._sgd_range(a, b, hyper, hp)
+        self._amax_key = self._params_key() if fold else None
         self._pending = [0] * len(self.chunks)
         if self.device.type == 'cuda':
             HF.amax_end_step(self.device)
@@ -389,10 +444,11 @@ class FlatParams:
         three host values."""
         if reduce:
             self.finish_reduction()
-        if hyper is not None:
-            HF.sgd_step_dev_(self.p_flat, self.g_flat, self.m_flat, hyper)
-        else:
-            HF.sgd_step_(self.p_flat, self.g_flat, self.m_flat, lr, momentum, weight_decay, 1.0 / self.world)
+        fold = hyper is not None and self._fold_amax()
+        if fold:
+            self.w_amax.zero_()
+        self._sgd_range(0, self.numel, hyper, (lr, momentum, weight_decay))
+        self._amax_key = self._params_key() if fold else None
         if self.device.type == 'cuda':
             HF.amax_end_step(self.device)       # records asked for between steps (validation) come from the loose arena, not from the step's
         self.wt_valid = self.wt_fp32_valid = self.split_valid = self.planes_valid = False       # the filters changed: transposed / split copies and amax records are stale until the next refresh

@@ -392,6 +392,11 @@ int dsrl_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, flo
 /* the same update with {lr, momentum, weight_decay, grad_scale} read from four floats in device memory when the kernel runs: a launch
  * captured in a hipGraph follows the per-epoch LR schedule (train_or_resume.py:109-113, 349) without being re-captured */
 int dsrl_sgd_step_dev(float* p, const float* g, float* buf, int64_t n, const float* hyper /*device, 4 floats*/, dsrl_stream_t stream);
+/* the same update driven by a device table of nseg rows {first float, floats, address of an amax record or 0} (int64 each) that covers the arena with segments of
+ * whole float4 (first float a multiple of 4, count a multiple of 4, each segment inside ONE parameter; one block per segment, <= 32768 floats recommended): for
+ * rows with a record the launch also leaves max |p| of the UPDATED values there (same bit patterns as dsrl_conv2d_filters_amax_batched; the records must be zero
+ * when the launch starts) - the conv filters' operand magnitudes for the next step come out of the optimiser pass instead of a sweep of their own */
+int dsrl_sgd_step_dev_segments(float* p, const float* g, float* buf, const int64_t* table, int64_t nseg, const float* hyper /*device, 4 floats*/, dsrl_stream_t stream);
 /* flag[0] |= 1 if any element is NaN (the reference's per-output NaN asserts folded into one readback) */
 int dsrl_nan_check(const float* x, int64_t n, int* flag, dsrl_stream_t stream);
 

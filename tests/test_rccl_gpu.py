@@ -241,3 +241,32 @@ def test_failed_capture_falls_back_to_eager(monkeypatch):
             assert step.graph_replays == 0 and not step.use_graph
         step.release()
     assert res[False] == res[True], (res[False][-1], res[True][-1])
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_optimiser_pass_leaves_the_filter_magnitudes(graph, monkeypatch):
+    """Round 5: dsrl_sgd_step_dev_segments updates the arena segment by segment and leaves max |w| of every conv filter it wrote in the filter's amax record,
+    so the next step's filter pass starts with the split (DSRL_SGD_AMAX=0: the separate measuring sweep of rounds 3-4).  Same records bit for bit, hence the
+    same split filters, losses and parameters; torch code that writes parameters between two replays (here: a scaled arena) invalidates the optimiser's
+    magnitudes and the step measures again (ddp.FlatParams._params_key / ensure_filter_amax)."""
+    from dualsuperreslearningforsemseg_amd import functional as HF
+    res = {}
+    for fold in ('1', '0'):
+        monkeypatch.setenv('DSRL_SGD_AMAX', fold)
+        hist, flat, step = _make(1, graph, 0.006)
+        import dualsuperreslearningforsemseg_amd.command_handlers.train_or_resume as T
+        from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+        (img, org), (tgt, _) = next(iter(T.SyntheticCityscapes(2, (64, 128), torch.device(DEV), length=1)))
+        assert (flat._amax_key is not None) == (fold == '1')
+        with torch.no_grad():
+            flat.p_flat.mul_(1.5)               # an external write: every filter magnitude the optimiser left is stale now
+        more = [step(img, org, tgt, 0.006, 0.9, 0.0, True)[0] for _ in range(3)]
+        torch.cuda.synchronize()
+        assert np.isfinite(more[-1]).all()
+        flat.refresh_transposed_filters()       # fold: keeps the optimiser's records; else: measures the current weights - the same numbers
+        torch.cuda.synchronize()
+        res[fold] = (hist + more, flat.p_flat.clone(), flat.w_amax.clone(), flat.wsplit_flat.clone())
+        step.release()
+    assert res['1'][0] == res['0'][0], (res['1'][0][-1], res['0'][0][-1])
+    for a, b in zip(res['1'][1:], res['0'][1:]):
+        assert torch.equal(a, b)
