@@ -88,6 +88,7 @@ struct ConvArgs {
     // partial sums of g = dy * [y > 0] and g * xhat per (row block, channel) in bstats [2][parts][K] (null: off)
     const float* bn_x; const float* bn_y; const float* bn_mean; const float* bn_invstd; float* bstats;
     int bn_ldx, bn_ldy, bn_relu;
+    int bn_fast;                          // KG == 1 builds: the BatchNorm-backward sums through LDS with 16-byte loads of x / y (host: alignment, K % 4 == 0, no parity order)
     // split kernels, dgrad of a strided conv (par = stride > 1, else 0): the GEMM rows are ordered by parity class - M-tile t (pbm rows) holds
     // rows (t / par^2) * pbm ... of class (ph, pw) = t % par^2, a class row j being pixel (n, hh*par + ph, wh*par + pw), (n, hh, wh) = j over the
     // Hh x Wh grid of the class - so that all rows of a tile share the taps that divide evenly (a row-major tile multiplies zeros for the

@@ -1114,7 +1114,10 @@ static TileCfg pick_cfg_wgrad(int K, int C) {
     int forced = env_int("DSRL_FORCE_CFG", -1);
     if (forced < 0) forced = env_int("DSRL_WGRAD_CFG", -1);
     if (forced >= 0 && forced < kNumCfg4) return (TileCfg)forced;
-    const int big = env_int("DSRL_WGRAD_BIG_CFG", -1);          // experiment: this tile for layers with K >= 128 and C >= 128
+    // layers with K >= 128 and C >= 128 (the per-tap grid: 1x1, strided and dilated convs of layers 2-4 and ASPP): 128x128 tiles.  Round 4 measured +-1 % for
+    // them; with the 3x3 convs gone to conv_wgrad3_kernel the remaining 1x1 problems gain +0.5 .. 1.0 % step throughput on three boxes (profiles/round5_ab.txt):
+    // an activation chunk is fetched and split once per 128 output columns instead of 64.  DSRL_WGRAD_BIG_CFG=-1: 128x64 as before
+    const int big = env_int("DSRL_WGRAD_BIG_CFG", 0);
     if (big >= 0 && big < kNumCfg4 && K >= 128 && C >= 128) return (TileCfg)big;
     if (C <= 32) return T128x32;
     return K <= 64 ? T64x64 : T128x64;
@@ -1222,6 +1225,8 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
     a.mtiles = (int)ceil_div(a.M, bm); a.ntiles = (int)ceil_div(a.K, bn);
     make_magic(a.Ho * a.Wo, a.mHW, a.sHW); make_magic(a.Wo, a.mW, a.sW); make_magic(a.ntiles, a.mNT, a.sNT);
     a.xcd_remap = env_int("DSRL_XCD_REMAP", 1);
+    // the fast BatchNorm-sum epilogue of the one-group builds parks the block's fp32 tile in LDS (conv_split_kernel.h): fp16 arithmetics, tiles up to 256x128
+    if (a.bn_fast && !(DGRAD && conv_f16() && (size_t)bm * bn * 4 <= 128 * 1024)) a.bn_fast = 0;
     if (a.planes) return launch_planes_igemm(a, (int)cfg, DGRAD, st);          // both operands as fp16 planes, staged by LDS-DMA (conv_planes.hip)
     dim3 grid((unsigned)(a.mtiles * a.ntiles), 1u, (unsigned)a.splits);
     const int npl = conv_planes(DGRAD ? PASS_DGRAD : PASS_FWD);
@@ -1262,7 +1267,7 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
 #undef DSRL_LAUNCH_KG
             return launch_status("conv_igemm_split_kernel<K groups>");
         }
-        const size_t lds2 = stages;
+        const size_t lds2 = std::max(stages, a.bn_fast ? (size_t)bm * bn * 4 : (size_t)0);
         if (cfg == T256x128 || cfg == T256x256) {               // 8 waves; f16x3 with or without pre-split filters, and bf16x6
 #define DSRL_LAUNCH_BIG(a_, b_, c_, d_)                                                                                                   \
             {                                                                                                                              \
@@ -1677,7 +1682,11 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
         const long long Mc = (long long)N * (H / stride) * (W / stride);
         if (Mc % bm == 0) { a.par = stride; a.Hh = H / stride; a.Wh = W / stride; a.pbm = bm; }
     }
-    if (bn) { a.bn_x = bn->x; a.bn_y = bn->y; a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bstats = bn->stats; a.bn_ldx = bn->ldx; a.bn_ldy = bn->ldy; a.bn_relu = bn->relu; }
+    if (bn) {
+        a.bn_x = bn->x; a.bn_y = bn->y; a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bstats = bn->stats; a.bn_ldx = bn->ldx; a.bn_ldy = bn->ldy; a.bn_relu = bn->relu;
+        a.bn_fast = a.par == 0 && C % 4 == 0 && bn->ldx % 4 == 0 && (!bn->relu || bn->ldy % 4 == 0) && ((uintptr_t)bn->x % 16) == 0 && (!bn->relu || ((uintptr_t)bn->y % 16) == 0) &&
+                    ((uintptr_t)bn->mean % 16) == 0 && ((uintptr_t)bn->invstd % 16) == 0 && ((uintptr_t)bn->stats % 16) == 0 && env_int("DSRL_BNSTATS_FAST", 1);
+    }
     return launch_igemm<true>(a, p.cfg, st);
 }
 

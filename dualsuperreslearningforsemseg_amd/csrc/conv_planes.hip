@@ -384,7 +384,69 @@ void conv_planes_kernel(const ConvArgs a) {
             }
         }
     }
-    if (DGRAD && a.bstats != nullptr && a.splits == 1) {
+    bool bstats_done = false;
+    if constexpr (DGRAD && KG == 1) {
+        if (a.bstats != nullptr && (a.splits == 1) && a.bn_fast) {
+            // Round 5: the same sums with 16-byte accesses (the code of conv_split_kernel.h: same order, bit-identical partials).  The accumulator layout (lane = column, register = row) forces one 4-byte load per element of x
+            // and y - 64 (128x64 tile) or 128 (128x128) dependent-ish loads per lane, 11-17 us behind the K loop of the wide 1x1 data gradients.  Here a wave
+            // parks its 32 MR x 32 NR tile in LDS (wave-private region of the idle stages, row-major), reads it back as float4 rows, and meets x / y with
+            // float4 loads: a quarter of the memory instructions, rows of 128 contiguous bytes per 8 lanes.  Host side: K % 4 == 0, strides multiples of 4,
+            // 16-byte aligned tensors, stride-1 launch (no parity order).  Same partials layout [2][mtiles * WGM][K]; summation order differs from the path below.
+            constexpr int TR = 32 * MR, TC = 32 * NR, CQ = TC / 4, RSTEP = 64 / CQ, NIT = TR / RSTEP, NB = NIT < 8 ? NIT : 8;
+            float* wt = reinterpret_cast<float*>(smem) + (size_t)wave * TR * TC;
+            __syncthreads();                                            // every wave is done with the LDS stages
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        wt[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * TC + j * 32 + (lane & 31)] = acc[i][j][e];
+            const int c4 = lane % CQ, r0_ = lane / CQ;
+            const int kk = n0 + wn * TC + 4 * c4;
+            const bool kok4 = kk < a.K;
+            const float4 mu4 = kok4 ? *reinterpret_cast<const float4*>(a.bn_mean + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 is4 = kok4 ? *reinterpret_cast<const float4*>(a.bn_invstd + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
+            const int mrow0 = m0 + wm * TR;
+#pragma unroll
+            for (int b0 = 0; b0 < NIT; b0 += NB) {
+                float4 xv[NB], yv[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int m = mrow0 + r0_ + RSTEP * (b0 + u);
+                    const bool ok = kok4 && m < a.M;
+                    xv[u] = ok ? *reinterpret_cast<const float4*>(a.bn_x + (long long)m * a.bn_ldx + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    yv[u] = (ok && a.bn_relu) ? *reinterpret_cast<const float4*>(a.bn_y + (long long)m * a.bn_ldy + kk) : make_float4(1.f, 1.f, 1.f, 1.f);
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int row = r0_ + RSTEP * (b0 + u);
+                    if (kok4 && mrow0 + row < a.M) {
+                        const float4 gv = *reinterpret_cast<const float4*>(wt + row * TC + 4 * c4);
+                        const float g0 = (a.bn_relu && !(yv[u].x > 0.f)) ? 0.f : gv.x, g1 = (a.bn_relu && !(yv[u].y > 0.f)) ? 0.f : gv.y;
+                        const float g2 = (a.bn_relu && !(yv[u].z > 0.f)) ? 0.f : gv.z, g3 = (a.bn_relu && !(yv[u].w > 0.f)) ? 0.f : gv.w;
+                        sg[0] += g0; sgx[0] += g0 * ((xv[u].x - mu4.x) * is4.x);
+                        sg[1] += g1; sgx[1] += g1 * ((xv[u].y - mu4.y) * is4.y);
+                        sg[2] += g2; sgx[2] += g2 * ((xv[u].z - mu4.z) * is4.z);
+                        sg[3] += g3; sgx[3] += g3 * ((xv[u].w - mu4.w) * is4.w);
+                    }
+                }
+            }
+#pragma unroll
+            for (int sft = CQ; sft < 64; sft <<= 1)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { sg[q] += __shfl_xor(sg[q], sft); sgx[q] += __shfl_xor(sgx[q], sft); }
+            if (lane < CQ && kok4) {
+                const int nparts = a.mtiles * WGM, part = tile_m * WGM + wm;
+                float* o = a.bstats + (long long)part * a.K + kk;
+                *reinterpret_cast<float4*>(o) = make_float4(sg[0], sg[1], sg[2], sg[3]);
+                *reinterpret_cast<float4*>(o + (long long)nparts * a.K) = make_float4(sgx[0], sgx[1], sgx[2], sgx[3]);
+            }
+            bstats_done = true;
+        }
+    }
+    if (DGRAD && a.bstats != nullptr && a.splits == 1 && !bstats_done) {
         // BatchNorm-backward partials of the gradient tile just written: sum(g), sum(g * xhat) per channel over the wave's 32*MR rows
         // (layout [2][mtiles * WGM][K], dsrl_bn_bwd_from_stats); K groups: shares meet in LDS, group 0 adds them in the order g = 0 .. KG-1
         const int nparts = a.mtiles * WGM, part = tile_m * WGM + wm;
@@ -580,7 +642,9 @@ __global__ __launch_bounds__(256) void filter_planes_batched_kernel(const long l
         constexpr int threads = 64 * WGM_ * WGN_ * KG_;                                                                                     \
         constexpr size_t slot = (size_t)(32 * MR_ * WGM_ + 32 * NR_ * WGN_) * 2 * 64;                                                      \
         constexpr size_t redb = KG_ > 1 ? (size_t)KG_ * MR_ * NR_ * 4 * (threads / KG_) * 16 + 8192 : 0;                                    \
-        constexpr size_t lds = slot * R_ * KG_ > redb ? slot * R_ * KG_ : redb;                                                             \
+        constexpr size_t tileb = (KG_ == 1 && DGRAD) ? (size_t)(32 * MR_ * WGM_) * (32 * NR_ * WGN_) * 4 : 0;      /* fast BatchNorm-sum epilogue: the fp32 tile */ \
+        constexpr size_t lds0 = slot * R_ * KG_ > redb ? slot * R_ * KG_ : redb;                                                            \
+        constexpr size_t lds = (tileb > lds0 && tileb <= 160 * 1024) ? tileb : lds0;                                                        \
         static_assert(lds <= 160 * 1024, "LDS");                                                                                            \
         static const hipError_t attr = hipFuncSetAttribute((const void*)conv_planes_kernel<MR_, NR_, WGM_, WGN_, KG_, 2, DGRAD, R_>,         \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \

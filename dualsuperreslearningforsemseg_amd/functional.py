@@ -649,8 +649,10 @@ class GradSlot:
 # then runs as one streaming kernel (dsrl_bn_bwd_from_stats).  A BNLink carries what the conv needs from the BN's forward and the
 # partials back; the BN only trusts them if the gradient it receives is the very buffer that conv wrote.
 bn_bwd_stats_enabled = os.environ.get('DSRL_BN_BWD_STATS', '1') != '0'
-# the same for bn3 via the next block's accumulating dgrad: correct, but measured slower (wide 4x-channel epilogues): off by default
-bn_bwd_stats_shared = os.environ.get('DSRL_BN_BWD_STATS_SHARED', '0') != '0'
+# the same for bn3 via the next block's accumulating dgrad.  Rounds 3-4: correct but slower (the wide 1x1 data gradients spent 11-17 us in an epilogue of
+# 4-byte loads of x / y).  Round 5: on since that epilogue reads float4 rows through LDS (conv_split_kernel.h, bn_fast): +0.65 % step throughput, 29 of the 45
+# device-wide-barrier BatchNorm launches become streaming from-sums launches (profiles/round5_ab.txt)
+bn_bwd_stats_shared = os.environ.get('DSRL_BN_BWD_STATS_SHARED', '1') != '0'
 
 
 class BNLink:

@@ -50,6 +50,18 @@ def _make(world_claim, graph, lr):
 def test_rccl_reduction_paths_match_half_lr_single_process():
     import torch.distributed as dist
     from dualsuperreslearningforsemseg_amd import ddp, functional as HF
+    # This test compares SCHEDULES (hook-launched chunks, one graph + chunked exchange, two graphs) through 7-step trajectories, which needs every run to
+    # form the same sums in the same order: a random-init batch-2 net amplifies a last-bit difference to 1e-3 within two steps (round 5: measured).  bn3's
+    # backward sums from the next block's accumulating dgrad (default since round 5) are one such difference - the block in front of the two-graph cut has no
+    # "next block" inside its graph and takes the barrier kernel instead - so they are off here; the default setting is covered by the graph == eager tests.
+    shared_was, HF.bn_bwd_stats_shared = HF.bn_bwd_stats_shared, False
+    try:
+        _reduction_paths_body(dist, ddp, HF)
+    finally:
+        HF.bn_bwd_stats_shared = shared_was
+
+
+def _reduction_paths_body(dist, ddp, HF):
     # two single-process references at half the learning rate: with the grouped weight-gradient launches (what the graph paths run) and with
     # the per-layer side-stream launches (what the eager N > 1 path runs, so that its chunk all-reduces start during backward: ddp.FlatParams.zero_grad)
     plains = {}
@@ -257,7 +269,7 @@ def test_optimiser_pass_leaves_the_filter_magnitudes(graph, monkeypatch):
         import dualsuperreslearningforsemseg_amd.command_handlers.train_or_resume as T
         from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
         (img, org), (tgt, _) = next(iter(T.SyntheticCityscapes(2, (64, 128), torch.device(DEV), length=1)))
-        assert (flat._amax_key is not None) == (fold == '1')
+        assert (flat._amax_key is not None) == (fold == '1' and graph)      # eager launches take host hyper-parameters (dsrl_sgd_step): no segments, the step measures
         with torch.no_grad():
             flat.p_flat.mul_(1.5)               # an external write: every filter magnitude the optimiser left is stale now
         more = [step(img, org, tgt, 0.006, 0.9, 0.0, True)[0] for _ in range(3)]
@@ -265,7 +277,8 @@ def test_optimiser_pass_leaves_the_filter_magnitudes(graph, monkeypatch):
         assert np.isfinite(more[-1]).all()
         flat.refresh_transposed_filters()       # fold: keeps the optimiser's records; else: measures the current weights - the same numbers
         torch.cuda.synchronize()
-        res[fold] = (hist + more, flat.p_flat.clone(), flat.w_amax.clone(), flat.wsplit_flat.clone())
+        # a record = 16 shards (which shard a block maxes into depends on its block index): the magnitude is the maximum over the shards
+        res[fold] = (hist + more, flat.p_flat.clone(), flat.w_amax.view(-1, 16, 16)[:, :, 0].max(dim=1).values.clone(), flat.wsplit_flat.clone())
         step.release()
     assert res['1'][0] == res['0'][0], (res['1'][0][-1], res['0'][0][-1])
     for a, b in zip(res['1'][1:], res['0'][1:]):
