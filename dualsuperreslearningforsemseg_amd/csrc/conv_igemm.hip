@@ -1290,7 +1290,13 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
                     set_error("conv_igemm_split_kernel: the 8-wave tiles exist for the f16x3 arithmetic only"); return DSRL_E_UNSUPPORTED;   \
                 }                                                                                                                          \
             }
-            if (cfg == T256x128) DSRL_LAUNCH_BIG(2, 2, 4, 2) else DSRL_LAUNCH_BIG(4, 2, 2, 4)
+            if (cfg == T256x128) DSRL_LAUNCH_BIG(2, 2, 4, 2)
+            else {
+                // 256x256, register-staged: the data-gradient builds needed 76-88 spilled registers and the planner never picked them (rule d takes 256x128
+                // for dgrad): removed in round 5.  The forward build (73 spills with two planes) stays for launches whose operands arrive without planes.
+                if constexpr (DGRAD) { set_error("conv_igemm_split_kernel: no 256x256 data-gradient build (256x128 is the 8-wave dgrad tile)"); return DSRL_E_UNSUPPORTED; }
+                else DSRL_LAUNCH_BIG(4, 2, 2, 4)
+            }
 #undef DSRL_LAUNCH_BIG
             return launch_status("conv_igemm_split_kernel<f16x3, 8 waves>");
         }
@@ -1371,7 +1377,11 @@ static void pick_split_plan(long long M, int N, int nq, bool dgrad, TileCfg& cfg
     const bool forced = env_int("DSRL_FORCE_CFG", -1) >= 0 || env_int("DSRL_FORCE_SPLITS", 0) > 0 || env_int("DSRL_FORCE_KG", 0) > 0;
     if (forced || N <= 32 || !env_int("DSRL_SPLIT_PLAN", 1)) return;
     if (conv_precision_mode() >= 4 && env_int("DSRL_BIG_TILES", 1) && N >= 192 && nq >= 32) {                                         // d)
-        if (!dgrad && cfg_blocks(T256x256, M, N) >= kNumCU) { cfg = T256x256; splits = 1; kg = 1; return; }
+        // 256x256 forward: the LDS-DMA kernel's tile (251 registers, no scratch).  The register-staged two-plane build of that tile spills, so with planes
+        // switched off altogether (DSRL_PLANES=0, set by functional when DSRL_PLANES_MODE=off) the f16x3 forward takes 256x128 like dgrad; f16x1 (one plane) fits
+        const bool t256 = conv_precision_mode() == 5 || env_int("DSRL_PLANES", 1) != 0;
+        if (!dgrad && t256 && cfg_blocks(T256x256, M, N) >= kNumCU) { cfg = T256x256; splits = 1; kg = 1; return; }
+        if (!dgrad && !t256 && cfg_blocks(T256x128, M, N) >= 2 * kNumCU) { cfg = T256x128; splits = 1; kg = 1; return; }
         if (dgrad && cfg_blocks(T256x128, M, N) >= 2 * kNumCU) { cfg = T256x128; splits = 1; kg = 1; return; }
         if (!dgrad && nq >= 256 && cfg_blocks(T256x128, M, N) * 8 >= kNumCU && cfg_blocks(T128x128, M, N) < kNumCU) { cfg = T256x128; splits = 8; kg = 1; return; }
     }
@@ -1739,9 +1749,10 @@ static void launch_wgrad(const WgradArgs& a_in, TileCfg cfg, int bm, int bn, dim
                 hipLaunchKernelGGL((conv_wgrad_split_kernel<a_, b_, c_, d_, NPL_, KG_, F16_>), grid, dim3(256 * KG_), lds, st, a);   \
             }
 #define DSRL_WKG_BY_NPL(a_, b_, c_, d_, KG_) { if (f16 && npl == 1) DSRL_LAUNCH_WKG(a_, b_, c_, d_, 1, KG_, true) else if (f16) DSRL_LAUNCH_WKG(a_, b_, c_, d_, 2, KG_, true) else if (npl == 2) DSRL_LAUNCH_WKG(a_, b_, c_, d_, 2, KG_, false) else DSRL_LAUNCH_WKG(a_, b_, c_, d_, 3, KG_, false) }
-            if (cfg == T64x64) { if (kg == 4) DSRL_WKG_BY_NPL(1, 1, 2, 2, 4) else DSRL_WKG_BY_NPL(1, 1, 2, 2, 2) }
-            else if (cfg == T128x64) { if (kg == 4) DSRL_WKG_BY_NPL(2, 1, 2, 2, 4) else DSRL_WKG_BY_NPL(2, 1, 2, 2, 2) }
-            else if (cfg == T64x128) { if (kg == 4) DSRL_WKG_BY_NPL(1, 2, 2, 2, 4) else DSRL_WKG_BY_NPL(1, 2, 2, 2, 2) }
+            // two pixel groups only: the four-group builds always lost (tools/wgrad_kg.py) and spilled 8-12 registers; removed in round 5
+            if (cfg == T64x64) DSRL_WKG_BY_NPL(1, 1, 2, 2, 2)
+            else if (cfg == T128x64) DSRL_WKG_BY_NPL(2, 1, 2, 2, 2)
+            else if (cfg == T64x128) DSRL_WKG_BY_NPL(1, 2, 2, 2, 2)
             else DSRL_WKG_BY_NPL(2, 2, 2, 2, 2)
 #undef DSRL_WKG_BY_NPL
 #undef DSRL_LAUNCH_WKG
@@ -1859,7 +1870,7 @@ static int wgrad_impl(const float* x, int ldx, const float* dy, int lddy, float*
     int psplits = p.psplits, kg = 1;
     if (conv_planes(PASS_WGRAD) && env_int("DSRL_WGRAD_KG", 1)) {
         const int npl = conv_planes(PASS_WGRAD);
-        const int maxkg = (p.cfg == T64x64 || p.cfg == T128x64 || p.cfg == T64x128) ? 4 : (p.cfg == T128x128 ? 2 : 1);
+        const int maxkg = (p.cfg == T64x64 || p.cfg == T128x64 || p.cfg == T64x128 || p.cfg == T128x128) ? 2 : 1;
         const int forced = env_int("DSRL_FORCE_WGRAD_KG", 0);
         kg = forced > 0 ? std::min(forced, maxkg) : ((RS == 1 && psplits >= 4) ? std::min(2, maxkg) : 1);
         if (kg == 3) kg = 2;

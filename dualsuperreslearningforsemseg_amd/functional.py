@@ -512,6 +512,8 @@ def planes_of(data, ld, amax, nplanes=2):
 # operands; a split launch costs ~6 us on the small ones, more than the planes kernel gains there) - producers that write planes beside their
 # fp32 output are used in every mode but 'off'
 planes_mode = os.environ.get('DSRL_PLANES_MODE', 'auto')
+if planes_mode == 'off':
+    os.environ.setdefault('DSRL_PLANES', '0')       # the library's planner then keeps the f16x3 forward off the 256x256 tile, whose register-staged build spills
 planes_min_elems = int(os.environ.get('DSRL_PLANES_MIN_ELEMS', str(8 << 20)))
 
 

@@ -170,3 +170,31 @@ def test_lds_dma_inline_asm_is_the_only_m0_user(tmp_path):
     assert len(users) > 100                                   # the DMA pieces are there
     odd = [u for u in users if not (u[0] == 's_mov_b32' and u[1] == 'm0,' and re.fullmatch(r's\d+', u[2]))]
     assert not odd, odd[:5]
+
+
+def test_no_new_register_spills():
+    """Scratch (spilled registers, private arrays) in a kernel of the library is a decision, not an accident: every kernel of the in-tree objects that needs
+    scratch must be on this list, with where it can still run (round 5 removed the 256x256 data-gradient and the four-group
+    weight-gradient builds, which the planner never picked)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import kernel_resources as KR
+    if not os.path.isfile(os.path.join(KR.LLVM, 'llvm-objdump')):
+        pytest.skip('needs llvm-objdump')
+    allowed = [
+        r'conv_igemm_split_kernel<4, 2, 2, 4, false, 2, 1, [12], false, false>',      # 256x256 forward, register-staged, two planes: only when a decoder-size conv arrives without planes
+        r'conv_igemm_f32_kernel<2, 2, 2, 2, (true|false), 4, false>',                  # exact-fp32 mode, <= 128-register build that keeps 4 blocks per CU (a measured win in that mode)
+        r'convt2x2_bwd_fused_kernel<(19, 19|8, 8)>',                                   # VALU fallback of the ConvTranspose backward (W % 4 != 0 or DSRL_CONVT_MFMA=0)
+    ]
+    csrc = os.path.join(ROOT, 'dualsuperreslearningforsemseg_amd', 'csrc')
+    objs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith('.o')]
+    if not objs:
+        pytest.skip('no in-tree objects (run __graft_entry__.build() first)')
+    bad = []
+    for o in objs:
+        ks = KR.kernels(o)
+        names = KR.demangle([k['name'] for k in ks])
+        for k, n in zip(ks, names):
+            if (k.get('scratch', 0) or k.get('vgpr_spill', 0)) and not any(re.search(a, n) for a in allowed):
+                bad.append((os.path.basename(o), n[:120], k.get('scratch', 0), k.get('vgpr_spill', 0)))
+    assert not bad, bad

@@ -20,7 +20,7 @@ def kernels(path):
         subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '--offloading', local], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp)
         dev = [p for p in os.listdir(tmp) if 'gfx950' in p]
         if not dev:
-            raise RuntimeError(f'no gfx950 code object in {path}')
+            return []               # host-only object (runtime.hip has no kernels)
         out = []
         for d in dev:
             notes = subprocess.run([os.path.join(LLVM, 'llvm-readelf'), '--notes', os.path.join(tmp, d)], check=True, capture_output=True, text=True).stdout
