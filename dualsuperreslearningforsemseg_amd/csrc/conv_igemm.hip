@@ -1506,10 +1506,11 @@ static int fwd_impl(const float* x, int ldx, const float* w, const float* bias, 
         }
         // both operands as fp16 planes carrying the scales of THESE records (dsrl_split_planes / dsrl_conv2d_filter_planes_batched): same tile plan,
         // same summation order, staged by LDS-DMA
-        if (conv_f16x3() && x_planes != nullptr && w_planes != nullptr && x_amax != nullptr && w_amax != nullptr && planes_usable(C, ldx, x_planes, w_planes) &&
+        // (round 5) f16x1 takes ONE plane per operand - the operand of a half-precision STORAGE format: fp16 activations at their tensor's scale
+        if (x_planes != nullptr && w_planes != nullptr && x_amax != nullptr && w_amax != nullptr && planes_usable(C, ldx, x_planes, w_planes) &&
             planes_cfg_supported((int)p.cfg, p.kg)) {
             const long long pe = (long long)N * H * W * ldx, we = (long long)K * R * S * C;
-            a.planes = 1; a.w_split = 0;
+            a.planes = conv_planes(PASS_FWD); a.w_split = 0;
             a.x = (const float*)x_planes; a.w = (const float*)w_planes;
             a.x_bytes = (unsigned)(span_bytes((long long)N * H * W, ldx, C) / 2); a.w_bytes = (unsigned)(we * 2);
             a.a_lo = (unsigned)planes_lo_offset(pe); a.b_lo = (unsigned)planes_lo_offset(we);
@@ -1636,7 +1637,7 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
     DSRL_REQUIRE(ws && ws_bytes >= wtb + p.ws, DSRL_E_WORKSPACE, "conv2d_dgrad: workspace %zu < %zu", ws_bytes, wtb + p.ws);
     const float* wt = wt_in;
     float* slabs = (float*)((char*)ws + wtb);
-    const bool use_planes = conv_f16x3() && dy_planes != nullptr && wt_planes != nullptr && dy_amax != nullptr && w_amax != nullptr && stride == 1 && K % 8 == 0 &&
+    const bool use_planes = conv_f16() && dy_planes != nullptr && wt_planes != nullptr && dy_amax != nullptr && w_amax != nullptr && stride == 1 && K % 8 == 0 &&
                             planes_usable(K, lddy, dy_planes, wt_planes) && planes_cfg_supported((int)p.cfg, p.kg);
     const bool use_split = conv_f16() && wt_split != nullptr && w_amax != nullptr && env_int("DSRL_PRESPLIT", 1);
     if (wt == nullptr && use_planes) wt = (const float*)wt_planes;       // replaced below; no fp32 transpose is built for it
@@ -1665,7 +1666,7 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
         }
         if (use_planes) {
             const long long pe = (long long)N * Ho * Wo * lddy, we = (long long)C * R * S * K;
-            a.planes = 1; a.w_split = 0;
+            a.planes = conv_planes(PASS_DGRAD); a.w_split = 0;
             a.x = (const float*)dy_planes; a.w = (const float*)wt_planes;
             a.x_bytes = (unsigned)(span_bytes((long long)N * Ho * Wo, lddy, K) / 2); a.w_bytes = (unsigned)(we * 2);
             a.a_lo = (unsigned)planes_lo_offset(pe); a.b_lo = (unsigned)planes_lo_offset(we);

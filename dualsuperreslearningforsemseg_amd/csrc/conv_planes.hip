@@ -637,21 +637,24 @@ __global__ __launch_bounds__(256) void filter_planes_batched_kernel(const long l
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-#define DSRL_PLANES_LAUNCH(MR_, NR_, WGM_, WGN_, KG_, R_)                                                                                   \
+// R_: ring depth with two planes (f16x3); with ONE plane (f16x1: a.planes == 1) a slot is half as large and the ring takes R1_ slots
+#define DSRL_PLANES_LAUNCH_N(MR_, NR_, WGM_, WGN_, KG_, NPL_, R_)                                                                          \
     {                                                                                                                                       \
         constexpr int threads = 64 * WGM_ * WGN_ * KG_;                                                                                     \
-        constexpr size_t slot = (size_t)(32 * MR_ * WGM_ + 32 * NR_ * WGN_) * 2 * 64;                                                      \
+        constexpr size_t slot = (size_t)(32 * MR_ * WGM_ + 32 * NR_ * WGN_) * NPL_ * 64;                                                   \
         constexpr size_t redb = KG_ > 1 ? (size_t)KG_ * MR_ * NR_ * 4 * (threads / KG_) * 16 + 8192 : 0;                                    \
         constexpr size_t tileb = (KG_ == 1 && DGRAD) ? (size_t)(32 * MR_ * WGM_) * (32 * NR_ * WGN_) * 4 : 0;      /* fast BatchNorm-sum epilogue: the fp32 tile */ \
         constexpr size_t lds0 = slot * R_ * KG_ > redb ? slot * R_ * KG_ : redb;                                                            \
         constexpr size_t lds = (tileb > lds0 && tileb <= 160 * 1024) ? tileb : lds0;                                                        \
         static_assert(lds <= 160 * 1024, "LDS");                                                                                            \
-        static const hipError_t attr = hipFuncSetAttribute((const void*)conv_planes_kernel<MR_, NR_, WGM_, WGN_, KG_, 2, DGRAD, R_>,         \
+        static const hipError_t attr = hipFuncSetAttribute((const void*)conv_planes_kernel<MR_, NR_, WGM_, WGN_, KG_, NPL_, DGRAD, R_>,      \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         (void)attr;                                                                                                                         \
-        hipLaunchKernelGGL((conv_planes_kernel<MR_, NR_, WGM_, WGN_, KG_, 2, DGRAD, R_>), grid, dim3(threads), lds, st, a);                  \
+        hipLaunchKernelGGL((conv_planes_kernel<MR_, NR_, WGM_, WGN_, KG_, NPL_, DGRAD, R_>), grid, dim3(threads), lds, st, a);               \
         return launch_status("conv_planes_kernel");                                                                                         \
     }
+#define DSRL_PLANES_LAUNCH2(MR_, NR_, WGM_, WGN_, KG_, R_, R1_) { if (a.planes == 1) DSRL_PLANES_LAUNCH_N(MR_, NR_, WGM_, WGN_, KG_, 1, R1_) else DSRL_PLANES_LAUNCH_N(MR_, NR_, WGM_, WGN_, KG_, 2, R_) }
+#define DSRL_PLANES_LAUNCH(MR_, NR_, WGM_, WGN_, KG_, R_) DSRL_PLANES_LAUNCH2(MR_, NR_, WGM_, WGN_, KG_, R_, R_)
 
 // cfg: enum TileCfg of conv_igemm.hip {T128x128, T256x64, T256x32, T64x64, T128x64, T64x128, T128x32, T256x128, T256x256}
 template <bool DGRAD>
@@ -690,7 +693,7 @@ static int launch_planes_t(const ConvArgs& a, int cfg, hipStream_t st) {
                 }
             }
 #endif
-            if (kg == 4) DSRL_PLANES_LAUNCH(1, 1, 2, 2, 4, 2)
+            if (kg == 4) DSRL_PLANES_LAUNCH2(1, 1, 2, 2, 4, 2, 4)
             if (kg == 2) { if (r == 2) DSRL_PLANES_LAUNCH(1, 1, 2, 2, 2, 2) else if (r == 3) DSRL_PLANES_LAUNCH(1, 1, 2, 2, 2, 3) else DSRL_PLANES_LAUNCH(1, 1, 2, 2, 2, 4) }
             if (r == 2) DSRL_PLANES_LAUNCH(1, 1, 2, 2, 1, 2) else DSRL_PLANES_LAUNCH(1, 1, 2, 2, 1, 3)
         case 4:     // 128x64
@@ -702,7 +705,7 @@ static int launch_planes_t(const ConvArgs& a, int cfg, hipStream_t st) {
             if (kg == 1) { if (r == 2) DSRL_PLANES_LAUNCH(1, 2, 2, 2, 1, 2) else DSRL_PLANES_LAUNCH(1, 2, 2, 2, 1, 3) }
             break;
         case 0:     // 128x128
-            if (kg == 1) { if (r == 3) DSRL_PLANES_LAUNCH(2, 2, 2, 2, 1, 3) else DSRL_PLANES_LAUNCH(2, 2, 2, 2, 1, 2) }
+            if (kg == 1) { if (r == 3) DSRL_PLANES_LAUNCH(2, 2, 2, 2, 1, 3) else DSRL_PLANES_LAUNCH2(2, 2, 2, 2, 1, 2, 4) }
             break;
         case 1:     // 256x64
             if (kg == 1) { if (r == 3) DSRL_PLANES_LAUNCH(2, 2, 4, 1, 1, 3) else DSRL_PLANES_LAUNCH(2, 2, 4, 1, 1, 2) }
@@ -711,7 +714,7 @@ static int launch_planes_t(const ConvArgs& a, int cfg, hipStream_t st) {
             if (kg == 1) { if (r == 2) DSRL_PLANES_LAUNCH(2, 2, 4, 2, 1, 2) else DSRL_PLANES_LAUNCH(2, 2, 4, 2, 1, 3) }
             break;
         case 8:     // 256x256, 8 waves
-            if (kg == 1) DSRL_PLANES_LAUNCH(4, 2, 2, 4, 1, 2)
+            if (kg == 1) DSRL_PLANES_LAUNCH2(4, 2, 2, 4, 1, 2, 3)
             break;
         default: break;
     }
@@ -719,6 +722,8 @@ static int launch_planes_t(const ConvArgs& a, int cfg, hipStream_t st) {
     return DSRL_E_UNSUPPORTED;
 }
 #undef DSRL_PLANES_LAUNCH
+#undef DSRL_PLANES_LAUNCH2
+#undef DSRL_PLANES_LAUNCH_N
 
 bool planes_cfg_supported(int cfg, int kg) {
     switch (cfg) {

@@ -316,7 +316,7 @@ class FlatParams:
                 HF.call('dsrl_conv2d_transpose_filters_batched', (self._amax_only_table if presplit else self._wt_table).data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
             if presplit:
                 HF.call('dsrl_conv2d_split_filters_batched', self._split_table.data_ptr(), self._wt_rows, self._wt_tiles, HF._stream())
-            planes = presplit and HF.planes_mode != 'off' and HF.get_conv_precision() == 'f16x3'
+            planes = presplit and HF.planes_mode != 'off' and HF.get_conv_precision() in ('f16x3', 'f16x1')      # f16x1 reads the first plane only
             if planes:
                 if HF.graph_keepalive is None and self._planes_pending():
                     self._build_plane_filters()         # first use, or more filters asked for planes since the last set was built (never inside a capture)

@@ -515,34 +515,46 @@ planes_mode = os.environ.get('DSRL_PLANES_MODE', 'auto')
 if planes_mode == 'off':
     os.environ.setdefault('DSRL_PLANES', '0')       # the library's planner then keeps the f16x3 forward off the 256x256 tile, whose register-staged build spills
 planes_min_elems = int(os.environ.get('DSRL_PLANES_MIN_ELEMS', str(8 << 20)))
+# Round 5: the reduced-precision 'f16x1' arithmetic (apex O1 / O2) takes ONE plane per operand - the conv a 2-byte storage format would run.  A one-plane split
+# pass moves 6 instead of 8 bytes per element and the conv gains more (tools/fp16_slice.py at config 5's shapes: cat_conv.0 forward 593 -> 406 us, dgrad
+# 772 -> 547 us; layer3 3x3 48 -> 35 us), so the pass pays from 2 Mi elements on, and for the data gradients of the >= 8 Mi-element operands as well.
+planes_min_elems_x1 = int(os.environ.get('DSRL_PLANES_MIN_ELEMS_X1', str(2 << 20)))
+
+
+def _planes_npl():
+    """planes per operand of the current arithmetic: 2 (f16x3), 1 (f16x1), 0 (no plane operands)"""
+    return {4: 2, 5: 1}.get(_conv_precision_code(), 0)
 
 
 def planes_wanted(data, ld, C, K, taps=9):
     """Would a conv with this activation operand take planes if its filter had them? (planes_mode 'auto' / 'all'; both channel counts multiples of 8;
     'auto': long K loops over large operands only - the 3x3 decoder convs)"""
-    if planes_mode == 'off' or _conv_precision_code() != 4 or C % 8 or K % 8 or ld % 8 or data.data_ptr() % 16:
+    npl = _planes_npl()
+    if planes_mode == 'off' or not npl or C % 8 or K % 8 or ld % 8 or data.data_ptr() % 16:
         return False
     N, Cc, H, W = data.shape
-    return planes_mode == 'all' or (N * H * W * Cc >= planes_min_elems and taps >= 9)
+    return planes_mode == 'all' or (N * H * W * Cc >= (planes_min_elems if npl == 2 else planes_min_elems_x1) and taps >= 9)
 
 
 def planes_for(t, data, ld, amax, taps=9, split_ok=True):
     """fp16 planes of operand tensor `t` (pixel-major copy `data`, pixel stride ld) scaled by ITS record `amax`, or None: the planes the tensor
     carries (left by its producer or by an earlier consumer of the same tensor in this step), else a split pass when planes_mode allows one."""
-    if planes_mode == 'off' or amax is None or _conv_precision_code() != 4:
+    npl = _planes_npl()
+    if planes_mode == 'off' or amax is None or not npl:
         return None
     gen = getattr(amax, '_dsrl_gen', -1)          # a step-arena record is re-issued (same address) by the next step: its generation is part of the key
     have = getattr(t, '_dsrl_planes', None)
-    if have is not None and have[1] == ld and have[2] == amax.data_ptr() and have[3] == data.data_ptr() and have[4] == t._version and have[5] == gen:
+    if (have is not None and have[1] == ld and have[2] == amax.data_ptr() and have[3] == data.data_ptr() and have[4] == t._version and have[5] == gen and
+            have[6] >= npl):
         return have[0]
     N, Cc, H, W = data.shape
     if Cc % 8 or ld % 8 or data.data_ptr() % 16:
         return None
-    if planes_mode != 'all' and (N * H * W * Cc < planes_min_elems or taps < 9 or not split_ok):
+    if planes_mode != 'all' and (N * H * W * Cc < (planes_min_elems if npl == 2 else planes_min_elems_x1) or taps < 9 or not split_ok):
         return None
-    buf = planes_of(data, ld, amax)
+    buf = planes_of(data, ld, amax, npl)
     try:
-        t._dsrl_planes = (buf, ld, amax.data_ptr(), data.data_ptr(), t._version, gen)
+        t._dsrl_planes = (buf, ld, amax.data_ptr(), data.data_ptr(), t._version, gen, npl)
         _planes_holders.append(weakref.ref(t))
     except Exception:           # noqa: BLE001
         pass
@@ -769,7 +781,9 @@ class _Conv2d(torch.autograd.Function):
         wtsp = _weight_split(ctx.wparam, '_dsrl_wtsplit') if (wa is not None and ctx.wparam is not None) else None
         wtpl = _weight_planes(ctx.wparam, '_dsrl_wtplanes') if (wa is not None and ctx.wparam is not None) else None
         # 'auto' never pays a split pass for a gradient (measured: the data-gradient launches gain less than the pass costs); planes a producer left are used
-        dyp = planes_for(dy_in, dy, lddy, dya, R * S, split_ok=planes_mode == 'all') if (wtpl is not None and ctx.needs_input_grad[0] and stride == 1 and K % 8 == 0) else None
+        # f16x1 (round 5): the one-plane split of a large gradient does pay (cat_conv.0 dgrad 772 -> 547 us at config 5's size for a ~60 us pass)
+        dy_split_ok = planes_mode == 'all' or (_planes_npl() == 1 and dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] >= planes_min_elems)
+        dyp = planes_for(dy_in, dy, lddy, dya, R * S, split_ok=dy_split_ok) if (wtpl is not None and ctx.needs_input_grad[0] and stride == 1 and K % 8 == 0) else None
         if ctx.needs_input_grad[1]:
             sink = _sink(ctx.wparam) if ctx.wparam is not None and _is_krsc(ctx.wparam) else None
             if sink is not None and wgrad_queue is not None:

@@ -246,6 +246,9 @@ def test_planes_kernel_bit_identical_to_register_staged(shape, cfg, kg, monkeypa
                 wp.data_ptr() if planes else None, None, y.data_ptr(), K, *shp, ws.data_ptr(), ws.numel(), stats.data_ptr() if parts else None, parts, st)
         res = [host(y), host(stats[:3 * parts * K])]
         for acc in (0, 1):
+            if cfg == 8 and not planes:
+                res += [None, None]         # no register-staged 256x256 data-gradient build any more (it spilled 76-88 registers; round 5): oracle below
+                continue
             dx = dx0.clone()
             bst = torch.zeros(int(HF.query('dsrl_bn_stats_floats', 2, max(dparts, 1), C)), device=DEV)
             HF.call('dsrl_conv2d_dgrad_planes', dy.data_ptr(), K, dya.data_ptr(), dyp.data_ptr() if planes else None, w.data_ptr(), None, rec.data_ptr(), wtsp.data_ptr(),
@@ -255,9 +258,13 @@ def test_planes_kernel_bit_identical_to_register_staged(shape, cfg, kg, monkeypa
             res += [host(dx), host(bst[:2 * dparts * C])]
         outs.append(res)
     for a_, b_ in zip(outs[0], outs[1]):
-        assert np.array_equal(a_, b_, equal_nan=True)
+        if a_ is not None:
+            assert np.array_equal(a_, b_, equal_nan=True)
     yo = O.conv2d(host(x).astype(np.float64), host(w).astype(np.float64), None, stride, pad, dil)
     check(outs[1][0], yo, 3e-6, 'y')
+    if cfg == 8:
+        dxo = O.conv2d_bwd(host(x).astype(np.float64), host(w).astype(np.float64), host(dy).astype(np.float64), stride, pad, dil)[0]
+        check(outs[1][2], dxo, 3e-6, 'dx (planes kernel, 256x256)'); check(outs[1][4], dxo + host(dx0), 3e-6, 'dx accumulated')
 
 
 @pytest.mark.parametrize('shape,splits', [((8, 256, 16, 32, 256, 3, 1, 1, 1), 4), ((8, 1024, 16, 32, 256, 1, 1, 0, 1), 4), ((4, 512, 16, 32, 512, 3, 1, 2, 2), 2),
@@ -326,6 +333,50 @@ def test_cooperative_splitk_matches_slabs_and_oracle(shape, splits, mode, monkey
         check(outs['1'][0], O.conv2d(host(x).astype(np.float64), host(w).astype(np.float64), None, stride, pad, dil), tol, 'y')
         dxo = O.conv2d_bwd(host(x).astype(np.float64), host(w).astype(np.float64), host(dy).astype(np.float64), stride, pad, dil, has_bias=False)[0]
         check(outs['1'][1], dxo, tol, 'dx'); check(outs['1'][2], dxo + host(dx0), tol, 'dx accumulated')
+    finally:
+        HF.set_conv_precision(None)
+        HF._query_cache.clear()
+
+
+@pytest.mark.parametrize('shape,cfg,kg', [((8, 256, 16, 32, 256, 3, 1, 1, 1), None, 0), ((2, 304, 16, 64, 192, 3, 1, 1, 1), 0, 0), ((4, 64, 64, 128, 256, 3, 1, 1, 1), 8, 0)])
+def test_one_plane_operands_bit_identical_to_f16x1_register_staged(shape, cfg, kg, monkeypatch):
+    """Round 5: in 'f16x1' mode conv_planes_kernel takes ONE fp16 plane per operand (hi = f16(x 2^e): the operand of a 2-byte storage format) - the values
+    the register-staged f16x1 kernel rounds to while staging - so forward and data gradient are BIT-identical to it for the same plan; deeper LDS rings
+    (4 slots for the 64x64 / four-group and the 128x128 tiles, 3 for 256x256).  Against fp64: the 11-bit tolerance of the arithmetic."""
+    N, C, H, W, K, R, stride, pad, dil = shape
+    if cfg is not None:
+        monkeypatch.setenv('DSRL_FORCE_CFG', str(cfg))
+    rs = np.random.RandomState(sum(shape) + 1)
+    x = dev(np.maximum(rs.standard_normal((N, C, H, W)), 0).astype(np.float32))
+    w = dev((rs.standard_normal((K, C, R, R)) / np.sqrt(C * R * R)).astype(np.float32))
+    Ho, Wo = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1, (W + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    dy = dev(rs.standard_normal((N, K, Ho, Wo)).astype(np.float32))
+    HF.set_conv_precision('f16x1')
+    try:
+        HF._query_cache.clear()
+        rec, wsp, wtsp, wtr = HF.split_filter(w)
+        wp, wtp = HF.filter_planes(w, rec)
+        xa, dya = HF.amax_for(x), HF.amax_for(dy)
+        xp, dyp = HF.planes_of(x, C, xa, 1), HF.planes_of(dy, K, dya, 1)
+        shp = (N, H, W, C, K, R, R, stride, pad, dil)
+        st = HF._stream()
+        ws = torch.empty(int(HF.query('dsrl_conv2d_dgrad_workspace_bytes', *shp)) + int(HF.query('dsrl_conv2d_fwd_workspace_bytes', *shp)) + 4096, device=DEV, dtype=torch.uint8)
+        outs = []
+        for planes in (False, True):
+            y = torch.empty((N, K, Ho, Wo), device=DEV).contiguous(memory_format=torch.channels_last)
+            HF.call('dsrl_conv2d_fwd_planes', x.data_ptr(), C, xa.data_ptr(), xp.data_ptr() if planes else None, w.data_ptr(), rec.data_ptr(), wsp.data_ptr(),
+                    wp.data_ptr() if planes else None, None, y.data_ptr(), K, *shp, ws.data_ptr(), ws.numel(), None, 0, st)
+            res = [host(y)]
+            if not (cfg == 8 and not planes):
+                dx = torch.empty((N, C, H, W), device=DEV).contiguous(memory_format=torch.channels_last)
+                HF.call('dsrl_conv2d_dgrad_planes', dy.data_ptr(), K, dya.data_ptr(), dyp.data_ptr() if planes else None, w.data_ptr(), None, rec.data_ptr(), wtsp.data_ptr(),
+                        wtp.data_ptr() if planes else None, dx.data_ptr(), C, *shp, ws.data_ptr(), ws.numel(), None, 0, None, 0, None, None, 0, None, 0, 0, st)
+                res.append(host(dx))
+            outs.append(res)
+        for a_, b_ in zip(outs[0], outs[1]):
+            assert np.array_equal(a_, b_, equal_nan=True)
+        check(outs[1][0], O.conv2d(host(x).astype(np.float64), host(w).astype(np.float64), None, stride, pad, dil), 1e-3, 'y')
+        check(outs[1][-1], O.conv2d_bwd(host(x).astype(np.float64), host(w).astype(np.float64), host(dy).astype(np.float64), stride, pad, dil)[0], 1e-3, 'dx')
     finally:
         HF.set_conv_precision(None)
         HF._query_cache.clear()
