@@ -62,6 +62,7 @@ PROTOTYPES = {
     'dsrl_conv2d_filter_planes_batched': (i32, [fp, i32, i64, stream_t]),
     'dsrl_conv2d_fwd_planes': (i32, [fp, i32, fp, fp, fp, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, stream_t]),
     'dsrl_conv2d_dgrad_planes': (i32, [fp, i32, fp, fp, fp, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, fp, i32, fp, fp, i32, fp, i32, i32, stream_t]),
+    'dsrl_conv2d_dgrad_planes_drop': (i32, [fp, i32, fp, fp, fp, fp, fp, fp, fp, fp, i32] + _conv_shape + [fp, sz, fp, i32, fp, i32, fp, fp, i32, f32, fp, i32, i32, stream_t]),
     'dsrl_conv2d_wgrad_amax': (i32, [fp, i32, fp, fp, i32, fp, fp] + _conv_shape + [fp, sz, stream_t]),
     'dsrl_conv_precision': (i32, [i32]),
     'dsrl_conv2d_inbounds_macs': (i64, _conv_shape),
@@ -83,6 +84,7 @@ PROTOTYPES = {
     'dsrl_bn_train_fwd': (i32, [fp, i32, fp, i32, i64, i32, f32, f32, fp, fp, fp, fp, fp, fp, fp, i32, i32, f32, u64, u32, fp, sz, fp, stream_t]),
     'dsrl_bn_bwd': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, f32, i32, fp, sz, fp, stream_t]),
     'dsrl_bn_bwd_from_stats': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, i32, fp, i32, fp, stream_t]),
+    'dsrl_bn_bwd_from_stats_drop': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, f32, i32, fp, i32, fp, stream_t]),
     'dsrl_dropout_fwd': (i32, [fp, i32, fp, i32, i64, i32, f32, u64, u32, stream_t]),
     'dsrl_dropout_bwd': (i32, [fp, i32, fp, i32, i64, i32, f32, u64, u32, stream_t]),
     'dsrl_bilinear_ac_fwd': (i32, [fp, i32, fp, i32, i32, i32, i32, i32, i32, i32, stream_t]),

@@ -909,7 +909,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_apply_kernel(const float* __
                                                                   float* __restrict__ dres, int lddr, int P, int C, int groups, int rows_per_slab,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int relu, int training,
-                                                                  const float* __restrict__ part, int nparts, unsigned* __restrict__ dx_amax) {
+                                                                  const float* __restrict__ part, int nparts, unsigned* __restrict__ dx_amax, float ks) {
     __shared__ double shm[8][2][32];
     __shared__ float fin[2][32];
     const int grp = blockIdx.x % groups, slab = blockIdx.x / groups;
@@ -960,8 +960,9 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_apply_kernel(const float* __
         const float4 dv = LD4(dy, p, lddy, q), xv = LD4(x, p, ldx, q);
         float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
         if (relu) yv = LD4(y, p, ldy, q);
-        const float g0 = masked_grad(dv.x, yv.x, relu, 0.f, 1.f), g1 = masked_grad(dv.y, yv.y, relu, 0.f, 1.f);
-        const float g2 = masked_grad(dv.z, yv.z, relu, 0.f, 1.f), g3 = masked_grad(dv.w, yv.w, relu, 0.f, 1.f);
+        // ks: 1 / (1 - p) of a Dropout behind the ReLU (the combined mask is y > 0), else 1 (exact)
+        const float g0 = masked_grad(dv.x, yv.x, relu, 0.f, ks), g1 = masked_grad(dv.y, yv.y, relu, 0.f, ks);
+        const float g2 = masked_grad(dv.z, yv.z, relu, 0.f, ks), g3 = masked_grad(dv.w, yv.w, relu, 0.f, ks);
         const float4 d = make_float4(gi[0] * (g0 - mb[0] - (xv.x - mu[0]) * is[0] * mg[0]), gi[1] * (g1 - mb[1] - (xv.y - mu[1]) * is[1] * mg[1]),
                                      gi[2] * (g2 - mb[2] - (xv.z - mu[2]) * is[2] * mg[2]), gi[3] * (g3 - mb[3] - (xv.w - mu[3]) * is[3] * mg[3]));
         ST4(dx, p, lddx, q) = d;
@@ -1394,6 +1395,15 @@ extern "C" int dsrl_bn_bwd_from_stats(const float* x, int ldx, const float* y, i
                                       float* dresidual, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
                                       float* dgamma, float* dbeta, int relu, int training, float* stats, int stats_parts, uint32_t* dx_amax,
                                       dsrl_stream_t stream) {
+    return dsrl_bn_bwd_from_stats_drop(x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, P, C, mean, invstd, gamma, dgamma, dbeta, relu, 0.f, training, stats, stats_parts,
+                                       dx_amax, stream);
+}
+extern "C" int dsrl_bn_bwd_from_stats_drop(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
+                                           float* dresidual, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
+                                           float* dgamma, float* dbeta, int relu, float drop_p, int training, float* stats, int stats_parts, uint32_t* dx_amax,
+                                           dsrl_stream_t stream) {
+    DSRL_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || relu), DSRL_E_BADARG, "bn_bwd_from_stats_drop: dropout p=%f needs the ReLU mask (y > 0)", drop_p);
+    const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     DSRL_REQUIRE(x && dy && dx && mean && invstd && gamma && stats && P > 0 && P < (1ll << 31) && C > 0, DSRL_E_BADARG, "bn_bwd_from_stats: bad arguments");
     DSRL_REQUIRE(y || !relu, DSRL_E_BADARG, "bn_bwd_from_stats: forward output needed for the relu mask");
     DSRL_REQUIRE(stats_parts > 0 && stats_parts <= 4096, DSRL_E_BADARG, "bn_bwd_from_stats: %d row blocks of partials (1..4096)", stats_parts);
@@ -1412,7 +1422,7 @@ extern "C" int dsrl_bn_bwd_from_stats(const float* x, int ldx, const float* y, i
     const int rows_per_slab = (int)ceil_div(P, (int64_t)slabs);
     slabs = (int)ceil_div(P, (int64_t)rows_per_slab);
     hipLaunchKernelGGL(bn_bwd_stats_apply_kernel, dim3((unsigned)(groups * slabs)), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (int)P, C,
-                       groups, rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, training, stats, stats_parts, dx_amax);
+                       groups, rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, training, stats, stats_parts, dx_amax, ks);
     return launch_status("bn_bwd_stats_apply_kernel");
 }
 

@@ -88,6 +88,7 @@ struct ConvArgs {
     // partial sums of g = dy * [y > 0] and g * xhat per (row block, channel) in bstats [2][parts][K] (null: off)
     const float* bn_x; const float* bn_y; const float* bn_mean; const float* bn_invstd; float* bstats;
     int bn_ldx, bn_ldy, bn_relu;
+    float bn_gscale;                      // factor on the masked gradient: 1 / (1 - p) when a Dropout sits behind the BatchNorm's ReLU (round 5), else 1
     int bn_fast;                          // KG == 1 builds: the BatchNorm-backward sums through LDS with 16-byte loads of x / y (host: alignment, K % 4 == 0, no parity order)
     // split kernels, dgrad of a strided conv (par = stride > 1, else 0): the GEMM rows are ordered by parity class - M-tile t (pbm rows) holds
     // rows (t / par^2) * pbm ... of class (ph, pw) = t % par^2, a class row j being pixel (n, hh*par + ph, wh*par + pw), (n, hh, wh) = j over the

@@ -1618,7 +1618,7 @@ extern "C" int dsrl_conv2d_filters_amax_batched(const int64_t* table, int64_t ns
     return launch_status("weight_amax_batched_kernel");
 }
 
-struct DgradBn { const float* x; const float* y; const float* mean; const float* invstd; float* stats; int ldx, ldy, relu; };
+struct DgradBn { const float* x; const float* y; const float* mean; const float* invstd; float* stats; int ldx, ldy, relu; float gscale = 1.f; };
 static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                       void* ws, size_t ws_bytes, dsrl_stream_t stream, int accumulate, const DgradBn* bn = nullptr,
@@ -1695,6 +1695,7 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
     }
     if (bn) {
         a.bn_x = bn->x; a.bn_y = bn->y; a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bstats = bn->stats; a.bn_ldx = bn->ldx; a.bn_ldy = bn->ldy; a.bn_relu = bn->relu;
+        a.bn_gscale = bn->gscale;
         a.bn_fast = a.par == 0 && C % 4 == 0 && bn->ldx % 4 == 0 && (!bn->relu || bn->ldy % 4 == 0) && ((uintptr_t)bn->x % 16) == 0 && (!bn->relu || ((uintptr_t)bn->y % 16) == 0) &&
                     ((uintptr_t)bn->mean % 16) == 0 && ((uintptr_t)bn->invstd % 16) == 0 && ((uintptr_t)bn->stats % 16) == 0 && env_int("DSRL_BNSTATS_FAST", 1);
     }
@@ -1943,6 +1944,16 @@ extern "C" int dsrl_conv2d_dgrad_planes(const float* dy, int lddy, const uint32_
                                         void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y, int bn_ldy,
                                         const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats, int stats_parts, int accumulate,
                                         dsrl_stream_t stream) {
+    return dsrl_conv2d_dgrad_planes_drop(dy, lddy, dy_amax, dy_planes, w, wt_in, w_amax, wt_split, wt_planes, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes,
+                                         bn_x, bn_ldx, bn_y, bn_ldy, bn_mean, bn_invstd, bn_relu, 0.f, bstats, stats_parts, accumulate, stream);
+}
+extern "C" int dsrl_conv2d_dgrad_planes_drop(const float* dy, int lddy, const uint32_t* dy_amax, const void* dy_planes, const float* w, const float* wt_in, const uint32_t* w_amax,
+                                             const void* wt_split, const void* wt_planes, float* dx, int lddx,
+                                             int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                             void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y, int bn_ldy,
+                                             const float* bn_mean, const float* bn_invstd, int bn_relu, float bn_drop_p, float* bstats, int stats_parts, int accumulate,
+                                             dsrl_stream_t stream) {
+    DSRL_REQUIRE(bn_drop_p >= 0.f && bn_drop_p < 1.f && (bn_drop_p == 0.f || bn_relu), DSRL_E_BADARG, "conv2d_dgrad_planes_drop: dropout p=%f needs the ReLU mask (y > 0)", bn_drop_p);
     if (bstats == nullptr)
         return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, accumulate ? 1 : 0, nullptr, dy_amax, w_amax, wt_split,
                           dy_planes, wt_planes);
@@ -1951,6 +1962,7 @@ extern "C" int dsrl_conv2d_dgrad_planes(const float* dy, int lddy, const uint32_
                  "conv2d_dgrad_planes: this launch writes %d row blocks of partials, the caller expects %d",
                  dsrl_conv2d_dgrad_stats_parts(N, H, W, C, K, R, S, stride, pad, dil), stats_parts);
     DgradBn bn{bn_x, bn_y, bn_mean, bn_invstd, bstats, bn_ldx, bn_ldy, bn_relu};
+    bn.gscale = bn_drop_p > 0.f ? 1.f / (1.f - bn_drop_p) : 1.f;          // the factor the dropout kernels apply (bn.hip: ks)
     return dgrad_impl(dy, lddy, w, wt_in, dx, lddx, N, H, W, C, K, R, S, stride, pad, dil, ws, ws_bytes, stream, accumulate ? 1 : 0, &bn, dy_amax, w_amax, wt_split,
                       dy_planes, wt_planes);
 }

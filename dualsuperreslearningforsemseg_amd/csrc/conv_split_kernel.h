@@ -594,8 +594,9 @@ void conv_igemm_split_kernel(const ConvArgs a) {
                     const int row = r0_ + RSTEP * (b0 + u);
                     if (kok4 && mrow0 + row < a.M) {
                         const float4 gv = *reinterpret_cast<const float4*>(wt + row * TC + 4 * c4);
-                        const float g0 = (a.bn_relu && !(yv[u].x > 0.f)) ? 0.f : gv.x, g1 = (a.bn_relu && !(yv[u].y > 0.f)) ? 0.f : gv.y;
-                        const float g2 = (a.bn_relu && !(yv[u].z > 0.f)) ? 0.f : gv.z, g3 = (a.bn_relu && !(yv[u].w > 0.f)) ? 0.f : gv.w;
+                        const float gs = a.bn_gscale;            // 1 / (1 - p) of a Dropout behind the ReLU (its mask is y > 0 as well), else 1: exact
+                        const float g0 = (a.bn_relu && !(yv[u].x > 0.f)) ? 0.f : gv.x * gs, g1 = (a.bn_relu && !(yv[u].y > 0.f)) ? 0.f : gv.y * gs;
+                        const float g2 = (a.bn_relu && !(yv[u].z > 0.f)) ? 0.f : gv.z * gs, g3 = (a.bn_relu && !(yv[u].w > 0.f)) ? 0.f : gv.w * gs;
                         sg[0] += g0; sgx[0] += g0 * ((xv[u].x - mu4.x) * is4.x);
                         sg[1] += g1; sgx[1] += g1 * ((xv[u].y - mu4.y) * is4.y);
                         sg[2] += g2; sgx[2] += g2 * ((xv[u].z - mu4.z) * is4.z);
@@ -645,7 +646,7 @@ void conv_igemm_split_kernel(const ConvArgs a) {
                 for (int e = 0; e < EPG; ++e) {
                     const int m = mb32 + rq + (e & 3) + 8 * (e >> 2);
                     if (kok && m < a.M) {
-                        const float g = (a.bn_relu && !(yv[e] > 0.f)) ? 0.f : share(i, j, e);
+                        const float g = (a.bn_relu && !(yv[e] > 0.f)) ? 0.f : share(i, j, e) * a.bn_gscale;
                         sg += g; sgx += g * ((xv[e] - mu) * is);
                     }
                 }

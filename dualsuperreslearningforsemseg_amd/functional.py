@@ -670,13 +670,14 @@ bn_bwd_stats_shared = os.environ.get('DSRL_BN_BWD_STATS_SHARED', '1') != '0'
 
 
 class BNLink:
-    __slots__ = ('x', 'y_ptr', 'y_shape', 'mean', 'invstd', 'relu', 'valid', 'stats', 'parts', 'dx_ptr', 'shared')
+    __slots__ = ('x', 'y_ptr', 'y_shape', 'mean', 'invstd', 'relu', 'valid', 'stats', 'parts', 'dx_ptr', 'shared', 'drop_p')
 
     def __init__(self, shared=False):
         self.x = self.mean = self.invstd = self.stats = None      # the BN output itself is NOT kept (it may carry this link: no cycles)
         self.y_ptr, self.y_shape = 0, None
         self.relu, self.valid, self.parts, self.dx_ptr = False, False, 0, 0
         self.shared = shared        # y feeds the two consumers of a GradSlot: the accumulating (= last) dgrad completes its gradient
+        self.drop_p = 0.0           # a Dropout(p) behind the BN's ReLU (round 5): y is the tensor behind it, its zeros are the combined mask
 
 
 class _Fork(torch.autograd.Function):
@@ -833,9 +834,9 @@ class _Conv2d(torch.autograd.Function):
                 # x is y = relu(bn(.)) of a BatchNorm that feeds only this conv: leave its backward partial sums with the data gradient
                 bstats = torch.empty(cquery('dsrl_bn_stats_floats', 2, parts, Cc), device=x.device, dtype=torch.float32)
                 _, bld = pm(link.x)
-                call('dsrl_conv2d_dgrad_planes', dy.data_ptr(), lddy, p_(dya), p_(dyp), w.data_ptr(), wt_ptr, p_(wa), p_(wtsp), p_(wtpl), dx.data_ptr(), Cc, *shp,
+                call('dsrl_conv2d_dgrad_planes_drop', dy.data_ptr(), lddy, p_(dya), p_(dyp), w.data_ptr(), wt_ptr, p_(wa), p_(wtsp), p_(wtpl), dx.data_ptr(), Cc, *shp,
                      ws.data_ptr(), ws.numel(), link.x.data_ptr(), bld, x.data_ptr(), ldx, link.mean.data_ptr(), link.invstd.data_ptr(), int(link.relu),
-                     bstats.data_ptr(), parts, int(acc), st)
+                     float(link.drop_p), bstats.data_ptr(), parts, int(acc), st)
                 link.stats, link.parts, link.dx_ptr = bstats, parts, dx.data_ptr()
             else:
                 call('dsrl_conv2d_dgrad_planes', dy.data_ptr(), lddy, p_(dya), p_(dyp), w.data_ptr(), wt_ptr, p_(wa), p_(wtsp), p_(wtpl), dx.data_ptr(), Cc, *shp,
@@ -914,7 +915,7 @@ class _StemConv(torch.autograd.Function):
         return None, dw, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, grad_slot=None):
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, grad_slot=None, in_link=None):
     """nn.Conv2d arithmetic (square stride/padding/dilation) on the MFMA implicit-GEMM kernels."""
     if grad_slot is not None and x.shape[1] % 4 != 0:
         grad_slot.closed = True             # the padded-channel fallback reports its own gradient: the shared buffer must not be used
@@ -925,6 +926,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, grad_slot=None
         padc = 4 - x.shape[1] % 4           # generic fallback: pad input and filter channels to a multiple of 4 (zeros contribute nothing)
         x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, padc))
         weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, padc))
+    if in_link is not None and x.shape[1] % 4 == 0 and bn_bwd_stats_enabled:
+        return _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation), grad_slot, 0, in_link)
     return _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation), grad_slot)
 
 
@@ -973,9 +976,9 @@ class _BNAct(torch.autograd.Function):
         if ya is not None:
             set_amax(y, ya)
         ctx.save_for_backward(x, y, mean, invstd, gamma)
-        if out_link is not None and drop_p == 0.0 and Cc % 32 == 0 and ldx == Cc:
+        if out_link is not None and (drop_p == 0.0 or relu) and Cc % 32 == 0 and ldx == Cc:
             out_link.x, out_link.mean, out_link.invstd, out_link.relu, out_link.valid = x, mean, invstd, bool(relu), True
-            out_link.y_ptr, out_link.y_shape = y.data_ptr(), tuple(y.shape)
+            out_link.y_ptr, out_link.y_shape, out_link.drop_p = y.data_ptr(), tuple(y.shape), float(drop_p)
         ctx.cfg = (bool(training), bool(relu), float(drop_p), residual is not None)
         ctx.gb = (gamma, beta) if isinstance(gamma, torch.nn.Parameter) and isinstance(beta, torch.nn.Parameter) else None
         return y
@@ -999,11 +1002,11 @@ class _BNAct(torch.autograd.Function):
         dxa = amax_slot(x.device) if f16_mode() else None       # max |dx|, left by the kernel: dx is the dy operand of the conv in front of this BN
         dxa_ptr = None if dxa is None else dxa.data_ptr()
         link = ctx.out_link
-        if link is not None and link.stats is not None and link.dx_ptr == dy.data_ptr() and lddy == Cc and drop_p == 0.0:
+        if link is not None and link.stats is not None and link.dx_ptr == dy.data_ptr() and lddy == Cc and (drop_p == 0.0 or relu):
             # the gradient we received is the buffer the consuming conv's dgrad wrote, and it left our two per-channel sums with it
-            call('dsrl_bn_bwd_from_stats', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,
+            call('dsrl_bn_bwd_from_stats_drop', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,
                  None if dres is None else dres.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                 dgamma.data_ptr(), dbeta.data_ptr(), int(relu), int(training), link.stats.data_ptr(), int(link.parts), dxa_ptr, _stream())
+                 dgamma.data_ptr(), dbeta.data_ptr(), int(relu), float(drop_p), int(training), link.stats.data_ptr(), int(link.parts), dxa_ptr, _stream())
         else:
             ws = _ws(cquery('dsrl_bn_workspace_bytes', P, Cc), x)
             call('dsrl_bn_bwd', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,

@@ -101,8 +101,14 @@ class DSRL(BaseModel):
         if (HF.grad_slots_enabled and self.stage > 1 and cat_features.requires_grad and t.is_grad_enabled()
                 and isinstance(self.SSSR_decoder['cat_conv'], HipSequential) and isinstance(self.SISR_decoder, HipSequential)):
             cat_features, slot = HF.fork(cat_features), HF.GradSlot()
-        SSSR_output = self.SSSR_decoder['cat_conv'](cat_features, grad_slot=slot) if slot is not None else self.SSSR_decoder['cat_conv'](cat_features)   # DSRL.py:168
-        SSSR_output = self.SSSR_decoder['cls_conv'](SSSR_output)                              # DSRL.py:169
+        # the output of cat_conv (BN -> ReLU -> Dropout, DSRL.py:44-49) feeds cls_conv only: its data gradient leaves that BatchNorm's backward sums
+        link = HF.BNLink() if (HF.bn_bwd_stats_enabled and t.is_grad_enabled() and isinstance(self.SSSR_decoder['cat_conv'], HipSequential)
+                               and isinstance(self.SSSR_decoder['cls_conv'], HipConv2d)) else None
+        kw = {} if link is None else {'out_link': link}
+        SSSR_output = (self.SSSR_decoder['cat_conv'](cat_features, grad_slot=slot, **kw) if slot is not None
+                       else self.SSSR_decoder['cat_conv'](cat_features, **kw))                # DSRL.py:168
+        SSSR_output = (self.SSSR_decoder['cls_conv'](SSSR_output, in_link=link) if (link is not None and link.valid)
+                       else self.SSSR_decoder['cls_conv'](SSSR_output))                       # DSRL.py:169
         SSSR_output = self.SSSR_decoder['upsample16_pred'](SSSR_output)                       # DSRL.py:170
         # DSRL.py:172-174: unused outputs are CPU zeros(1) whatever the model device
         SISR_output = t.zeros(1, requires_grad=False)

@@ -19,8 +19,9 @@ def _single(v):
 
 
 class HipConv2d(nn.Conv2d):
-    def forward(self, x, grad_slot=None):
-        """grad_slot: functional.GradSlot shared with the other consumers of x (all of them convs or a residual BN), see functional.fork."""
+    def forward(self, x, grad_slot=None, in_link=None):
+        """grad_slot: functional.GradSlot shared with the other consumers of x (all of them convs or a residual BN), see functional.fork.
+        in_link: functional.BNLink of the BatchNorm that produced x, when this conv is its ONLY consumer (the data gradient leaves the BN's backward sums)."""
         if self.groups != 1 or self.padding_mode != 'zeros':
             raise HF.DsrlHipError('HipConv2d: groups=1 and zero padding only')
         k = self.kernel_size
@@ -29,7 +30,7 @@ class HipConv2d(nn.Conv2d):
                 grad_slot.closed = True         # this consumer reports its own gradient: nobody may accumulate into a shared buffer
             # feature transformers, DSRL.py:88-93; x may carry the slot it shares with the fused loss (functional.fused_losses)
             return HF.pointwise_strided(x, self.weight, _single(self.stride), getattr(x, '_dsrl_out_slot', None))
-        return HF.conv2d(x, self.weight, self.bias, _single(self.stride), _single(self.padding), _single(self.dilation), grad_slot=grad_slot)
+        return HF.conv2d(x, self.weight, self.bias, _single(self.stride), _single(self.padding), _single(self.dilation), grad_slot=grad_slot, in_link=in_link)
 
 
 class HipBatchNorm2d(nn.BatchNorm2d):
@@ -107,10 +108,14 @@ class HipMaxPool2d(nn.MaxPool2d):
 class HipSequential(nn.Sequential):
     """nn.Sequential that runs Conv2d -> BatchNorm2d -> ReLU -> Dropout as conv + one fused BN/activation pass."""
 
-    def forward(self, x, residual=None, grad_slot=None):
-        """grad_slot goes to the first module when that is a HipConv2d (the consumer of x)."""
+    def forward(self, x, residual=None, grad_slot=None, out_link=None):
+        """grad_slot goes to the first module when that is a HipConv2d (the consumer of x).  BatchNorm-backward links (functional.BNLink, round 5): the
+        output of a fused conv -> BN -> ReLU (-> Dropout) group that is followed by another conv -> BN group feeds ONLY that conv, so its data gradient
+        can leave the BN's two per-channel sums (cat_conv: DSRL.py:34-49); `out_link` does the same for the last group when the caller knows the single
+        consumer of this Sequential's output (DSRL.forward_head: cls_conv)."""
         mods = list(self)
         i, n = 0, len(mods)
+        link_in = None              # link of the tensor x currently is, if a BN group just produced it
         if grad_slot is not None and not (n and isinstance(mods[0], HipConv2d)):
             grad_slot.closed = True             # nobody here can honour the slot
         seed = HF.current_seed()
@@ -140,8 +145,15 @@ class HipSequential(nn.Sequential):
                     if mods[j].training and mods[j].p > 0:
                         p, stream = mods[j].p, getattr(mods[j], 'rng_stream', 0)
                     j += 1
+                # does the output feed exactly one fused conv -> BN group of this Sequential (or, for the last group, the caller's single consumer)?
+                nxt = (j + 1 < n and isinstance(mods[j], HipConv2d) and isinstance(mods[j + 1], nn.BatchNorm2d) and mods[j].groups == 1 and mods[j].in_channels % 32 == 0)
+                lout = None
+                if HF.bn_bwd_stats_enabled and torch.is_grad_enabled() and residual is None:
+                    lout = HF.BNLink() if nxt else (out_link if j >= n else None)
                 x = HF.conv2d_bn_act(x, m.weight, m.bias, _single(m.stride), _single(m.padding), _single(m.dilation), bn, relu=relu, drop_p=p, seed=seed,
-                                     rng_stream=stream, residual=residual if j >= n else None, grad_slot=grad_slot if i == 0 else None)
+                                     rng_stream=stream, residual=residual if j >= n else None, grad_slot=grad_slot if i == 0 else None,
+                                     in_link=link_in, out_link=lout)
+                link_in = lout if nxt else None
                 i = j
             else:
                 x = m(x, grad_slot=grad_slot) if (i == 0 and grad_slot is not None and isinstance(m, HipConv2d)) else m(x)

@@ -176,6 +176,14 @@ int dsrl_conv2d_dgrad_planes(const float* dy, int lddy, const uint32_t* dy_amax,
                              void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y, int bn_ldy,
                              const float* bn_mean, const float* bn_invstd, int bn_relu, float* bstats /*nullable*/, int stats_parts, int accumulate,
                              dsrl_stream_t stream);
+/* the same with a Dropout(p) between the BatchNorm's ReLU and this conv (DSRL.py:38-41,46-49: cat_conv): bn_y is the tensor BEHIND the dropout, whose zeros are the
+ * combined mask, and the sums are taken of g = dy / (1 - p) where bn_y > 0 (round 5) */
+int dsrl_conv2d_dgrad_planes_drop(const float* dy, int lddy, const uint32_t* dy_amax, const void* dy_planes /*nullable*/, const float* w, const float* wt /*nullable*/,
+                             const uint32_t* w_amax, const void* wt_split /*nullable*/, const void* wt_planes /*nullable*/, float* dx, int lddx,
+                             int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                             void* ws, size_t ws_bytes, const float* bn_x, int bn_ldx, const float* bn_y, int bn_ldy,
+                             const float* bn_mean, const float* bn_invstd, int bn_relu, float bn_drop_p, float* bstats /*nullable*/, int stats_parts, int accumulate,
+                             dsrl_stream_t stream);
 int dsrl_conv2d_wgrad_amax(const float* x, int ldx, const uint32_t* x_amax, const float* dy, int lddy, const uint32_t* dy_amax, float* dw,
                            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                            void* ws, size_t ws_bytes, dsrl_stream_t stream);
@@ -275,6 +283,11 @@ int dsrl_bn_bwd(const float* x, int ldx, const float* y, int ldy, const float* d
 int dsrl_bn_bwd_from_stats(const float* x, int ldx, const float* y /*nullable*/, int ldy, const float* dy, int lddy, float* dx, int lddx,
                            float* dresidual /*nullable*/, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
                            float* dgamma /*nullable*/, float* dbeta /*nullable*/, int relu, int training, float* stats, int stats_parts,
+                           uint32_t* dx_amax /*nullable*/, dsrl_stream_t stream);
+/* ... with a Dropout(p) behind the ReLU: y is the tensor behind the dropout (mask y > 0, factor 1 / (1 - p)) */
+int dsrl_bn_bwd_from_stats_drop(const float* x, int ldx, const float* y /*nullable*/, int ldy, const float* dy, int lddy, float* dx, int lddx,
+                           float* dresidual /*nullable*/, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
+                           float* dgamma /*nullable*/, float* dbeta /*nullable*/, int relu, float drop_p, int training, float* stats, int stats_parts,
                            uint32_t* dx_amax /*nullable*/, dsrl_stream_t stream);
 
 /* Device-resident dropout key. By default every dropout-bearing launch (dsrl_bn_apply, dsrl_bn_train_fwd*, dsrl_dropout_*) bakes its
