@@ -1454,7 +1454,8 @@ def test_bn_backward_statistics_from_dgrad_epilogue(shared):
     old, orig_call, old_shared = HF.bn_bwd_stats_enabled, HF.call, HF.bn_bwd_stats_shared
 
     def counting(name, *a):
-        key = 'dsrl_conv2d_dgrad_bnstats' if (name == 'dsrl_conv2d_dgrad_planes' and a[30] is not None) else name       # a[30]: the bstats argument
+        key = 'dsrl_conv2d_dgrad_bnstats' if (name == 'dsrl_conv2d_dgrad_planes_drop' and a[31] is not None) else name       # a[31]: the bstats argument
+        key = 'dsrl_bn_bwd_from_stats' if name == 'dsrl_bn_bwd_from_stats_drop' else key
         counts[-1][key] = counts[-1].get(key, 0) + 1
         return orig_call(name, *a)
 
@@ -1480,7 +1481,8 @@ def test_bn_backward_statistics_from_dgrad_epilogue(shared):
     assert counts[0].get('dsrl_bn_bwd_from_stats', 0) == 0 and counts[0].get('dsrl_conv2d_dgrad_bnstats', 0) == 0
     # bn1, bn2 of 33 bottlenecks + bn3 of the blocks whose output feeds only the next block (completed by its accumulating dgrad)
     # (a BN whose output has a further consumer - layer1's output also feeds the decoder - receives a summed gradient and rightly ignores them)
-    lo, hi = (90, 99) if shared else (66, 66)
+    # (round 5: + the two decoder BatchNorms of cat_conv, whose outputs feed conv4 / cls_conv only)
+    lo, hi = (92, 101) if shared else (68, 68)
     assert lo <= counts[1].get('dsrl_bn_bwd_from_stats', 0) <= counts[1].get('dsrl_conv2d_dgrad_bnstats', 0) <= hi
     bad = {k: rel_err(grads[1][k], grads[0][k]) for k in grads[0] if rel_err(grads[1][k], grads[0][k]) > 5e-4}
     assert not bad, bad
