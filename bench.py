@@ -496,7 +496,7 @@ def main():
         try:        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (not collectable in-process)
             import hashlib
             src_now = hashlib.sha256(open(os.path.join(ROOT, 'dualsuperreslearningforsemseg_amd', 'csrc', 'conv_igemm.hip'), 'rb').read()).hexdigest()[:16]
-            for fn in ('round4_pmc_traffic.json', 'round3_pmc_traffic.json', 'round2_pmc_traffic.json', 'round1_pmc_traffic.json'):
+            for fn in ('round5_pmc_traffic.json', 'round4_pmc_traffic.json', 'round3_pmc_traffic.json', 'round2_pmc_traffic.json', 'round1_pmc_traffic.json'):
                 path = os.path.join(ROOT, 'profiles', fn)
                 if not os.path.isfile(path):
                     continue
@@ -509,17 +509,21 @@ def main():
                     pl_now = hashlib.sha256(open(os.path.join(ROOT, 'dualsuperreslearningforsemseg_amd', 'csrc', 'conv_planes.hip'), 'rb').read()).hexdigest()[:16]
                     # false: the kernels changed since that profile (profiles before round 4 carry no stamp for conv_planes.hip)
                     w3_now = hashlib.sha256(open(os.path.join(ROOT, 'dualsuperreslearningforsemseg_amd', 'csrc', 'conv_wgrad3.hip'), 'rb').read()).hexdigest()[:16]
+                    # round 5: the forward / dgrad kernel template lives in conv_split_kernel.h, its 128x128 two-group builds in conv_sk.hip
+                    hk_now = hashlib.sha256(open(os.path.join(ROOT, 'dualsuperreslearningforsemseg_amd', 'csrc', 'conv_split_kernel.h'), 'rb').read() +
+                                            open(os.path.join(ROOT, 'dualsuperreslearningforsemseg_amd', 'csrc', 'conv_sk.hip'), 'rb').read()).hexdigest()[:16]
                     roof['traffic_kernel_source_unchanged'] = (stamp.get('conv_igemm_sha16') == src_now and stamp.get('conv_planes_sha16', pl_now) == pl_now
-                                                               and stamp.get('conv_wgrad3_sha16', w3_now) == w3_now)
+                                                               and stamp.get('conv_wgrad3_sha16', w3_now) == w3_now and stamp.get('conv_split_kernel_sha16') == hk_now)
                     break
             # matrix-pipe busy fraction of the dominant family from the committed SQ-counter pass of this command (tools/pmc_step.sh): the share of
             # SIMD cycles in which an MFMA executes - what `frac` leaves unsaid about WHY a launch is below its roof
-            sq_path = os.path.join(ROOT, 'profiles', 'round4_sq_counters_step.json')
+            sq_name = next((n for n in ('round5_sq_counters_step.json', 'round4_sq_counters_step.json') if os.path.isfile(os.path.join(ROOT, 'profiles', n))), 'round5_sq_counters_step.json')
+            sq_path = os.path.join(ROOT, 'profiles', sq_name)
             if os.path.isfile(sq_path):
                 fam = json.load(open(sq_path)).get('_families', {}).get(roof.get('kernel'))
                 if fam:
                     roof['mfma_busy'] = fam['mfma_busy']
-                    roof['mfma_busy_source'] = 'profiles/round4_sq_counters_step.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE over the graph-replayed step)'
+                    roof['mfma_busy_source'] = f'profiles/{sq_name} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE over the graph-replayed step)'
         except Exception:
             pass
         if world == 1:

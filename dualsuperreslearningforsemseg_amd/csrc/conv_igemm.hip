@@ -1461,8 +1461,9 @@ static int fwd_stats_parts(const FwdPlan& p, int npl, bool dgrad = false) {
         return ((p.ws / ((size_t)p.splits * p.M * sizeof(float))) % 32 == 0 && ceil_div(p.M, 64) <= 256) ? (int)ceil_div(p.M, 64) : 0;
     if (!npl || (p.splits > 1 && !p.coop)) return 0;
     int bm, bn; cfg_dims(p.cfg, bm, bn);
+    // forward: ONE partial per block tile (round 5: the wave rows of a tile are merged in the conv epilogue); dgrad sums: one per wave row
     static const int kWGM[kNumCfg] = {2, 4, 4, 2, 2, 2, 4, 4, 2};    // waves along M per block tile, DSRL_CFG_SWITCH order (+ the two 8-wave tiles)
-    const long long parts = ceil_div(p.M, bm) * kWGM[p.cfg];
+    const long long parts = ceil_div(p.M, bm) * (dgrad ? kWGM[p.cfg] : 1);
     return parts <= kMaxStatsParts ? (int)parts : 0;       // more than 256: the BatchNorm kernels reduce them to 32 first (bn.hip: stats_reduce)
 }
 extern "C" int dsrl_conv2d_fwd_stats_parts(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {

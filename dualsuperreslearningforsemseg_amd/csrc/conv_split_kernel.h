@@ -682,35 +682,67 @@ void conv_igemm_split_kernel(const ConvArgs a) {
             }
         }
     }
-    if (KG > 1 && grp > 0) return;              // the forward statistics below are taken by group 0 from the whole tile
+    const bool stats_wave = !(KG > 1 && grp > 0);    // the forward statistics below are taken by group 0 from the whole tile (every wave stays for the block barrier)
     // ---- BatchNorm partials of the tile this block just wrote: for every output channel (n, mean, M2) over the wave's 32*MR rows,
     //      two passes over the registers (exact centred second moment), the two lanes that share a channel combined with one shuffle.
     //      Layout [3][mtiles * WGM][K] = what bn_partial4_kernel writes, consumed by dsrl_bn_train_fwd_from_stats.
     if (a.stats != nullptr && single) {
-        const int nparts = a.mtiles * WGM, part = tile_m * WGM + wm;
+        // Round 5: ONE partial per block tile.  The WGM wave rows of a tile used to leave one partial each (128 row blocks for an M = 4096 tensor on 64x64
+        // tiles), and every block of the BatchNorm kernel merges all of them for its 32 channels before it streams a row: 2.9 us of a 6.9 us launch at
+        // 128 partials, 1.1-1.4 us at 64 (tools/bn_prologue_probe.py).  The wave rows meet in LDS and wave row 0 merges them in the order wm = 1 .. WGM-1
+        // (Chan's update: exact counts, the same formulas the BatchNorm kernels use).  Layout [3][mtiles][K].
+        const int nparts = a.mtiles, part = tile_m;
+        float* mg = reinterpret_cast<float*>(smem) + (KG > 1 ? (size_t)KG * MR * NR * 4 * 256 * 4 : 0);  // [WGM][WGN * NR][3][32], behind the K-group reduction area (the dgrad sums' exchange area)
+        float sn[NR], sm[NR], sq[NR];
+        if (stats_wave) {
 #pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const int k = n0 + (wn * NR + j) * 32 + col;
-            const bool kok = k < a.K;
-            const float bv = (a.bias != nullptr && kok) ? a.bias[k] : 0.f;
-            float n = 0.f, sum = 0.f;
+            for (int j = 0; j < NR; ++j) {
+                const int k = n0 + (wn * NR + j) * 32 + col;
+                const bool kok = k < a.K;
+                const float bv = (a.bias != nullptr && kok) ? a.bias[k] : 0.f;
+                float n = 0.f, sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < MR; ++i)
+                for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (m0 + (wm * MR + i) * 32 + rq + (e & 3) + 8 * (e >> 2) < a.M) { n += 1.f; sum += acc[i][j][e] + bv; }
-            n += __shfl_xor(n, 32); sum += __shfl_xor(sum, 32);
-            const float mean = n > 0.f ? sum / n : 0.f;
-            float q = 0.f;
+                    for (int e = 0; e < 16; ++e)
+                        if (m0 + (wm * MR + i) * 32 + rq + (e & 3) + 8 * (e >> 2) < a.M) { n += 1.f; sum += acc[i][j][e] + bv; }
+                n += __shfl_xor(n, 32); sum += __shfl_xor(sum, 32);
+                const float mean = n > 0.f ? sum / n : 0.f;
+                float q = 0.f;
 #pragma unroll
-            for (int i = 0; i < MR; ++i)
+                for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (m0 + (wm * MR + i) * 32 + rq + (e & 3) + 8 * (e >> 2) < a.M) { const float d = acc[i][j][e] + bv - mean; q += d * d; }
-            q += __shfl_xor(q, 32);
-            if (lane < 32 && kok) {
-                float* o = a.stats + (long long)part * a.K + k;
-                o[0] = n; o[(long long)nparts * a.K] = mean; o[2ll * nparts * a.K] = q;
+                    for (int e = 0; e < 16; ++e)
+                        if (m0 + (wm * MR + i) * 32 + rq + (e & 3) + 8 * (e >> 2) < a.M) { const float d = acc[i][j][e] + bv - mean; q += d * d; }
+                q += __shfl_xor(q, 32);
+                sn[j] = n; sm[j] = mean; sq[j] = q;
+                if (WGM > 1 && wm > 0 && lane < 32) {
+                    float* o = mg + ((wm * (WGN * NR) + wn * NR + j) * 3) * 32 + lane;
+                    o[0] = n; o[32] = mean; o[64] = q;
+                }
+            }
+        }
+        if constexpr (WGM > 1) __syncthreads();
+        if (stats_wave && wm == 0 && lane < 32) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int k = n0 + (wn * NR + j) * 32 + col;
+                float na = sn[j], ma = sm[j], qa = sq[j];
+#pragma unroll
+                for (int w = 1; w < WGM; ++w) {
+                    const float* o = mg + ((w * (WGN * NR) + wn * NR + j) * 3) * 32 + lane;
+                    const float nb = o[0], mb = o[32], qb = o[64];
+                    if (nb > 0.f) {
+                        const float nt = na + nb, d = mb - ma;
+                        ma += d * (nb / nt);
+                        qa += qb + d * d * (na * nb / nt);
+                        na = nt;
+                    }
+                }
+                if (k < a.K) {
+                    float* o = a.stats + (long long)part * a.K + k;
+                    o[0] = na; o[(long long)nparts * a.K] = ma; o[2ll * nparts * a.K] = qa;
+                }
             }
         }
     }

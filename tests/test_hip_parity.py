@@ -1560,8 +1560,13 @@ def test_full_model_total_loss_backward_with_fa_vs_oracle():
     """The WHOLE loss (CE + w1 MSE + w2 FA, train_or_resume.py:435-438) back-propagated through the assembled model at 128x256 input, B=2
     (feature-transformer maps 32x64 -> 8x8 similarity matrices), through the production loss path (functional.fused_losses: fused CE/MSE
     kernels, sparse transformer gradient accumulated into the published dense one) against the fp64 oracle, default (fp32-equivalent)
-    arithmetic, with FIXED bounds: losses 1e-3, logits 5e-3 of their range; gradients in the L2 norm over the whole arena and for the tensors
-    the FA term reaches first."""
+    arithmetic, with FIXED bounds: losses 1e-3, logits 5e-3 of their range; gradients in the L2 norm over the whole arena and for the head tensors.
+
+    Two backward passes (round 5).  The FA term is an all-pairs L1 of two similarity matrices: its gradient w.r.t. an entry is a SUM OF SIGNS over 64 pairs
+    (FALoss.py:27-34), so a near-tie that lands on the other side in fp32 changes that entry by 2 of <= 64 - a last-bit change of any forward sum (a
+    different BatchNorm merge order, measured this round) moved the head gradients from 3e-4 to 9e-3 of the oracle with both builds exact to 1e-8 in
+    their statistics.  So: (1) the smooth part, CE + w1 MSE with the FA weight at zero, at the tight bound (2e-3, measured 2-5e-4); (2) the whole loss
+    at a bound that admits a few flipped pairs (3e-2) - a wrong FA backward (sign, normalisation, pooling) is an error of order 1, not 1e-2."""
     from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
     torch.manual_seed(11)
     model = D.DSRL(3, cs)
@@ -1579,31 +1584,44 @@ def test_full_model_total_loss_backward_with_fa_vs_oracle():
     x = rs.standard_normal((2, 3, 128, 256)).astype(np.float32)
     tg = rs.randint(0, 19, (2, 256, 512)).astype(np.uint8); tg[rs.uniform(size=tg.shape) < 0.1] = 255
     org = rs.standard_normal((2, 3, 256, 512)).astype(np.float32)
-    outs = model(dev(x, cl=False))
-    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
-    vals = HF.fused_losses(outs, dev(tg), dev(org), 255, 0.1, 1.0, 3, flag)
-    vals[3].backward()
-    out = O.model_forward({k: v.astype(np.float64) for k, v in sd.items()}, x.astype(np.float64), 3, True)
-    L64 = O.total_loss(out, tg, org.astype(np.float64), 3, backward=True)
-    assert out.SSSR_ft.v.shape == (2, 1, 32, 64) and float(L64[2]) > 0
-    check(host(vals[:4]), np.array(L64), 1e-3, 'losses (CE, MSE, FA, total)')
-    check(host(outs[0]), out.SSSR.v, 5e-3, 'logits')
-    check(host(outs[2]), out.SSSR_ft.v, 5e-3, 'SSSR_ft'); check(host(outs[3]), out.SISR_ft.v, 5e-3, 'SISR_ft')
 
     def l2(a, b):
         a = np.asarray(a, np.float64).ravel(); b = np.asarray(b, np.float64).ravel()
         return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
-    P = dict(model.named_parameters())
-    rep = {k: l2(host(P[k].grad), out.params[k].g) for k in ('SSSR_feature_transformer.0.weight', 'SISR_feature_transformer.0.weight', 'SSSR_decoder.upsample16_pred.6.weight',
-                                                           'SISR_decoder.0.weight', 'SSSR_decoder.cat_conv.0.weight', 'feature_extractor.aspp.branches.5.0.weight',
-                                                           'feature_extractor.backbone.layer4.2.conv3.weight', 'feature_extractor.backbone.layer1.0.conv1.weight')}
-    names = [k for k in P if P[k].grad is not None and k in out.params]
-    cat = lambda f: np.concatenate([np.asarray(f(k), np.float64).ravel() for k in names])
-    rep['all gradients (L2)'] = l2(cat(lambda k: host(P[k].grad)), cat(lambda k: out.params[k].g))
-    print({k: '%.2e' % v for k, v in rep.items()})
-    for k in ('SSSR_feature_transformer.0.weight', 'SISR_feature_transformer.0.weight', 'SSSR_decoder.upsample16_pred.6.weight', 'SISR_decoder.0.weight'):
-        assert rep[k] <= HEAD_GRAD_BOUND, (k, rep[k])
-    assert rep['all gradients (L2)'] <= ARENA_GRAD_BOUND, rep
+    heads = ('SSSR_feature_transformer.0.weight', 'SISR_feature_transformer.0.weight', 'SSSR_decoder.upsample16_pred.6.weight', 'SISR_decoder.0.weight')
+    FA_FLIP_BOUND = 3e-2
+    for w2, bound in ((0.0, HEAD_GRAD_BOUND), (1.0, FA_FLIP_BOUND)):
+        for p_ in model.parameters():
+            p_.grad = None
+        bn_state = {k: v.clone() for k, v in model.state_dict().items() if 'running' in k}
+        outs = model(dev(x, cl=False))
+        model.load_state_dict(bn_state, strict=False)            # both passes see the same running statistics (they do not enter a training forward anyway)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        vals = HF.fused_losses(outs, dev(tg), dev(org), 255, 0.1, w2, 3, flag)
+        vals[3].backward()
+        out = O.model_forward({k: v.astype(np.float64) for k, v in sd.items()}, x.astype(np.float64), 3, True)
+        L64 = O.total_loss(out, tg, org.astype(np.float64), 3, w2=w2, backward=True)
+        assert out.SSSR_ft.v.shape == (2, 1, 32, 64)
+        check(host(vals[:4]), np.array(L64), 1e-3, 'losses (CE, MSE, FA, total)')
+        check(host(outs[0]), out.SSSR.v, 5e-3, 'logits')
+        check(host(outs[2]), out.SSSR_ft.v, 5e-3, 'SSSR_ft'); check(host(outs[3]), out.SISR_ft.v, 5e-3, 'SISR_ft')
+        P = dict(model.named_parameters())
+        tensors = heads + ('SSSR_decoder.cat_conv.0.weight', 'feature_extractor.aspp.branches.5.0.weight', 'feature_extractor.backbone.layer4.2.conv3.weight',
+                           'feature_extractor.backbone.layer1.0.conv1.weight')
+        rep = {k: l2(host(P[k].grad), out.params[k].g) for k in tensors if P[k].grad is not None and float(np.abs(out.params[k].g).max()) > 0}
+        names = [k for k in P if P[k].grad is not None and k in out.params]
+        cat = lambda f: np.concatenate([np.asarray(f(k), np.float64).ravel() for k in names])      # noqa: E731
+        rep['all gradients (L2)'] = l2(cat(lambda k: host(P[k].grad)), cat(lambda k: out.params[k].g))
+        print('w2 =', w2, {k: '%.2e' % v for k, v in rep.items()})
+        if w2 == 0.0:
+            g0 = P['SSSR_feature_transformer.0.weight'].grad
+            assert g0 is None or float(g0.abs().max()) == 0.0                                           # no FA weight: the transformers receive no gradient
+        else:
+            assert float(L64[2]) > 0 and 'SSSR_feature_transformer.0.weight' in rep
+        for k in heads:
+            if k in rep:
+                assert rep[k] <= bound, (w2, k, rep[k])
+        assert rep['all gradients (L2)'] <= ARENA_GRAD_BOUND, rep
 
 
 def test_full_model_vs_stock_torch_fp64():

@@ -14,7 +14,9 @@ pm = json.load(open(f'{G}/{tag}_pmc_traffic.json'))
 pm['_stamp'] = {'commit': subprocess.run(['git', '-C', R, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip(),
                 'conv_igemm_sha16': hashlib.sha256(open(f'{R}/dualsuperreslearningforsemseg_amd/csrc/conv_igemm.hip', 'rb').read()).hexdigest()[:16],
                 'conv_planes_sha16': hashlib.sha256(open(f'{R}/dualsuperreslearningforsemseg_amd/csrc/conv_planes.hip', 'rb').read()).hexdigest()[:16],
-                'conv_wgrad3_sha16': hashlib.sha256(open(f'{R}/dualsuperreslearningforsemseg_amd/csrc/conv_wgrad3.hip', 'rb').read()).hexdigest()[:16]}
+                'conv_wgrad3_sha16': hashlib.sha256(open(f'{R}/dualsuperreslearningforsemseg_amd/csrc/conv_wgrad3.hip', 'rb').read()).hexdigest()[:16],
+                'conv_split_kernel_sha16': hashlib.sha256(open(f'{R}/dualsuperreslearningforsemseg_amd/csrc/conv_split_kernel.h', 'rb').read() +
+                                                          open(f'{R}/dualsuperreslearningforsemseg_amd/csrc/conv_sk.hip', 'rb').read()).hexdigest()[:16]}
 json.dump(pm, open(f'{R}/profiles/{P}_pmc_traffic.json', 'w'), indent=1)
 line = open(f'{G}/{tag}_bench.json').read().strip().splitlines()[-1]
 open(f'{R}/profiles/{P}_bench_line.json', 'w').write(line + '\n')
