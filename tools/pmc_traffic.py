@@ -13,7 +13,7 @@ def family(name):
         if f16 not in (None, '0', 'false'):
             return 'f16x1' if npl == '1' else 'f16x3'
         return 'bf16x3' if npl == '2' else 'bf16x6'
-    m = re.search(r'conv_igemm_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)(?:, \d+)?(?:, (\w+))?(?:, \w+)?>', name)
+    m = re.search(r'conv_igemm_split_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)(?:, \d+)?(?:, (\w+))?(?:, \w+){0,2}>', name)       # ..., STR1, COOP (round 5)
     if m:
         return f"conv_igemm_split_kernel<{arith(m.group(6), m.group(7))}> ({'dgrad' if m.group(5) == 'true' else 'forward'})"
     m = re.search(r'conv_planes_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false)', name)
