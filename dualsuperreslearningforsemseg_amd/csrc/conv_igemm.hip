@@ -1387,10 +1387,11 @@ static void pick_split_plan(long long M, int N, int nq, bool dgrad, TileCfg& cfg
     }
     // e) round 5 (conv_sk.hip, profiles/round5_sk_tiles_ab.txt): exactly half a chip of 128x128 tiles on a long K loop (layer4: M = 4096, N = 512, the 3x3
     //    conv and the 2048 -> 512 1x1 and its mirror-image dgrad) - two K groups per tile and split-K 2 across workgroups, reduced inside the launch:
-    //    -5 .. -10 % against 128x128 tiles with split-K slabs.  The layer3 shapes (64 tiles, split-K 4) came out even with 64x64 tiles / four K groups
-    //    and stay there; DSRL_SK_AUTO=0 turns the rule off, =2 also sends the 64-tile shapes (N = 256, nq >= 64) through it with split-K 4.
+    //    -5 .. -10 % against 128x128 tiles with split-K slabs IN ISOLATION.  In the step the rule came out even when it was introduced and 0.4 % behind
+    //    at the end of the round (once bn3's sums from the next block's dgrad and the decoder links were in: profiles/round5_ab.txt), and the layer3 shapes
+    //    (64 tiles, split-K 4) lose 3 %: the rule is OFF by default.  DSRL_SK_AUTO=1: the layer4 shapes, =2: also the 64-tile shapes (N = 256, nq >= 64).
     if (conv_precision_mode() >= 4 && N % 128 == 0 && M % 128 == 0) {
-        const int sk = env_int("DSRL_SK_AUTO", 1);
+        const int sk = env_int("DSRL_SK_AUTO", 0);
         const long long t = cfg_blocks(T128x128, M, N);
         if (sk >= 1 && t == kNumCU / 2 && nq >= 64) { cfg = T128x128; splits = 2; kg = 2; return; }
         if (sk >= 2 && t == kNumCU / 4 && nq >= 64) { cfg = T128x128; splits = 4; kg = 2; return; }
