@@ -208,6 +208,7 @@ def test_planes_kernel_bit_identical_to_register_staged(shape, cfg, kg, monkeypa
     BatchNorm partials of the forward epilogue, data gradients (plain and accumulating) and the BatchNorm-backward sums of the dgrad epilogue are
     BIT-identical.  The planes themselves are checked against the split the register-staged kernel performs (hi = f16(x 2^e), lo = f16(x 2^e - hi))."""
     N, C, H, W, K, R, stride, pad, dil = shape
+    monkeypatch.setenv('DSRL_PLANES', '1')       # this test hands planes over explicitly, whatever DSRL_PLANES_MODE the suite runs under
     if cfg is not None:
         monkeypatch.setenv('DSRL_FORCE_CFG', str(cfg))
     if kg:
@@ -344,6 +345,7 @@ def test_one_plane_operands_bit_identical_to_f16x1_register_staged(shape, cfg, k
     the register-staged f16x1 kernel rounds to while staging - so forward and data gradient are BIT-identical to it for the same plan; deeper LDS rings
     (4 slots for the 64x64 / four-group and the 128x128 tiles, 3 for 256x256).  Against fp64: the 11-bit tolerance of the arithmetic."""
     N, C, H, W, K, R, stride, pad, dil = shape
+    monkeypatch.setenv('DSRL_PLANES', '1')
     if cfg is not None:
         monkeypatch.setenv('DSRL_FORCE_CFG', str(cfg))
     rs = np.random.RandomState(sum(shape) + 1)
