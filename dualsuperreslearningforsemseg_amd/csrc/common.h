@@ -23,6 +23,11 @@ int launch_status(const char* what);
 // Binds the calling thread to the device that owns `stream` (autograd runs backward on its own thread).
 int bind_stream_device(hipStream_t s);
 
+// convt_dma.hip: ConvTranspose2d k2 s2 backward staged by LDS-DMA (19 -> 19 channels, W % 128 == 0)
+bool convt_bwd_dma_supported(const void* x, const void* dy, int W, int Cin, int Cout);
+int convt_bwd_dma_blocks(long long nseg, int cap);
+int launch_convt_bwd_dma(const float* x, const float* w, const float* dy, float* dx, float* part, int N, int H, int W, int nblocks, hipStream_t st);
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 

@@ -1112,6 +1112,12 @@ extern "C" int dsrl_convt2x2_bwd(const float* x, const float* w, const float* dy
     const int nseg_per_row2 = (int)ceil_div(W, 128);
     const long long nseg2 = (long long)N * H * nseg_per_row2;
     const int nb2 = (int)std::min<long long>(nb, nseg2);
+    if (mfma && convt_bwd_dma_supported(x, dy, W, Cin, Cout)) {            // LDS-DMA staging, one block per CU (convt_dma.hip)
+        const int nb3 = convt_bwd_dma_blocks(nseg2, nb);
+        if (int e = launch_convt_bwd_dma(x, w, dy, dx, (float*)ws, N, H, W, nb3, st)) return e;
+        hipLaunchKernelGGL((convt2x2_dw_finalize_kernel<19, 19>), dim3((unsigned)ceil_div(19 * 19 * 4 + 19, 32)), dim3(256), 0, st, (const float*)ws, nb3, dw, dbias);
+        return launch_status("convt2x2_dw_finalize_kernel");
+    }
 #define DSRL_CONVT_BWD_BODY                                                                                                         \
     if (mfma) {                                                                                                                     \
         hipLaunchKernelGGL((convt2x2_bwd_mfma_kernel<CI, CO>), dim3(nb2), dim3(256), 0, st, x, w, dy, dx, (float*)ws, N, H, W, nseg_per_row2, (int)nseg2); \

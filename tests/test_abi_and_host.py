@@ -152,24 +152,30 @@ def test_bn_fused_block_budget_roundtrip():
     assert HF.set_bn_fused_max_blocks(first if first >= 0 else None) == -1
 
 
-def test_lds_dma_inline_asm_is_the_only_m0_user(tmp_path):
-    """conv_planes.hip sets M0 inside inline asm without declaring it (hipcc refuses "m0" as a clobber: reserved register).  That is sound only while
-    nothing else in that code object touches M0: disassemble it and require every instruction that names m0 to be one of those s_mov_b32."""
+@pytest.mark.parametrize('unit,least', [('conv_planes', 100), ('convt_dma', 10)])
+def test_lds_dma_inline_asm_is_the_only_m0_user(tmp_path, unit, least):
+    """lds_dma.h sets M0 inside inline asm without declaring it (hipcc refuses "m0" as a clobber: reserved register).  That is sound only while
+    nothing else in the code objects that include it touches M0: disassemble them and require every instruction that names m0 to be one of those
+    s_mov_b32."""
     import shutil, subprocess
     objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
-    obj = os.path.join(ROOT, 'dualsuperreslearningforsemseg_amd', 'csrc', 'conv_planes.o')
+    obj = os.path.join(ROOT, 'dualsuperreslearningforsemseg_amd', 'csrc', unit + '.o')
     if not (os.path.isfile(objdump) and os.path.isfile(obj)):
         pytest.skip('needs llvm-objdump and the in-tree object file')
-    local = tmp_path / 'conv_planes.o'
+    local = tmp_path / (unit + '.o')
     shutil.copy(obj, local)
     subprocess.run([objdump, '--offloading', str(local)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp_path)
     dev = [p for p in os.listdir(tmp_path) if 'gfx950' in p]
     assert len(dev) == 1, os.listdir(tmp_path)
     asm = subprocess.run([objdump, '-d', str(tmp_path / dev[0])], check=True, capture_output=True, text=True).stdout
     users = [ln.split('//')[0].split() for ln in asm.splitlines() if re.search(r'\bm0\b', ln.split('//')[0])]
-    assert len(users) > 100                                   # the DMA pieces are there
+    assert len(users) > least                                 # the DMA pieces are there
     odd = [u for u in users if not (u[0] == 's_mov_b32' and u[1] == 'm0,' and re.fullmatch(r's\d+', u[2]))]
     assert not odd, odd[:5]
+    # and no other translation unit of the library includes the helper
+    for src in os.listdir(os.path.dirname(obj)):
+        if src.endswith('.hip') and src[:-4] not in ('conv_planes', 'convt_dma'):
+            assert 'lds_dma.h' not in open(os.path.join(os.path.dirname(obj), src)).read(), src
 
 
 def test_no_new_register_spills():

@@ -589,6 +589,30 @@ def test_convT_vs_oracle_ragged(shape, mfma, monkeypatch):
         check(a, c, 1e-5)
 
 
+@pytest.mark.parametrize('shape,cap', [((1, 19, 3, 128), 0), ((2, 19, 5, 256), 3), ((2, 19, 9, 384), 2), ((3, 19, 4, 128), 5)])
+def test_convT_backward_lds_dma_vs_oracle_and_register_staged(shape, cap, monkeypatch):
+    # convt_dma.hip (W % 128 == 0, 19 -> 19): segments staged by LDS-DMA into a three-slot ring, one block per CU.  Against the fp64 oracle, and
+    # bit-identical to convt2x2_bwd_mfma_kernel when both walk the segments with the same number of blocks (same MFMA order within a segment, same
+    # segments per block, same merge).  cap = blocks allowed: 3 blocks for 20 segments / 2 for 54 wrap the ring many times, 5 for 12 leaves blocks
+    # with 3 and with 2 segments (the tail of the counted waits), cap 0 = one segment per block.
+    rs = np.random.RandomState(sum(shape))
+    C = shape[1]
+    if cap:
+        monkeypatch.setenv('DSRL_CONVT_MAX_BLOCKS', str(cap))
+    x = rs.standard_normal(shape).astype(np.float32); w = rs.standard_normal((C, C, 2, 2)).astype(np.float32); b = rs.standard_normal(C).astype(np.float32)
+    dy = rs.standard_normal((shape[0], C, 2 * shape[2], 2 * shape[3])).astype(np.float32)
+    dxo, dwo, dbo = O.conv_transpose2d_k2s2_bwd(x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64), has_bias=True)
+    grads = {}
+    for dma in ('1', '0'):
+        monkeypatch.setenv('DSRL_CONVT_DMA', dma)
+        xt = dev(x).requires_grad_(True); wt = dev(w, cl=False).requires_grad_(True); bt = dev(b).requires_grad_(True)
+        HF.conv_transpose2d_k2s2(xt, wt, bt).backward(dev(dy))
+        check(host(xt.grad), dxo, 1e-5); check(host(wt.grad), dwo, 1e-5); check(host(bt.grad), dbo, 1e-5)
+        grads[dma] = (xt.grad, wt.grad, bt.grad)
+    for a, c in zip(grads['1'], grads['0']):
+        assert torch.equal(a, c)
+
+
 @pytest.mark.parametrize('name', ['up2', 'up4', 'up_bcast', 'up_odd'])
 def test_bilinear_golden(golden, name):
     g = golden('ops_micro')
