@@ -97,6 +97,11 @@ PROTOTYPES = {
     'dsrl_convt2x2_fwd': (i32, [fp, fp, fp, fp, i32, i32, i32, i32, i32, stream_t]),
     'dsrl_convt2x2_bwd_workspace_bytes': (sz, [i32] * 5),
     'dsrl_convt2x2_bwd': (i32, [fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, fp, sz, stream_t]),
+    'dsrl_convt2x2_fwd_ce_supported': (i32, [fp, fp, i32, i32, i32, i32, i32]),
+    'dsrl_convt2x2_fwd_ce_workspace_bytes': (sz, [i32, i32, i32]),
+    'dsrl_convt2x2_fwd_ce': (i32, [fp, fp, fp, fp, i32, i32, i32, i32, i32, fp, i32, fp, fp, fp, sz, stream_t]),
+    'dsrl_convt2x2_bwd_ce_supported': (i32, [fp, fp, fp, i32, i32, i32, i32, i32]),
+    'dsrl_convt2x2_bwd_ce': (i32, [fp, fp, fp, fp, i32, fp, fp, fp, i32, fp, fp, fp, i32, i32, i32, i32, i32, fp, sz, stream_t]),
     'dsrl_pixel_shuffle_fwd': (i32, [fp, fp, i32, i32, i32, i32, i32, stream_t]),
     'dsrl_pixel_shuffle_bwd': (i32, [fp, fp, i32, i32, i32, i32, i32, stream_t]),
     'dsrl_pointwise_strided_fwd': (i32, [fp, fp, fp, i32, i32, i32, i32, i32, stream_t]),

@@ -134,7 +134,12 @@ class TrainStep:
         cuts = None
         try:
             with t.set_grad_enabled(do_train):
-                outs = self.model(input_image)                                             # :420
+                if self.fused_losses and do_train:
+                    # the layer that produces the logits evaluates the CE value in its own forward kernel (HF.logits_target), :435
+                    with HF.logits_target(target if target.dtype == t.uint8 and target.is_contiguous() else None, self.ignore, self.flag):
+                        outs = self.model(input_image)                                     # :420
+                else:
+                    outs = self.model(input_image)                                         # :420
                 if self.fused_losses:
                     # CE + MSE + FA, their gradients, the NaN asserts (:426-433) and the loss mix (:435-438) in one launch set
                     vals = HF.fused_losses(outs, target, input_org, self.ignore, self.w1, self.w2, self.stage, self.flag, self.fa.subsample_factor)

@@ -27,6 +27,8 @@ int bind_stream_device(hipStream_t s);
 bool convt_bwd_dma_supported(const void* x, const void* dy, int W, int Cin, int Cout);
 int convt_bwd_dma_blocks(long long nseg, int cap);
 int launch_convt_bwd_dma(const float* x, const float* w, const float* dy, float* dx, float* part, int N, int H, int W, int nblocks, hipStream_t st);
+int launch_convt_bwd_dma_ce(const float* x, const float* w, const float* logits, float* dx, float* part, int N, int H, int W, int nblocks,
+                            const unsigned char* target, int ignore_index, const float* count, const float* ft_g, const float* ft_w, int ft_s, hipStream_t st);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
@@ -57,6 +59,20 @@ __device__ inline float philox_uniform(uint64_t e, uint64_t seed, uint32_t strea
     const uint64_t q = e >> 2;
     philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
     return (float)(r[e & 3] >> 8) * 5.9604644775390625e-08f;
+}
+
+// ---------------------------------------------------------------- exp(x) for x <= 0 (softmax terms exp(v - max))
+// v_exp_f32 on t = fl(x * log2 e) with the rounding error of that product and the low part of log2 e put back to first order:
+// exp(x) = 2^t * 2^r, r = (x * L2E_HI - t) + x * L2E_LO exactly (one fma each), 2^r = 1 + r ln 2 + O(r^2), |r| < 2^-23 |t|.  Six instructions instead
+// of libm's ~20 (range reduction + polynomial + overflow / denormal cases, none of which a non-positive argument needs); within 2 ulp of expf for
+// x in [-87, 0], 0 below (the hardware flushes the denormal result).  ce_fused_kernel and the ConvTranspose backward that forms the CE gradient
+// itself (convt_dma.hip) both use it: their results are bit-identical.
+__device__ __forceinline__ float exp_nonpos(float x) {
+    constexpr float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f, LN2 = 0.693147182464599609375f;
+    const float t = x * L2E_HI;
+    const float r = fmaf(x, L2E_LO, fmaf(x, L2E_HI, -t));
+    const float e0 = __builtin_amdgcn_exp2f(t);
+    return fmaf(e0, r * LN2, e0);
 }
 
 // ---------------------------------------------------------------- wave / block reductions

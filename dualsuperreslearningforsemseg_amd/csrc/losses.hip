@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const float* __restrict__
             for (int c = 1; c < C; ++c) m = fmaxf(m, v[c]);
             const float vt = v[max(min(tg == ignore_index ? 0 : tg, C - 1), 0)];
             float s = 0.f;
-            for (int c = 0; c < C; ++c) { const float e = expf(v[c] - m); s += e; v[c] = e; }       // the tile keeps exp(v - m): one expf per logit
+            for (int c = 0; c < C; ++c) { const float e = exp_nonpos(v[c] - m); s += e; v[c] = e; }       // the tile keeps exp(v - m): one exp per logit
             bad |= !(s == s);                   // any NaN logit poisons the sum (fmaxf alone would skip it)
             if (tg != ignore_index) {
                 loss += (double)(m + logf(s) - vt);
@@ -663,6 +663,10 @@ extern "C" int dsrl_mse_bwd(const float* a, const float* b, int64_t n, const flo
     return launch_status("mse_bwd_kernel");
 }
 
+int launch_ce_finalize(const double* part, int nb, float* loss_out, hipStream_t st) {       // for dsrl_convt2x2_fwd_ce (spatial.hip)
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, part, nb, loss_out);
+    return launch_status("ce_finalize_kernel");
+}
 extern "C" size_t dsrl_ce_fused_workspace_bytes(int64_t P) { return (size_t)2 * loss_blocks(P) * sizeof(double) + kCountBlocks * sizeof(unsigned); }
 extern "C" int dsrl_ce_fused(const float* logits, int ld, const uint8_t* target, int64_t P, int C, int ignore_index, float* dlogits, int lddl,
                              float* loss_out, int* nan_flag, void* ws, size_t ws_bytes, dsrl_stream_t stream) {

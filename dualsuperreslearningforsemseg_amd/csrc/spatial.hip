@@ -340,10 +340,15 @@ __global__ __launch_bounds__(256) void convt2x2_fwd_kernel(const float* __restri
 // the bias against a column of ones in X - v_mfma_f32_32x32x2_f32 (exact fp32 products).  A block walks row segments of 128 input pixels (grid-stride, the
 // next segment's input in flight); a wave forms the [32 px x 4*CO] tile of its pixels in 3 x 10 MFMAs (CI = CO = 19; the filter sits in 30 registers),
 // the tile goes through LDS in the [px][tap][co] order in which BOTH output rows are contiguous, and leaves as 16-byte stores.
+// CE = true (dsrl_convt2x2_fwd_ce): y is the logits of nn.CrossEntropyLoss(ignore_index) and `ce.target` is known: every thread also evaluates the
+// loss of two output pixels from the tile in LDS (max, exp, sum, log in ce_fused_kernel's arithmetic; NaN logit -> flag bit 0, label outside
+// [0, CO) -> NaN loss + flag bit 1) while the tile is being stored: the 319 MB read of a loss pass of its own disappears.  Per-block partials
+// (sum of the pixel losses, number of pixels that count) as two doubles in ce.part; ce_finalize_kernel merges them.
+struct ConvtFwdCe { const unsigned char* target; double* part; int* nan_flag; int ignore_index; };
 using f32x16_f = __attribute__((ext_vector_type(16))) float;
-template <int CI, int CO>
+template <int CI, int CO, bool CE = false>
 __global__ __launch_bounds__(256, 2) void convt2x2_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                                 float* __restrict__ y, int N, int H, int W, int nseg_per_row, int nseg) {
+                                                                 float* __restrict__ y, int N, int H, int W, int nseg_per_row, int nseg, ConvtFwdCe ce) {
     constexpr int TP = 128, COLS = 4 * CO, GS = COLS + 1, NK = (CI + 2) / 2, XS = 2 * NK, NJ = (COLS + 31) / 32;
     static_assert(CI + 1 <= XS && NJ <= 3 && (TP * CI) % 4 == 0 && (2 * TP * CO) % 4 == 0, "tile does not fit");
     constexpr int XV = TP * CI / 4, DV = 2 * TP * CO / 4;                   // float4 per x segment / per output row segment
@@ -376,13 +381,15 @@ __global__ __launch_bounds__(256, 2) void convt2x2_fwd_mfma_kernel(const float* 
         }
     };
     const int px0 = 32 * wv;
+    double ce_loss = 0.0, ce_cnt = 0.0;
+    bool ce_bad = false, ce_bad_label = false;
     int seg = (int)blockIdx.x;
     if (seg < nseg) gload(seg);
     for (; seg < nseg; seg += (int)gridDim.x) {
         const int row = seg / nseg_per_row;
         const int w0 = (seg - row * nseg_per_row) * TP, npx = min(TP, W - w0);
         const int n = row / H, h = row - n * H;
-        __syncthreads();                        // the previous segment's stores have read buf
+        __syncthreads();                        // the previous segment's stores (and loss reads) are done with buf
 #pragma unroll
         for (int k = 0; k < XR; ++k)
             if (tid + 256 * k < XV) { const int t = 4 * (tid + 256 * k); xa[xword(t)] = RX[k].x; xa[xword(t + 1)] = RX[k].y; xa[xword(t + 2)] = RX[k].z; xa[xword(t + 3)] = RX[k].w; }
@@ -416,6 +423,41 @@ __global__ __launch_bounds__(256, 2) void convt2x2_fwd_mfma_kernel(const float* 
                     const u32x4 v = {__float_as_uint(b[dword(t)]), __float_as_uint(b[dword(t + 1)]), __float_as_uint(b[dword(t + 2)]), __float_as_uint(b[dword(t + 3)])};
                     __builtin_amdgcn_raw_buffer_store_b128(v, i == 0 ? r0 : r1, (int)((unsigned)(tid + 256 * k) * 16u), 0, 0);     // past a ragged segment's end: dropped
                 }
+        if (CE) {
+#pragma unroll 1
+            for (int u = 0; u < 2; ++u) {
+                const int o = tid + 256 * u, px = o >> 2, tap = o & 3;             // output pixel (2h + (tap >> 1), 2 (w0 + px) + (tap & 1))
+                if (px >= npx) continue;
+                const int tg = ce.target[((long long)(n * 2 * H + 2 * h + (tap >> 1))) * (2 * W) + 2 * (w0 + px) + (tap & 1)];
+                const float* v = buf + px * GS + tap * CO;
+                ce_bad_label |= tg != ce.ignore_index && tg >= CO;
+                float m = v[0];
+#pragma unroll
+                for (int c = 1; c < CO; ++c) m = fmaxf(m, v[c]);
+                const float vt = v[min(tg == ce.ignore_index ? 0 : tg, CO - 1)];
+                float sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) sum += exp_nonpos(v[c] - m);
+                ce_bad |= !(sum == sum);            // any NaN logit poisons the sum (fmaxf alone would skip it)
+                if (tg != ce.ignore_index) { ce_loss += (double)(m + logf(sum) - vt); ce_cnt += 1.0; }
+            }
+        }
+    }
+    if (CE) {
+        __shared__ double shd[4];
+        if (ce_bad_label) ce_loss = __builtin_nan("");
+        double l = wave_sum_d(ce_loss), c = wave_sum_d(ce_cnt);
+        __syncthreads();
+        if (lane == 0) shd[wv] = l;
+        __syncthreads();
+        l = shd[0] + shd[1] + shd[2] + shd[3];
+        __syncthreads();
+        if (lane == 0) shd[wv] = c;
+        __syncthreads();
+        c = shd[0] + shd[1] + shd[2] + shd[3];
+        if (tid == 0) { ce.part[2 * blockIdx.x] = l; ce.part[2 * blockIdx.x + 1] = c; }
+        if (ce.nan_flag && __any(ce_bad) && lane == 0) atomicOr(ce.nan_flag, 1);
+        if (ce.nan_flag && __any(ce_bad_label) && lane == 0) atomicOr(ce.nan_flag, 2);
     }
 }
 
@@ -961,6 +1003,7 @@ __global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float* __restr
             const long long o = ((long long)(n * H + ho * s) * W + wo * s) * C + c;
             const float g = dy[e];
             acc = fmaf(g, x[o], acc);
+            if (accumulate == 2) continue;          // dw only: the consumer of dy forms dx itself (dsrl_convt2x2_bwd_ce)
             if (accumulate) dx[o] += g * wc; else dx[o] = g * wc;
         }
         sh[threadIdx.x] = acc;
@@ -1084,14 +1127,40 @@ extern "C" int dsrl_convt2x2_fwd(const float* x, const float* w, const float* bi
         const long long nseg = (long long)N * H * nseg_per_row;
         if ((!mv || atoi(mv) != 0) && W % 4 == 0 && nseg < (1ll << 31) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0) {
             const int nb = (int)std::min<long long>(nseg, convt_block_cap(4 * 512));
-            DSRL_CONVT_DISPATCH(19, 19, hipLaunchKernelGGL((convt2x2_fwd_mfma_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, x, w, bias, y, N, H, W, nseg_per_row, (int)nseg); return launch_status("convt2x2_fwd_mfma_kernel");)
-            DSRL_CONVT_DISPATCH(8, 8, hipLaunchKernelGGL((convt2x2_fwd_mfma_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, x, w, bias, y, N, H, W, nseg_per_row, (int)nseg); return launch_status("convt2x2_fwd_mfma_kernel");)
+            DSRL_CONVT_DISPATCH(19, 19, hipLaunchKernelGGL((convt2x2_fwd_mfma_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, x, w, bias, y, N, H, W, nseg_per_row, (int)nseg, ConvtFwdCe{}); return launch_status("convt2x2_fwd_mfma_kernel");)
+            DSRL_CONVT_DISPATCH(8, 8, hipLaunchKernelGGL((convt2x2_fwd_mfma_kernel<CI, CO>), dim3(nb), dim3(256), 0, st, x, w, bias, y, N, H, W, nseg_per_row, (int)nseg, ConvtFwdCe{}); return launch_status("convt2x2_fwd_mfma_kernel");)
         }
     }
     DSRL_CONVT_DISPATCH(19, 19, hipLaunchKernelGGL((convt2x2_fwd_kernel<CI, CO>), grid, dim3(256), 0, st, x, w, bias, y, N, H, W); return launch_status("convt2x2_fwd_kernel");)
     DSRL_CONVT_DISPATCH(8, 8, hipLaunchKernelGGL((convt2x2_fwd_kernel<CI, CO>), grid, dim3(256), 0, st, x, w, bias, y, N, H, W); return launch_status("convt2x2_fwd_kernel");)
     set_error("convt2x2_fwd: channel counts %d->%d not instantiated (19->19, 8->8)", Cin, Cout);
     return DSRL_E_UNSUPPORTED;
+}
+// ce_finalize_kernel lives in losses.hip
+int launch_ce_finalize(const double* part, int nb, float* loss_out, hipStream_t st);
+extern "C" int dsrl_convt2x2_fwd_ce_supported(const float* x, const float* y, int N, int H, int W, int Cin, int Cout) {
+    const char* v = getenv("DSRL_CONVT_CE");
+    const char* mv = getenv("DSRL_CONVT_MFMA");
+    if ((v && atoi(v) == 0) || (mv && atoi(mv) == 0)) return 0;
+    return (x && y && N > 0 && H > 0 && W > 0 && Cin == 19 && Cout == 19 && W % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+            (long long)N * H * ceil_div(W, 128) < (1ll << 31)) ? 1 : 0;
+}
+extern "C" size_t dsrl_convt2x2_fwd_ce_workspace_bytes(int N, int H, int W) {
+    return (size_t)std::min<long long>((long long)N * H * ceil_div(W, 128), convt_block_cap(4 * 512)) * 2 * sizeof(double);
+}
+extern "C" int dsrl_convt2x2_fwd_ce(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Cout,
+                                    const uint8_t* target, int ignore_index, float* loss_out, int* nan_flag, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(x && w && y && target && loss_out && ws && N > 0 && H > 0 && W > 0 && ((uintptr_t)ws % 8) == 0, "convt2x2_fwd_ce")
+    DSRL_REQUIRE(dsrl_convt2x2_fwd_ce_supported(x, y, N, H, W, Cin, Cout), DSRL_E_UNSUPPORTED,
+                 "convt2x2_fwd_ce: needs 19 -> 19 channels, W %% 4 == 0, 16-byte aligned tensors (got %d -> %d, W = %d) and DSRL_CONVT_MFMA / DSRL_CONVT_CE not 0", Cin, Cout, W);
+    DSRL_REQUIRE(ws_bytes >= dsrl_convt2x2_fwd_ce_workspace_bytes(N, H, W), DSRL_E_WORKSPACE, "convt2x2_fwd_ce: workspace too small");
+    const int nseg_per_row = (int)ceil_div(W, 128);
+    const long long nseg = (long long)N * H * nseg_per_row;
+    const int nb = (int)std::min<long long>(nseg, convt_block_cap(4 * 512));
+    ConvtFwdCe ce{target, (double*)ws, nan_flag, ignore_index};
+    hipLaunchKernelGGL((convt2x2_fwd_mfma_kernel<19, 19, true>), dim3(nb), dim3(256), 0, st, x, w, bias, y, N, H, W, nseg_per_row, (int)nseg, ce);
+    if (int e = launch_status("convt2x2_fwd_mfma_kernel")) return e;
+    return launch_ce_finalize((const double*)ws, nb, loss_out, st);
 }
 static bool env_flag_convt_fused() { const char* v = getenv("DSRL_CONVT_FUSED_BWD"); return !v || atoi(v) != 0; }   // 0: the separate dx / dw kernels
 static int convt_dw_blocks(int N, int H, int W) { return (int)std::min<long long>(convt_block_cap(1024), (long long)N * H * ceil_div(W, 64)); }
@@ -1112,7 +1181,7 @@ extern "C" int dsrl_convt2x2_bwd(const float* x, const float* w, const float* dy
     const int nseg_per_row2 = (int)ceil_div(W, 128);
     const long long nseg2 = (long long)N * H * nseg_per_row2;
     const int nb2 = (int)std::min<long long>(nb, nseg2);
-    if (mfma && convt_bwd_dma_supported(x, dy, W, Cin, Cout)) {            // LDS-DMA staging, one block per CU (convt_dma.hip)
+    if (mfma && convt_bwd_dma_supported(x, dy, W, Cin, Cout) && (long long)N * 4 * H * W * Cout * 4 < (1ll << 32)) {            // LDS-DMA staging, one block per CU (convt_dma.hip)
         const int nb3 = convt_bwd_dma_blocks(nseg2, nb);
         if (int e = launch_convt_bwd_dma(x, w, dy, dx, (float*)ws, N, H, W, nb3, st)) return e;
         hipLaunchKernelGGL((convt2x2_dw_finalize_kernel<19, 19>), dim3((unsigned)ceil_div(19 * 19 * 4 + 19, 32)), dim3(256), 0, st, (const float*)ws, nb3, dw, dbias);
@@ -1144,6 +1213,26 @@ extern "C" int dsrl_convt2x2_bwd(const float* x, const float* w, const float* dy
     DSRL_CONVT_DISPATCH(8, 8, DSRL_CONVT_BWD_BODY)
     set_error("convt2x2_bwd: channel counts %d->%d not instantiated (19->19, 8->8)", Cin, Cout);
     return DSRL_E_UNSUPPORTED;
+}
+
+extern "C" int dsrl_convt2x2_bwd_ce_supported(const float* x, const float* logits, const uint8_t* target, int N, int H, int W, int Cin, int Cout) {
+    const char* v = getenv("DSRL_CONVT_CE");
+    if (v && atoi(v) == 0) return 0;
+    return (x && logits && target && N > 0 && H > 0 && convt_bwd_dma_supported(x, logits, W, Cin, Cout) && ((uintptr_t)target % 16) == 0 &&
+            (long long)N * H * (W / 128) < (1ll << 31) && (long long)N * 4 * H * W * Cout * 4 < (1ll << 32)) ? 1 : 0;
+}
+extern "C" int dsrl_convt2x2_bwd_ce(const float* x, const float* w, const float* logits, const uint8_t* target, int ignore_index, const float* ce_count,
+                                    const float* ft_g, const float* ft_w, int ft_stride, float* dx, float* dw, float* dbias,
+                                    int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(x && w && logits && target && ce_count && dx && dw && ws && N > 0 && H > 0 && W > 0 && (!ft_g || (ft_w && ft_stride > 0)), "convt2x2_bwd_ce")
+    DSRL_REQUIRE(dsrl_convt2x2_bwd_ce_supported(x, logits, target, N, H, W, Cin, Cout), DSRL_E_UNSUPPORTED,
+                 "convt2x2_bwd_ce: needs 19 -> 19 channels, W %% 128 == 0, 16-byte aligned tensors (got %d -> %d, W = %d) and DSRL_CONVT_DMA / DSRL_CONVT_CE not 0", Cin, Cout, W);
+    DSRL_REQUIRE(ws_bytes >= dsrl_convt2x2_bwd_workspace_bytes(N, H, W, Cin, Cout), DSRL_E_WORKSPACE, "convt2x2_bwd_ce: workspace too small");
+    const long long nseg = (long long)N * H * (W / 128);
+    const int nb3 = convt_bwd_dma_blocks(nseg, convt_dw_blocks(N, H, W));
+    if (int e = launch_convt_bwd_dma_ce(x, w, logits, dx, (float*)ws, N, H, W, nb3, target, ignore_index, ce_count, ft_g, ft_w, ft_stride, st)) return e;
+    hipLaunchKernelGGL((convt2x2_dw_finalize_kernel<19, 19>), dim3((unsigned)ceil_div(19 * 19 * 4 + 19, 32)), dim3(256), 0, st, (const float*)ws, nb3, dw, dbias);
+    return launch_status("convt2x2_dw_finalize_kernel");
 }
 
 static size_t pixel_shuffle_tile_bytes(int c, int r) { return (size_t)kPsTile * c * (r * r + 1) * sizeof(float); }
@@ -1184,7 +1273,8 @@ extern "C" size_t dsrl_pointwise_strided_bwd_workspace_bytes(int N, int H, int W
 }
 extern "C" int dsrl_pointwise_strided_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int accumulate,
                                           int N, int H, int W, int C, int stride, void* ws, size_t ws_bytes, dsrl_stream_t stream) {
-    DSRL_PROLOGUE(x && w && dy && dx && dw && ws && N > 0 && H > 0 && W > 0 && C > 0 && stride > 0, "pointwise_strided_bwd")
+    DSRL_PROLOGUE(x && w && dy && (dx || accumulate == 2) && dw && ws && N > 0 && H > 0 && W > 0 && C > 0 && stride > 0 && accumulate >= 0 && accumulate <= 2,
+                  "pointwise_strided_bwd")
     DSRL_REQUIRE(ws_bytes >= dsrl_pointwise_strided_bwd_workspace_bytes(N, H, W, C, stride), DSRL_E_WORKSPACE, "pointwise_strided_bwd: workspace too small");
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     if (!accumulate) {

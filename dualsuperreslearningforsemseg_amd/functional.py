@@ -1191,9 +1191,61 @@ def cat_channels(xs):
 
 
 # ------------------------------------------------------------------------------------------------ ConvTranspose k2s2 / PixelShuffle / pointwise
+convt_ce_enabled = os.environ.get('DSRL_CONVT_CE', '1') != '0'
+
+
+class LogitsGrad:
+    """Hand-over between the layer that produces the logits (the last ConvTranspose2d of the SSSR decoder, DSRL.py:64-69) and the loss that is the
+    root of the backward pass (fused_losses).  When the loss finds this object on its logits and the shape qualifies, it computes only the CE VALUE,
+    leaves `target`, `count` (device pointer holder) here and reports no gradient; the stride-8 feature transformer leaves its incoming gradient and
+    weights; the ConvTranspose backward then forms d(CE)/d(logits) (+ the transformer's rank-one term) inside its own kernel
+    (dsrl_convt2x2_bwd_ce): the 319 MB gradient of the 256x512 step is neither written nor read."""
+    __slots__ = ('y', 'xshape', 'x_ptr', 'armed', 'target', 'ignore_index', 'count', 'ft', 'value', 'value_key')
+
+    def __init__(self):
+        self.y = None; self.xshape = None; self.x_ptr = 0; self.armed = False; self.target = None; self.ignore_index = 255; self.count = None; self.ft = None
+        self.value = None           # [CE, pixel count, ...] when the producing layer already evaluated the loss (logits_target), and for which
+        self.value_key = None       # (target pointer, ignore_index, NaN flag pointer)
+
+    def usable(self, logits, target):
+        """Can the loss leave the gradient to the producer?  logits must be exactly the producer's output buffer."""
+        if not (convt_ce_enabled and self.y is not None and logits.data_ptr() == self.y.data_ptr() and tuple(logits.shape) == tuple(self.y.shape)):
+            return False
+        N, Ci, H, W = self.xshape
+        return bool(cquery('dsrl_convt2x2_bwd_ce_supported', self.x_ptr, logits.data_ptr(), target.data_ptr(), N, H, W, Ci, logits.shape[1]))
+
+
+
+_logits_target = None
+
+
+class logits_target:
+    """with logits_target(target, ignore_index, flag): ... model(x) ... - tells the layer that produces the logits (HipConvTranspose2d.logits_layer) what
+    they will be compared with, so that its forward kernel evaluates nn.CrossEntropyLoss while the output tile is on chip (dsrl_convt2x2_fwd_ce) and
+    fused_losses finds the value ready (LogitsGrad.value) instead of reading the logits again.  target: (N,H,W) uint8, contiguous; flag: the int32 NaN
+    flag fused_losses will be given.  Outside the block, or when the shape does not qualify, nothing changes."""
+
+    def __init__(self, target, ignore_index, flag):
+        ok = (convt_ce_enabled and target is not None and target.is_cuda and target.dtype == torch.uint8 and target.is_contiguous() and target.dim() == 3
+              and flag is not None and flag.dtype == torch.int32)
+        self.new = (target, int(ignore_index), flag) if ok else None
+
+    def __enter__(self):
+        global _logits_target
+        self.old, _logits_target = _logits_target, self.new
+        return self
+
+    def __exit__(self, *exc):
+        global _logits_target
+        _logits_target = self.old
+        return False
+
+
 class _ConvT2x2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, holder=None):
+        ctx.set_materialize_grads(False)        # dy is None when the loss left its gradient to this layer (LogitsGrad)
+        ctx.holder = holder
         x = pm_dense(x)
         _need_gpu(w, bias)
         w_param = w
@@ -1203,10 +1255,23 @@ class _ConvT2x2(torch.autograd.Function):
         if w.shape[0] != Ci or tuple(w.shape[2:]) != (2, 2):
             raise DsrlHipError(f'conv_transpose2d_k2s2: weight {tuple(w.shape)} does not match input channels {Ci}')
         y = new_cl((N, Co, 2 * H, 2 * W), x)
-        call('dsrl_convt2x2_fwd', x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), N, H, W, Ci, Co, _stream())
+        lt = _logits_target if holder is not None else None
+        if (lt is not None and tuple(lt[0].shape) == (N, 2 * H, 2 * W) and lt[0].device == x.device
+                and cquery('dsrl_convt2x2_fwd_ce_supported', x.data_ptr(), y.data_ptr(), N, H, W, Ci, Co)):
+            tgt, ign, flag = lt
+            holder.value = torch.empty(8, device=x.device, dtype=torch.float32)
+            holder.value_key = (tgt.data_ptr(), ign, flag.data_ptr())
+            ws = _ws(cquery('dsrl_convt2x2_fwd_ce_workspace_bytes', N, H, W), x)
+            call('dsrl_convt2x2_fwd_ce', x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), N, H, W, Ci, Co,
+                 tgt.data_ptr(), ign, holder.value.data_ptr(), flag.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+        else:
+            call('dsrl_convt2x2_fwd', x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), N, H, W, Ci, Co, _stream())
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.params = (w_param if isinstance(w_param, torch.nn.Parameter) else None, bias if isinstance(bias, torch.nn.Parameter) else None)
+        if holder is not None:
+            holder.y = y; holder.xshape = (N, Ci, H, W); holder.x_ptr = x.data_ptr()
+            y._dsrl_logits_grad = holder
         return y
 
     @staticmethod
@@ -1214,24 +1279,37 @@ class _ConvT2x2(torch.autograd.Function):
         x, w = ctx.saved_tensors
         N, Ci, H, W = x.shape
         Co = w.shape[1]
-        dy = pm_dense(dy)
+        h = ctx.holder
+        fused = dy is None and h is not None and h.armed
+        if dy is None and not fused:
+            raise DsrlHipError('conv_transpose2d_k2s2: backward reached without a gradient for the output')
+        if not fused:
+            dy = pm_dense(dy)
         dx = new_cl((N, Ci, H, W), x)
         wsink = _sink_flat(ctx.params[0], w.numel())
         bsink = _sink_flat(ctx.params[1], Co) if ctx.has_bias else None
         dw = wsink if wsink is not None else torch.empty_like(w)
         db = (bsink if bsink is not None else torch.empty(Co, device=x.device, dtype=torch.float32)) if ctx.has_bias else None
         ws = _ws(cquery('dsrl_convt2x2_bwd_workspace_bytes', N, H, W, Ci, Co), x)
-        call('dsrl_convt2x2_bwd', x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(),
-             N, H, W, Ci, Co, ws.data_ptr(), ws.numel(), _stream())
+        if fused:
+            ft_g, ft_w, ft_s = h.ft if h.ft is not None else (None, None, 0)
+            call('dsrl_convt2x2_bwd_ce', x.data_ptr(), w.data_ptr(), h.y.data_ptr(), h.target.data_ptr(), int(h.ignore_index), h.count.data_ptr() + 4,
+                 None if ft_g is None else ft_g.data_ptr(), None if ft_w is None else ft_w.data_ptr(), int(ft_s),
+                 dx.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(), N, H, W, Ci, Co, ws.data_ptr(), ws.numel(), _stream())
+            h.armed = False; h.ft = None; h.target = None; h.count = None; h.y = None; h.value = None
+        else:
+            call('dsrl_convt2x2_bwd', x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(),
+                 N, H, W, Ci, Co, ws.data_ptr(), ws.numel(), _stream())
         if wsink is not None:
             _sunk(ctx.params[0]); dw = None
         if bsink is not None:
             _sunk(ctx.params[1]); db = None
-        return dx, _deliver(ctx.params[0], dw), _deliver(ctx.params[1], db)
+        return dx, _deliver(ctx.params[0], dw), _deliver(ctx.params[1], db), None
 
 
-def conv_transpose2d_k2s2(x, weight, bias=None):
-    return _ConvT2x2.apply(x, weight, bias)
+def conv_transpose2d_k2s2(x, weight, bias=None, logits_grad=None):
+    """logits_grad: a LogitsGrad when this output may be the logits of fused_losses (see there); None otherwise."""
+    return _ConvT2x2.apply(x, weight, bias, logits_grad)
 
 
 class _PixelShuffle(torch.autograd.Function):
@@ -1264,6 +1342,7 @@ class _PointwiseStrided(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride, out_slot=None):
         ctx.out_slot = out_slot
+        ctx.logits_grad = getattr(x, '_dsrl_logits_grad', None)
         x = pm_dense(x)
         _need_gpu(w)
         N, Cc, H, W = x.shape
@@ -1288,6 +1367,19 @@ class _PointwiseStrided(torch.autograd.Function):
         # gradient it returned for x; our contribution lives on the stride grid only (1/64 of the pixels) and is added into that buffer
         # instead of being materialised as a mostly-zero tensor that autograd would then add with a full pass
         slot = ctx.out_slot
+        lg = ctx.logits_grad
+        if lg is not None and lg.armed and lg.y is not None and lg.y.data_ptr() == x.data_ptr() and lg.ft is None:
+            # the loss left d(loss)/d(x) to the layer that produced x (LogitsGrad): that kernel adds g * w on the stride grid itself
+            wsink = _sink_flat(ctx.wparam, Cc)
+            dw = wsink if wsink is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
+            ws = _ws(cquery('dsrl_pointwise_strided_bwd_workspace_bytes', N, H, W, Cc, ctx.stride), x)
+            call('dsrl_pointwise_strided_bwd', x.data_ptr(), wf.data_ptr(), dy.data_ptr(), None, dw.data_ptr(), 2,
+                 N, H, W, Cc, ctx.stride, ws.data_ptr(), ws.numel(), _stream())
+            lg.ft = (dy, wf, ctx.stride)
+            if wsink is not None:
+                _sunk(ctx.wparam)
+                return None, None, None, None
+            return None, _deliver(ctx.wparam, dw.view(ctx.wshape)), None, None
         acc = (slot is not None and not slot.closed and slot.buf is not None and tuple(slot.buf.shape) == (N, Cc, H, W)
                and _ld_of(slot.buf) == Cc)
         dx = slot.buf if acc else new_cl((N, Cc, H, W), x)
@@ -1394,10 +1486,16 @@ class _FusedLosses(torch.autograd.Function):
         dev = logits.device
         scal = torch.empty(8, device=dev, dtype=torch.float32)          # [0:2] CE + pixel count, [2] MSE
         vals = torch.empty(5, device=dev, dtype=torch.float32)
-        dl = new_cl((N, Cc, H, W), logits) if want else None
-        ws = _ws(cquery('dsrl_ce_fused_workspace_bytes', P), logits)
-        call('dsrl_ce_fused', logits.data_ptr(), ld, target.data_ptr(), P, Cc, int(ignore_index), None if dl is None else dl.data_ptr(), Cc,
-             scal.data_ptr(), flag.data_ptr(), ws.data_ptr(), ws.numel(), st)
+        lg = getattr(sssr, '_dsrl_logits_grad', None) if want else None
+        if lg is not None and not (ld == Cc and lg.usable(logits, target)):
+            lg = None
+        dl = new_cl((N, Cc, H, W), logits) if (want and lg is None) else None      # lg: the producer of the logits forms this gradient in its own backward
+        if lg is not None and lg.value is not None and lg.value_key == (target.data_ptr(), int(ignore_index), flag.data_ptr()):
+            scal = lg.value                                             # the producer's forward kernel evaluated the loss (logits_target)
+        else:
+            ws = _ws(cquery('dsrl_ce_fused_workspace_bytes', P), logits)
+            call('dsrl_ce_fused', logits.data_ptr(), ld, target.data_ptr(), P, Cc, int(ignore_index), None if dl is None else dl.data_ptr(), Cc,
+                 scal.data_ptr(), flag.data_ptr(), ws.data_ptr(), ws.numel(), st)
         da = None
         mse_ptr = fa_ptr = None
         ctx.fa = None
@@ -1425,6 +1523,9 @@ class _FusedLosses(torch.autograd.Function):
             fa_ptr = fa_out.data_ptr()
             ctx.fa = (ft1, ft2, saved, k, fa_out)
         call('dsrl_loss_mix', scal.data_ptr(), mse_ptr, fa_ptr, float(w1), float(w2), flag.data_ptr(), vals.data_ptr(), st)
+        if lg is not None:
+            lg.target = target; lg.ignore_index = int(ignore_index); lg.count = scal; lg.ft = None; lg.armed = True
+        ctx.lg = lg
         ctx.grads = (dl, da)
         ctx.w2 = float(w2)
         ctx.slots = (getattr(sssr, '_dsrl_out_slot', None), getattr(sisr, '_dsrl_out_slot', None) if stage > 1 else None)
@@ -1434,7 +1535,7 @@ class _FusedLosses(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dl, da = ctx.grads
-        if dl is None:
+        if dl is None and ctx.lg is None:
             raise DsrlHipError('fused_losses: backward without a gradient-enabled forward')
         # the gradients were written by the forward pass for d(total) = 1: a caller that scales the loss or differentiates another element would get
         # them unscaled.  Checked once per process (one host read), outside graph capture - the training step's own call pattern never changes.

@@ -42,6 +42,7 @@ class DSRL(BaseModel):
                                              HipConvTranspose2d(out_channels, out_channels, kernel_size=2, stride=2, padding=0, bias=True))})  # DSRL.py:53-69
         for (name, idx), stream in _DROPOUT_STREAMS.items():
             mods[name][idx].rng_stream = stream
+        mods['upsample16_pred'][6].logits_layer = True        # its output is SSSR_output: the CE gradient can be formed inside its backward (HF.LogitsGrad)
         return mods
 
     @staticmethod

@@ -73,7 +73,9 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
     def forward(self, x):
         if self.kernel_size != (2, 2) or self.stride != (2, 2) or self.padding != (0, 0) or self.output_padding != (0, 0) or self.groups != 1:
             raise HF.DsrlHipError('HipConvTranspose2d implements kernel_size=2, stride=2, padding=0 (DSRL.py:55-69)')
-        return HF.conv_transpose2d_k2s2(x, self.weight, self.bias)
+        # logits_layer (set by the model on the layer whose output goes to the loss): the loss may leave its gradient to this layer's backward
+        lg = HF.LogitsGrad() if (getattr(self, 'logits_layer', False) and HF.convt_ce_enabled and torch.is_grad_enabled() and x.requires_grad) else None
+        return HF.conv_transpose2d_k2s2(x, self.weight, self.bias, lg)
 
 
 class HipUpsamplingBilinear2d(nn.UpsamplingBilinear2d):

@@ -325,6 +325,26 @@ size_t dsrl_convt2x2_bwd_workspace_bytes(int N, int H, int W, int Cin, int Cout)
 int dsrl_convt2x2_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dbias /*nullable*/,
                       int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, dsrl_stream_t stream);
 
+/* dsrl_convt2x2_fwd that also evaluates nn.CrossEntropyLoss(ignore_index), mean reduction, of its output against `target` (N,2H,2W bytes) while the
+ * output tile is in LDS (DSRL.py:69 -> train_or_resume.py:435): loss_out[0] = the loss, loss_out[1] = the number of pixels that count, as
+ * dsrl_ce_fused writes them; nan_flag (nullable) bit 0 = NaN logit, bit 1 = label outside [0, Cout).  19 -> 19 channels, W % 4 == 0. */
+int dsrl_convt2x2_fwd_ce_supported(const float* x, const float* y, int N, int H, int W, int Cin, int Cout);
+size_t dsrl_convt2x2_fwd_ce_workspace_bytes(int N, int H, int W);
+int dsrl_convt2x2_fwd_ce(const float* x, const float* w, const float* bias /*nullable*/, float* y, int N, int H, int W, int Cin, int Cout,
+                         const uint8_t* target, int ignore_index, float* loss_out, int* nan_flag /*nullable*/, void* ws, size_t ws_bytes, dsrl_stream_t stream);
+
+/* The same backward when y IS the logits of nn.CrossEntropyLoss(ignore_index) with mean reduction (DSRL.py:69 feeds train_or_resume.py:435) and the
+ * loss is the root of the backward pass with unit gradient: dy = d(CE)/d(logits) is formed inside the kernel from `logits` (the forward output y),
+ * `target` (N,2H,2W bytes) and `ce_count` (the number of pixels that are not ignore_index, dsrl_ce_fused's loss_out[1]), in the arithmetic of
+ * dsrl_ce_fused, and never written to memory.  ft_g (nullable): the incoming gradient (N, ceil(2H/s), ceil(2W/s)) of the stride-s single-channel 1x1
+ * conv that also reads the logits (feature transformer, DSRL.py:88-93) and ft_w its Cout weights: g * w_c is added on the stride grid, as
+ * dsrl_pointwise_strided_bwd(accumulate = 1) would.  Results are bit-identical to dsrl_ce_fused -> dsrl_pointwise_strided_bwd -> dsrl_convt2x2_bwd.
+ * _supported: 1 when the shape can take this path (19 -> 19 channels, W % 128 == 0, 16-byte aligned tensors); otherwise use the three calls. */
+int dsrl_convt2x2_bwd_ce_supported(const float* x, const float* logits, const uint8_t* target, int N, int H, int W, int Cin, int Cout);
+int dsrl_convt2x2_bwd_ce(const float* x, const float* w, const float* logits, const uint8_t* target, int ignore_index, const float* ce_count,
+                         const float* ft_g /*nullable*/, const float* ft_w /*nullable*/, int ft_stride, float* dx, float* dw, float* dbias /*nullable*/,
+                         int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, dsrl_stream_t stream);
+
 /* nn.PixelShuffle(r) (DSRL.py:84): x (N,H,W,c*r*r) -> y (N,H*r,W*r,c) */
 int dsrl_pixel_shuffle_fwd(const float* x, float* y, int N, int H, int W, int c, int r, dsrl_stream_t stream);
 int dsrl_pixel_shuffle_bwd(const float* dy, float* dx, int N, int H, int W, int c, int r, dsrl_stream_t stream);
@@ -332,7 +352,7 @@ int dsrl_pixel_shuffle_bwd(const float* dy, float* dx, int N, int H, int W, int 
 /* 1x1 stride-s conv with a single output channel, no bias (feature transformers, DSRL.py:88-93) */
 int dsrl_pointwise_strided_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int stride, dsrl_stream_t stream);
 size_t dsrl_pointwise_strided_bwd_workspace_bytes(int N, int H, int W, int C, int stride);
-/* dx is fully written (zeros off the stride grid) when accumulate == 0, else dx += on the stride grid only */
+/* dx is fully written (zeros off the stride grid) when accumulate == 0, dx += on the stride grid only when 1; 2: dw only (dx may be null) */
 int dsrl_pointwise_strided_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int accumulate,
                                int N, int H, int W, int C, int stride, void* ws, size_t ws_bytes, dsrl_stream_t stream);
 

@@ -613,6 +613,119 @@ def test_convT_backward_lds_dma_vs_oracle_and_register_staged(shape, cap, monkey
         assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize('shape,cap,ft', [((1, 4, 128), 0, 8), ((2, 6, 256), 3, 8), ((2, 9, 384), 2, 0), ((3, 4, 128), 5, 4)])
+def test_convT_backward_with_cross_entropy_inside_bit_identical_to_three_calls(shape, cap, ft, monkeypatch):
+    # dsrl_convt2x2_bwd_ce: the ConvTranspose backward that forms d(CE)/d(logits) (+ the stride-s feature transformer's g * w_c) inside the kernel, against
+    # the three calls it replaces - dsrl_ce_fused (writes the gradient), dsrl_pointwise_strided_bwd(accumulate = 1), dsrl_convt2x2_bwd - bit for bit:
+    # dx, dw, db.  Ignored pixels (10 % + one whole row), block caps that make blocks walk many segments; and the CE gradient
+    # itself against the fp64 oracle through dx.
+    from dualsuperreslearningforsemseg_amd._lib import call, query
+    N, H, W = shape
+    C = 19
+    rs = np.random.RandomState(N * 1000 + H * 10 + W)
+    if cap:
+        monkeypatch.setenv('DSRL_CONVT_MAX_BLOCKS', str(cap))
+    x = torch.tensor(rs.standard_normal((N, H, W, C)).astype(np.float32), device=DEV)
+    w = torch.tensor(rs.standard_normal((C, C, 2, 2)).astype(np.float32), device=DEV)
+    logits = torch.tensor((rs.standard_normal((N, 2 * H, 2 * W, C)) * 3).astype(np.float32), device=DEV)
+    tg = rs.randint(0, C, (N, 2 * H, 2 * W)).astype(np.uint8); tg[rs.uniform(size=tg.shape) < 0.1] = 255; tg[0, 1, :] = 255
+    target = torch.tensor(tg, device=DEV)
+    P = N * 4 * H * W
+    st = HF._stream()
+    Hf, Wf = ((2 * H - 1) // ft + 1, (2 * W - 1) // ft + 1) if ft else (0, 0)
+    ftg = torch.tensor(rs.standard_normal((N, Hf, Wf)).astype(np.float32), device=DEV) if ft else None
+    ftw = torch.tensor(rs.standard_normal(C).astype(np.float32), device=DEV) if ft else None
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ws = torch.empty(query('dsrl_ce_fused_workspace_bytes', P), dtype=torch.uint8, device=DEV)
+    wsb = torch.empty(query('dsrl_convt2x2_bwd_workspace_bytes', N, H, W, C, C), dtype=torch.uint8, device=DEV)
+    assert query('dsrl_convt2x2_bwd_ce_supported', x.data_ptr(), logits.data_ptr(), target.data_ptr(), N, H, W, C, C) == 1
+    # the three calls
+    scal = torch.zeros(8, device=DEV); dl = torch.empty_like(logits)
+    call('dsrl_ce_fused', logits.data_ptr(), C, target.data_ptr(), P, C, 255, dl.data_ptr(), C, scal.data_ptr(), flag.data_ptr(), ws.data_ptr(), ws.numel(), st)
+    dl_ce = dl.clone()
+    if ft:
+        dwf = torch.empty(C, device=DEV)
+        wsf = torch.empty(query('dsrl_pointwise_strided_bwd_workspace_bytes', N, 2 * H, 2 * W, C, ft), dtype=torch.uint8, device=DEV)
+        call('dsrl_pointwise_strided_bwd', logits.data_ptr(), ftw.data_ptr(), ftg.data_ptr(), dl.data_ptr(), dwf.data_ptr(), 1, N, 2 * H, 2 * W, C, ft,
+             wsf.data_ptr(), wsf.numel(), st)
+        dwf2 = torch.empty(C, device=DEV)
+        call('dsrl_pointwise_strided_bwd', logits.data_ptr(), ftw.data_ptr(), ftg.data_ptr(), None, dwf2.data_ptr(), 2, N, 2 * H, 2 * W, C, ft,
+             wsf.data_ptr(), wsf.numel(), st)
+        assert torch.equal(dwf, dwf2)                       # accumulate = 2: the weight gradient alone
+    dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty(C, device=DEV)
+    call('dsrl_convt2x2_bwd', x.data_ptr(), w.data_ptr(), dl.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), N, H, W, C, C, wsb.data_ptr(), wsb.numel(), st)
+    # the one call: the loss pass writes no gradient
+    scal2 = torch.zeros(8, device=DEV)
+    call('dsrl_ce_fused', logits.data_ptr(), C, target.data_ptr(), P, C, 255, None, C, scal2.data_ptr(), flag.data_ptr(), ws.data_ptr(), ws.numel(), st)
+    assert torch.equal(scal[:2], scal2[:2])
+    dx2 = torch.full_like(x, 7.0); dw2 = torch.full_like(w, 7.0); db2 = torch.full((C,), 7.0, device=DEV)
+    call('dsrl_convt2x2_bwd_ce', x.data_ptr(), w.data_ptr(), logits.data_ptr(), target.data_ptr(), 255, scal2.data_ptr() + 4,
+         None if not ft else ftg.data_ptr(), None if not ft else ftw.data_ptr(), ft, dx2.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
+         N, H, W, C, C, wsb.data_ptr(), wsb.numel(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    # and against the oracle: d(CE)/d(logits) in fp64, pushed through the fp64 ConvTranspose backward
+    lg64 = host(logits).astype(np.float64)
+    z = lg64 - lg64.max(-1, keepdims=True); p = np.exp(z); p /= p.sum(-1, keepdims=True)
+    live = tg != 255
+    g64 = p.copy(); idx = np.where(live)
+    g64[idx[0], idx[1], idx[2], tg[live]] -= 1.0
+    g64 *= live[..., None] / live.sum()
+    check(host(dl_ce), g64, 1e-5)
+    if ft:
+        g64[:, ::ft, ::ft, :] += host(ftg).astype(np.float64)[..., None] * host(ftw).astype(np.float64)
+    dxo, dwo, dbo = O.conv_transpose2d_k2s2_bwd(host(x).astype(np.float64).transpose(0, 3, 1, 2), host(w).astype(np.float64), g64.transpose(0, 3, 1, 2), has_bias=True)
+    check(host(dx2).transpose(0, 3, 1, 2), dxo, 1e-5); check(host(dw2), dwo, 1e-5); check(host(db2), dbo, 1e-5)
+
+
+@pytest.mark.parametrize('shape,cap', [((1, 3, 128), 0), ((2, 5, 200), 3), ((2, 9, 328), 5), ((3, 4, 12), 0)])
+def test_convT_forward_with_cross_entropy_value_inside(shape, cap, monkeypatch):
+    # dsrl_convt2x2_fwd_ce: the forward whose kernel also evaluates nn.CrossEntropyLoss of its output from the tile in LDS.  y bit-identical to
+    # dsrl_convt2x2_fwd; loss and pixel count against dsrl_ce_fused on that y (1e-6: another summation order of the pixel losses) and the fp64 oracle;
+    # ragged last segments (200, 328 = 2 * 128 + 72, 12), blocks walking several segments (cap); NaN input -> flag bit 0, label 200 -> NaN loss + bit 1.
+    from dualsuperreslearningforsemseg_amd._lib import call, query
+    N, H, W = shape
+    C = 19
+    rs = np.random.RandomState(N * 1000 + H * 10 + W)
+    if cap:
+        monkeypatch.setenv('DSRL_CONVT_MAX_BLOCKS', str(cap))
+    x = torch.tensor(rs.standard_normal((N, H, W, C)).astype(np.float32), device=DEV)
+    w = torch.tensor(rs.standard_normal((C, C, 2, 2)).astype(np.float32), device=DEV); b = torch.tensor(rs.standard_normal(C).astype(np.float32), device=DEV)
+    tg = rs.randint(0, C, (N, 2 * H, 2 * W)).astype(np.uint8); tg[rs.uniform(size=tg.shape) < 0.1] = 255; tg[0, 1, :] = 255
+    target = torch.tensor(tg, device=DEV)
+    st = HF._stream()
+    P = N * 4 * H * W
+    assert query('dsrl_convt2x2_fwd_ce_supported', x.data_ptr(), x.data_ptr(), N, H, W, C, C) == 1
+    ws = torch.empty(query('dsrl_convt2x2_fwd_ce_workspace_bytes', N, H, W), dtype=torch.uint8, device=DEV)
+    wsc = torch.empty(query('dsrl_ce_fused_workspace_bytes', P), dtype=torch.uint8, device=DEV)
+
+    def run(xin, tgt):
+        y0 = torch.empty((N, 2 * H, 2 * W, C), device=DEV); y1 = torch.full_like(y0, 7.0)
+        f0 = torch.zeros(1, dtype=torch.int32, device=DEV); f1 = torch.zeros(1, dtype=torch.int32, device=DEV)
+        s0 = torch.zeros(8, device=DEV); s1 = torch.zeros(8, device=DEV)
+        call('dsrl_convt2x2_fwd', xin.data_ptr(), w.data_ptr(), b.data_ptr(), y0.data_ptr(), N, H, W, C, C, st)
+        call('dsrl_ce_fused', y0.data_ptr(), C, tgt.data_ptr(), P, C, 255, None, C, s0.data_ptr(), f0.data_ptr(), wsc.data_ptr(), wsc.numel(), st)
+        call('dsrl_convt2x2_fwd_ce', xin.data_ptr(), w.data_ptr(), b.data_ptr(), y1.data_ptr(), N, H, W, C, C, tgt.data_ptr(), 255, s1.data_ptr(), f1.data_ptr(),
+             ws.data_ptr(), ws.numel(), st)
+        torch.cuda.synchronize()
+        return y0, y1, host(s0), host(s1), int(f0), int(f1)
+    y0, y1, s0, s1, f0, f1 = run(x, target)
+    assert torch.equal(y0, y1) and f0 == 0 and f1 == 0
+    assert s0[1] == s1[1] == float((tg != 255).sum())
+    assert abs(s0[0] - s1[0]) <= 1e-6 * abs(s0[0])
+    lg64 = host(y1).astype(np.float64)
+    lse = np.log(np.exp(lg64 - lg64.max(-1, keepdims=True)).sum(-1)) + lg64.max(-1)
+    live = tg != 255
+    ref = float((lse[live] - np.take_along_axis(lg64, np.where(live, tg, 0)[..., None].astype(np.int64), -1)[..., 0][live]).mean())
+    assert abs(s1[0] - ref) <= 1e-5 * abs(ref)
+    xb = x.clone(); xb[0, 0, 0, 0] = float('nan')
+    _, _, s0, s1, f0, f1 = run(xb, target)
+    assert f0 == 1 and f1 == 1 and np.isnan(s1[0])
+    tb = target.clone(); tb[0, 0, 1] = 200
+    _, _, s0, s1, f0, f1 = run(x, tb)
+    assert f0 == 2 and f1 == 2 and np.isnan(s0[0]) and np.isnan(s1[0])
+
+
 @pytest.mark.parametrize('name', ['up2', 'up4', 'up_bcast', 'up_odd'])
 def test_bilinear_golden(golden, name):
     g = golden('ops_micro')
@@ -1648,6 +1761,63 @@ def test_full_model_total_loss_backward_with_fa_vs_oracle():
             if k in rep:
                 assert rep[k] <= bound, (w2, k, rep[k])
         assert rep['all gradients (L2)'] <= ARENA_GRAD_BOUND, rep
+
+
+def test_logits_gradient_formed_inside_the_producer_is_bit_identical_in_the_whole_step(monkeypatch):
+    """HF.LogitsGrad (round 5): with the CE gradient formed inside the last ConvTranspose's backward (dsrl_convt2x2_bwd_ce) every parameter gradient of the
+    whole model, stage 3 with the FA term and the feature transformer's sparse contribution, equals the path that writes d(CE)/d(logits) to memory -
+    bit for bit (128x256 input: the layer sees W = 256, a multiple of the 128-pixel segment; dropout active, same Philox key in both passes)."""
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    torch.manual_seed(5)
+    model = D.DSRL(3, cs)
+    with torch.no_grad():
+        model.SSSR_feature_transformer[1].bias.fill_(0.3); model.SISR_feature_transformer[1].bias.fill_(0.3)
+    model = model.to(DEV).to(memory_format=torch.channels_last).train()
+    assert model.SSSR_decoder['upsample16_pred'][6].logits_layer
+    rs = np.random.RandomState(2)
+    x = dev(rs.standard_normal((2, 3, 128, 256)).astype(np.float32), cl=False)
+    tg = rs.randint(0, 19, (2, 256, 512)).astype(np.uint8); tg[rs.uniform(size=tg.shape) < 0.1] = 255
+    org = dev(rs.standard_normal((2, 3, 256, 512)).astype(np.float32))
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    grads, vals_ = {}, {}
+    launches = {}
+    for on in (True, False, 'value'):
+        monkeypatch.setattr(HF, 'convt_ce_enabled', bool(on))
+        model.load_state_dict(state)
+        for p_ in model.parameters():
+            p_.grad = None
+        HF.set_dropout_seed(77)
+        counts = {}
+        orig = HF.call
+
+        def counting(name, *a, _c=counts, _o=orig):
+            _c[name] = _c.get(name, 0) + 1
+            return _o(name, *a)
+        monkeypatch.setattr(HF, 'call', counting)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        tgd = dev(tg)
+        if on == 'value':                        # the loss value too comes from the producer: its forward kernel evaluates it (HF.logits_target)
+            with HF.logits_target(tgd, 255, flag):
+                outs = model(x)
+        else:
+            outs = model(x)
+        vals = HF.fused_losses(outs, tgd, org, 255, 0.1, 1.0, 3, flag)
+        vals[3].backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(HF, 'call', orig)
+        launches[on] = counts
+        grads[on] = {k: p_.grad.clone() for k, p_ in model.named_parameters() if p_.grad is not None}
+        vals_[on] = vals.clone()
+    assert launches[True].get('dsrl_convt2x2_bwd_ce', 0) == 1 and launches[True].get('dsrl_convt2x2_bwd', 0) == 1, launches[True]
+    assert launches[False].get('dsrl_convt2x2_bwd_ce', 0) == 0 and launches[False].get('dsrl_convt2x2_bwd', 0) == 2, launches[False]
+    assert launches['value'].get('dsrl_convt2x2_fwd_ce', 0) == 1 and launches['value'].get('dsrl_ce_fused', 0) == 0 and launches['value'].get('dsrl_convt2x2_bwd_ce', 0) == 1
+    assert launches[True].get('dsrl_ce_fused', 0) == 1
+    assert torch.equal(vals_[True], vals_[False])
+    check(host(vals_['value']), host(vals_[True]), 1e-6)            # the pixel losses are summed in another order
+    assert grads[True].keys() == grads[False].keys() == grads['value'].keys()
+    for other in (False, 'value'):
+        bad = [k for k in grads[True] if not torch.equal(grads[True][k], grads[other][k])]
+        assert not bad, (other, bad[:5])
 
 
 def test_full_model_vs_stock_torch_fp64():
