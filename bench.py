@@ -276,6 +276,22 @@ def hbm_roofline(torch, HF, flat, B, H, W, reps=10):
     dy = torch.randn_like(y)
     add('convt2x2_fwd (final ConvTranspose2d 19->19, logits write)', (P // 4 + P) * 19 * 4, _time_ms(lambda: HF.conv_transpose2d_k2s2(x.detach(), wt.detach(), bias.detach()), reps, torch))
     add('convt2x2_bwd (dx + dw + db)', (P + 2 * P // 4) * 19 * 4, _time_ms(lambda: torch.autograd.grad(y, (x, wt, bias), dy, retain_graph=True), reps, torch))
+    # the production tail when the shape qualifies (round 5): the CE value inside the forward kernel, its gradient formed inside the backward kernel
+    xd, yd = x.detach(), torch.empty_like(y)
+    if HF.cquery('dsrl_convt2x2_fwd_ce_supported', xd.data_ptr(), yd.data_ptr(), B, H, W, 19, 19) and \
+            HF.cquery('dsrl_convt2x2_bwd_ce_supported', xd.data_ptr(), yd.data_ptr(), tgt.data_ptr(), B, H, W, 19, 19):
+        scal = torch.zeros(8, device=dev)
+        wsf = HF._ws(HF.cquery('dsrl_convt2x2_fwd_ce_workspace_bytes', B, H, W), xd)
+        add('convt2x2_fwd_ce (final ConvTranspose2d forward + CrossEntropy value + NaN check in one kernel; with its finalize launch)', (P // 4 + P) * 19 * 4 + P,
+            _time_ms(lambda: _lib.call('dsrl_convt2x2_fwd_ce', xd.data_ptr(), wt.data_ptr(), bias.data_ptr(), yd.data_ptr(), B, H, W, 19, 19, tgt.data_ptr(), 255,
+                                       scal.data_ptr(), flag.data_ptr(), wsf.data_ptr(), wsf.numel(), st), reps, torch))
+        dxb, dwb, dbb = torch.empty_like(xd), torch.empty_like(wt), torch.empty(19, device=dev)
+        wsb = HF._ws(HF.cquery('dsrl_convt2x2_bwd_workspace_bytes', B, H, W, 19, 19), xd)
+        ftg, ftw = torch.randn((B, Ho // 8, Wo // 8), device=dev), torch.randn(19, device=dev)
+        add('convt2x2_bwd_ce (d(CE)/d(logits) formed inside + feature-transformer term + dx + dw + db; replaces ce_fused\'s gradient write and convt2x2_bwd\'s read)',
+            (P + 2 * P // 4) * 19 * 4 + P,
+            _time_ms(lambda: _lib.call('dsrl_convt2x2_bwd_ce', xd.data_ptr(), wt.data_ptr(), yd.data_ptr(), tgt.data_ptr(), 255, scal.data_ptr() + 4, ftg.data_ptr(), ftw.data_ptr(), 8,
+                                       dxb.data_ptr(), dwb.data_ptr(), dbb.data_ptr(), B, H, W, 19, 19, wsb.data_ptr(), wsb.numel(), st), reps, torch))
     bn = torch.nn.BatchNorm2d(256).to(dev).train()
     xb = torch.randn((B, 256, H // 4, W // 4), device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     nb = xb.numel() * 4
