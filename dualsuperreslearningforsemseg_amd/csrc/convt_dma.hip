@@ -15,12 +15,15 @@
 // a segment and the per-block partial layout are those of convt2x2_bwd_mfma_kernel; convt2x2_dw_finalize_kernel merges the partials.
 //
 // CE = true (dsrl_convt2x2_bwd_ce): the layer's output IS the logits of nn.CrossEntropyLoss and the incoming gradient is never materialised.  The
-// DMA brings the LOGITS rows and the target bytes of the segment, and every wave turns its 64 output pixels into d(loss)/d(logits) in place in LDS -
-// max, exp, sum, scale in the order and with the roundings of ce_fused_kernel (losses.hip), plus the stride-s feature transformer's rank-one
-// contribution g * w_c on the sampled pixels (pointwise_bwd_kernel's `dx += g * w`) - one segment ahead of the MFMAs that consume it, by four more
-// waves (8-11, one per SIMD, vector ALU only) while waves 0-7 multiply the previous segment: inside the MFMA waves the same work cost +44 us of 129
-// (in-order issue: a wave's exps and its MFMAs cannot overlap), beside them it runs in the matrix pipe's shadow.  The 319 MB gradient write of the loss pass and its 319 MB read here disappear; results are bit-identical
-// to ce_fused + this kernel with CE = false.
+// DMA brings the LOGITS rows and the target bytes of the segment, and d(loss)/d(logits) is formed in place in LDS - max, exp, sum, scale in the order
+// and with the roundings of ce_fused_kernel (losses.hip), plus the stride-s feature transformer's rank-one contribution g * w_c on the sampled pixels
+// (pointwise_bwd_kernel's `dx += g * w`) - one segment ahead of the MFMAs that consume it.  TW = true (default): by four more waves (8-11, one per SIMD,
+// two output pixels per lane) while waves 0-7 multiply the previous segment; TW = false (DSRL_CONVT_CE_WAVES=8): inside the eight MFMA waves, one
+// pixel per lane, the dx waves before their MFMAs and the dw waves after theirs.  The 319 MB gradient write of the loss pass and its 319 MB read
+// here disappear; results are bit-identical to ce_fused + pointwise_bwd + this kernel with CE = false.
+// Measured (profiles/round5_convt_tail.txt): 135 us without CE, 176-183 us with (TW), 188-195 (TW = false).  The softmax does not hide behind the
+// MFMAs: SQ counters read 43 % of the SIMD cycles in MFMAs + 28 % in the other vector instructions with no co-execution counted, i.e. the ~290
+// vector instructions per pixel add to the matrix work whichever wave issues them.
 #include "common.h"
 #include "lds_dma.h"
 #include <algorithm>
