@@ -156,6 +156,7 @@ struct WgradArgs {
     float* dw_final;
     int rblocks;
     const unsigned* amax_dy; const unsigned* amax_x;        // f16x3: max |.| (bit patterns) of dy and of x
+    int no_ident;               // DSRL_WGRAD_IDENT=0: the general per-row addressing also for taps that read pixel p for pixel p (A/B knob)
 };
 
 // conv_wgrad3.hip: 3x3 / stride-1 weight gradients with all nine taps in one block (f16x3 / f16x1; tile 64 out channels x 64 in channels: wgrad3_tile()).
