@@ -176,6 +176,17 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// four channels per lane (C % 4 == 0, 16-byte aligned rows): one 16-byte store per lane instead of four 4-byte ones (21 -> 7 us on ASPP's 33 MB)
+__global__ __launch_bounds__(256) void gap_bwd4_kernel(const float* __restrict__ dy, float* __restrict__ dx, int lddx, int N, int HW, int C4) {
+    const long long total = (long long)N * HW * C4;
+    const float inv = 1.f / (float)HW;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C4); const long long p = e / C4; const int n = (int)(p / HW);
+        const float4 g = reinterpret_cast<const float4*>(dy)[(long long)n * C4 + c];
+        *reinterpret_cast<float4*>(dx + p * lddx + 4 * c) = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+    }
+}
+
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
                                                            int N, int H, int W, int C, int Ho, int Wo) {
     const long long total = (long long)N * Ho * Wo * C;
@@ -1087,6 +1098,10 @@ extern "C" int dsrl_global_avgpool_fwd(const float* x, int ldx, float* y, int N,
 }
 extern "C" int dsrl_global_avgpool_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, dsrl_stream_t stream) {
     DSRL_PROLOGUE(dy && dx && N > 0 && HW > 0 && C > 0 && lddx >= C, "global_avgpool_bwd")
+    if (C % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0) {
+        hipLaunchKernelGGL(gap_bwd4_kernel, dim3(flat_grid((long long)N * HW * (C / 4))), dim3(256), 0, st, dy, dx, lddx, N, HW, C / 4);
+        return launch_status("gap_bwd4_kernel");
+    }
     hipLaunchKernelGGL(gap_bwd_kernel, dim3(flat_grid((long long)N * HW * C)), dim3(256), 0, st, dy, dx, lddx, N, HW, C);
     return launch_status("gap_bwd_kernel");
 }

@@ -1115,7 +1115,8 @@ def upsample_bilinear_ac(x, size):
 
 class _GlobalAvgPool(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, gslot=None):
+        ctx.gslot = gslot
         x, ldx = pm(x)
         N, Cc, H, W = x.shape
         y = new_cl((N, Cc, 1, 1), x)
@@ -1129,11 +1130,16 @@ class _GlobalAvgPool(torch.autograd.Function):
         dy = dy.contiguous().view(N, Cc)
         dx = new_cl((N, Cc, H, W), dy)
         call('dsrl_global_avgpool_bwd', dy.data_ptr(), dx.data_ptr(), Cc, N, H * W, Cc, _stream())
-        return dx
+        slot = ctx.gslot
+        if slot is not None and not slot.closed and slot.buf is None:
+            slot.buf = dx           # first contribution of a shared input (GradSlot): the data gradients of the other consumers accumulate into it
+        return dx, None
 
 
-def global_avg_pool(x):
-    return _GlobalAvgPool.apply(x)
+def global_avg_pool(x, grad_slot=None):
+    """grad_slot: functional.GradSlot shared with the other consumers of x (ASPP: the four conv branches).  This op runs first in the backward pass
+    (it is the last consumer in the forward), so its dense gradient becomes the shared buffer; published later it would stay a gradient of its own."""
+    return _GlobalAvgPool.apply(x, grad_slot)
 
 
 class _MaxPool3x3s2(torch.autograd.Function):

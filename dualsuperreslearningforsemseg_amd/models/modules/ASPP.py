@@ -36,6 +36,7 @@ class ASPP(t.nn.Module):
         if HF.grad_slots_enabled and x.requires_grad and t.is_grad_enabled() and all(isinstance(self.branches[i], HipSequential) for i in range(4)):
             xs, slot = HF.fork(x), HF.GradSlot()
         outs = [self.branches[i](xs, grad_slot=slot) if slot is not None else self.branches[i](xs) for i in range(4)]     # ASPP.py:37
-        g = self.branches[4](self.avg(x))                                      # ASPP.py:38-39 (train-mode BN needs batch >= 2)
+        # the pooled branch reads the same features: last consumer in the forward = first in the backward, its gradient becomes the shared buffer
+        g = self.branches[4](HF.global_avg_pool(xs, slot) if slot is not None else self.avg(x))        # ASPP.py:38-39 (train-mode BN needs batch >= 2)
         outs.append(HF.upsample_bilinear_ac(g, x.shape[-2:]))                  # ASPP.py:40 (1x1 -> HxW, align_corners)
         return self.branches[5](HF.cat_channels(outs))                         # ASPP.py:44

@@ -949,6 +949,32 @@ def test_pools_golden(golden):
     y.backward(dev(g['maxpool.dy'])); check(host(x.grad), g['maxpool.dx'], 1e-6)
 
 
+@pytest.mark.parametrize('C', [2048, 19, 6])
+def test_global_avgpool_backward_both_kernels(C):
+    # the 16-byte kernel (C % 4 == 0) and the scalar one: dy / HW, exact
+    rs = np.random.RandomState(C)
+    x = rs.standard_normal((2, C, 5, 7)).astype(np.float32); dy = rs.standard_normal((2, C, 1, 1)).astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    y = HF.global_avg_pool(xt); check(host(y), x.mean((2, 3), keepdims=True), 1e-6)
+    y.backward(dev(dy))
+    assert np.array_equal(host(xt.grad), np.broadcast_to(dy * np.float32(1.0 / 35.0), x.shape))
+
+
+def test_aspp_pooled_branch_publishes_the_shared_gradient():
+    rs = np.random.RandomState(3)
+    x = rs.standard_normal((2, 32, 6, 8)).astype(np.float32); w = (rs.standard_normal((16, 32, 1, 1)) * 0.2).astype(np.float32)
+    dyp = rs.standard_normal((2, 32, 1, 1)).astype(np.float32); dyc = rs.standard_normal((2, 16, 6, 8)).astype(np.float32)
+    xt = dev(x).requires_grad_(True); wt = dev(w).requires_grad_(True)
+    xs, slot = HF.fork(xt), HF.GradSlot()
+    a = HF.conv2d(xs, wt, None, 1, 0, 1, grad_slot=slot)
+    b = HF.global_avg_pool(xs, slot)
+    torch.autograd.backward([a, b], [dev(dyc), dev(dyp)])
+    assert slot.buf is not None and not slot.closed            # one buffer: the pool's, completed by the conv (a leaf's .grad is autograd's copy of it)
+    check(host(slot.buf), host(xt.grad), 0.0)
+    ref = np.einsum('nkhw,kc->nchw', dyc.astype(np.float64), w[:, :, 0, 0].astype(np.float64)) + dyp.astype(np.float64) / 48.0
+    check(host(xt.grad), ref, 1e-5)
+
+
 def test_ce_mse_sgd_golden(golden):
     g = golden('ops_micro')
     lg = dev(g['ce.logits']).requires_grad_(True)

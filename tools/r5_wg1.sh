@@ -1,11 +1,11 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "wgrad or conv_golden or full_model or head" > gpurun_out/wg1_tests.txt 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/wg1_tests.txt
-for v in 1 0 1 0; do
-  DSRL_WGRAD_IDENT=$v timeout -k 10 300 python bench.py --steps 60 --warmup 15 --no-prof --no-cpu-baseline --no-config5 > gpurun_out/wg1_bench_$v.json 2> gpurun_out/wg1_bench_$v.err || exit 1
-  python - <<EOF
-import json
-d=json.loads(open('gpurun_out/wg1_bench_$v.json').read().strip().splitlines()[-1])
-print('DSRL_WGRAD_IDENT=$v', d['value'], d['ms_per_step'], d['config']['losses_last_step'])
+timeout -k 10 900 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "aspp or ASPP or full_model or head or slot or pool" > gpurun_out/wg1_tests.txt 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/wg1_tests.txt
+bash tools/kstats_run.sh wg3 || exit 1
+grep -i "ATen\|total kernel\|CUDAFunctor_add" gpurun_out/wg3_kstats.txt
+python - <<'EOF'
+import csv
+rows=list(csv.DictReader(open('gpurun_out/wg3_stats/p_kernel_stats.csv')))
+for r in rows:
+    if 'CUDAFunctor_add' in r['Name'] or 'gap_bwd' in r['Name']: print(int(r['Calls'])/14, float(r['AverageNs'])/1e3, r['Name'][:90])
 EOF
-done
