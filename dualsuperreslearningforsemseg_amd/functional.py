@@ -649,13 +649,17 @@ def current_seed():
 # consumed inside the block only; other users of the original tensor see one ordinary gradient.  Any case the protocol does not
 # cover falls back to returning a separate gradient (closed slot), which autograd sums as usual.
 grad_slots_enabled = os.environ.get('DSRL_GRAD_SLOTS', '1') != '0'
+# one slot for the three consumers of layer1's output (ResNet101.forward / DSRL.forward_head, round 5)
+outer_grad_slot = os.environ.get('DSRL_OUTER_SLOT', '1') != '0'
 
 
 class GradSlot:
-    __slots__ = ('buf', 'closed')
+    __slots__ = ('buf', 'closed', 'link')
 
     def __init__(self):
         self.buf, self.closed = None, False
+        self.link = None            # the BNLink whose backward sums the LAST contributor leaves (set where both are created); a contributor without
+                                    # that link arriving after the sums exist withdraws them (they would miss its part of the gradient)
 
 
 # Backward counterpart of conv2d_bn_act: when y = relu(bn(x)) feeds exactly one conv, that conv's data-gradient kernel produces the
@@ -811,6 +815,8 @@ class _Conv2d(torch.autograd.Function):
             acc = (slot is not None and not slot.closed and slot.buf is not None and tuple(slot.buf.shape) == (N, Cc, H, W)
                    and slot.buf.is_contiguous(memory_format=CL))
             dx = slot.buf if acc else new_cl((N, Cc, H, W), x)
+            if slot is not None and slot.link is not None and slot.link is not ctx.in_link and slot.link.stats is not None:
+                slot.link.stats = None      # sums left by an earlier contributor do not contain this gradient: that BatchNorm takes its own path
             ws = _ws(cquery('dsrl_conv2d_dgrad_workspace_bytes', *shp), x)
             wt_ptr = None
             if ctx.wt is not None:

@@ -95,7 +95,9 @@ class DSRL(BaseModel):
         aspp_features = fe['aspp'](backbone_features)
         h, w = aspp_features.shape[-2:]
         aspp_features = HF.upsample_bilinear_ac(aspp_features, (4 * h, 4 * w))                 # DSRL.py:163
-        lowlevel_features = fe['shortcut_conv'](lowlevel_features)                            # DSRL.py:164
+        oslot = getattr(lowlevel_features, '_dsrl_outer_slot', None)                          # shared with layer2's first block (ResNet101.forward)
+        lowlevel_features = (fe['shortcut_conv'](lowlevel_features, grad_slot=oslot) if (oslot is not None and isinstance(fe['shortcut_conv'], HipSequential))
+                             else fe['shortcut_conv'](lowlevel_features))                     # DSRL.py:164
         cat_features = HF.cat_channels([aspp_features, lowlevel_features])                    # DSRL.py:165
         # cat_features feeds cat_conv.0 and (stage > 1) the SISR conv: both data gradients accumulate in one buffer (HF.GradSlot)
         slot = None

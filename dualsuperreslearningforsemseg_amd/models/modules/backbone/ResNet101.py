@@ -36,10 +36,15 @@ class Bottleneck(t.nn.Module):
         slot = None
         # bn3 of the previous block left a link on its output: the data gradient that completes our input's shared buffer carries its sums
         lin = getattr(x, '_dsrl_bnlink', None) if HF.bn_bwd_stats_enabled else None
-        if HF.grad_slots_enabled and x.requires_grad and t.is_grad_enabled():
+        outer = getattr(x, '_dsrl_outer_slot', None)       # x is already a fork with a slot that a consumer outside this block shares (ResNet101.forward)
+        if outer is not None and HF.grad_slots_enabled and t.is_grad_enabled():
+            slot = outer
+        elif HF.grad_slots_enabled and x.requires_grad and t.is_grad_enabled():
             x, slot = HF.fork(x), HF.GradSlot()
         if slot is None:
             lin = None
+        elif lin is not None:
+            slot.link = lin
         if self.downsample is None:
             identity = x
         elif len(self.downsample) == 2 and isinstance(self.downsample[0], HipConv2d) and self.downsample[0].bias is None:
@@ -143,6 +148,16 @@ class ResNet101(t.nn.Module):
         x = HF.batch_norm_act(self.conv1(x), self.bn1, relu=True)        # ResNet101.py:92-94
         x = self.maxpool(x)
         x = self.layer1(x)
+        # layer1's output has three consumers: conv1 and the downsample conv of layer2's first block, and the decoder's shortcut conv (DSRL.py:164).
+        # One fork + slot for all three (the block adopts it, DSRL.forward_head hands it to the shortcut conv): their data gradients land in one
+        # buffer instead of two tensors and an add pass over 67 MB.  Not with the two-phase backward (the tensor is cut into a leaf there).
+        if (HF.grad_slots_enabled and HF.outer_grad_slot and t.is_grad_enabled() and x.requires_grad and getattr(self, '_dsrl_cut', None) is None
+                and isinstance(self.layer2[0], Bottleneck)):
+            link = getattr(x, '_dsrl_bnlink', None)
+            x = HF.fork(x)
+            x._dsrl_outer_slot = HF.GradSlot()
+            if link is not None:
+                x._dsrl_bnlink = link
         low_level_features = x                                            # ResNet101.py:98
         x = self.layer2(x)
         x = self.layer3(x)

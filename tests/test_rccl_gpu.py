@@ -54,11 +54,14 @@ def test_rccl_reduction_paths_match_half_lr_single_process():
     # form the same sums in the same order: a random-init batch-2 net amplifies a last-bit difference to 1e-3 within two steps (round 5: measured).  bn3's
     # backward sums from the next block's accumulating dgrad (default since round 5) are one such difference - the block in front of the two-graph cut has no
     # "next block" inside its graph and takes the barrier kernel instead - so they are off here; the default setting is covered by the graph == eager tests.
+    # The shared gradient buffer of layer1's three consumers (round 5) is another: the two-graph schedule cuts that tensor into a leaf and sums in another order.
     shared_was, HF.bn_bwd_stats_shared = HF.bn_bwd_stats_shared, False
+    outer_was, HF.outer_grad_slot = HF.outer_grad_slot, False
     try:
         _reduction_paths_body(dist, ddp, HF)
     finally:
         HF.bn_bwd_stats_shared = shared_was
+        HF.outer_grad_slot = outer_was
 
 
 def _reduction_paths_body(dist, ddp, HF):
