@@ -1608,7 +1608,7 @@ def fused_losses(outs, target, input_org, ignore_index, w1, w2, stage, flag, sub
     """-> 5-float device tensor [CE, w1*MSE, w2*FA, total, NaN flag]; `outs` = DSRL.forward's 4-tuple.  vals[3].backward() is the only
     supported backward (the function is the root of the pass); `flag` is the int32 NaN flag the fused kernels OR into."""
     sssr, sisr, ft1, ft2 = outs
-    dummy = sssr.new_zeros(1)
+    dummy = _const1(0.0, sssr.device)            # stands in for the outputs a lower stage does not have (a cached constant: no fill launch per step)
     return _FusedLosses.apply(sssr, sisr if stage > 1 else dummy, ft1 if stage > 2 else dummy, ft2 if stage > 2 else dummy, target,
                               input_org if stage > 1 else dummy, int(ignore_index), float(w1), float(w2), int(stage), flag, int(subsample_factor))
 
