@@ -1321,6 +1321,8 @@ static int launch_igemm(const ConvArgs& a_in, TileCfg cfg, hipStream_t st) {
 #undef DSRL_LAUNCH_BIG
             return launch_status("conv_igemm_split_kernel<f16x3, 8 waves>");
         }
+        if (cfg == T128x128 && f16 && a.tickets != nullptr && a.splits > 1)          // the same plan with the split-K reduction inside the launch (DSRL_SK_COOP1)
+            return launch_sk_igemm(a, DGRAD, s1, npl, st);
 #define DSRL_SPLIT_ONE(...)                                                                                                  \
         { static const hipError_t at_ = hipFuncSetAttribute((const void*)conv_igemm_split_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); (void)at_; \
           hipLaunchKernelGGL((conv_igemm_split_kernel<__VA_ARGS__>), grid, dim3(256), lds2, st, a); }
@@ -1445,7 +1447,7 @@ static FwdPlan plan_fwd(int N, int Hin, int Win, int Cin, int Kout, int R, int S
     // (one arrival ticket per tile in the activation's amax record), partial tiles within one buffer descriptor
     cfg_dims(p.cfg, bm, bn);
     const long long t2 = ceil_div(p.M, bm) * ceil_div(Kout, bn);
-    p.coop = p.splits > 1 && p.kg == 2 && p.cfg == T128x128 && conv_precision_mode() >= 4 && t2 <= kCoopMaxTiles &&
+    p.coop = p.splits > 1 && (p.kg == 2 || (p.kg == 1 && env_int("DSRL_SK_COOP1", 1))) && p.cfg == T128x128 && conv_precision_mode() >= 4 && t2 <= kCoopMaxTiles &&
              (long long)p.splits * t2 * bm * bn * 4 < (1ll << 31) && env_int("DSRL_SK_COOP", 1);
     p.ws = p.splits > 1 ? (p.coop ? (size_t)p.splits * t2 * bm * bn * sizeof(float) : (size_t)p.splits * p.M * Kout * sizeof(float)) : 0;
     return p;

@@ -10,6 +10,7 @@
 #include "common.h"
 #include "conv_common.h"
 #include "conv_split_kernel.h"
+#include <algorithm>
 
 namespace dsrl {
 
@@ -21,17 +22,24 @@ size_t sk_lds_bytes() { return kSkLds; }
 
 bool sk_supported(int cfg, int kg, int npl, bool f16, bool w_split) {
     (void)w_split;
-    return cfg == 0 && kg == 2 && f16 && (npl == 1 || npl == 2);
+    return cfg == 0 && (kg == 2 || kg == 1) && f16 && (npl == 1 || npl == 2);
 }
 
-template <bool DGRAD, int NPL, int ARITH, bool STR1>
-static int launch_one(const ConvArgs& a, hipStream_t st) {
-    auto* k = conv_igemm_split_kernel<2, 2, 2, 2, DGRAD, NPL, 2, ARITH, STR1, true>;
+template <bool DGRAD, int NPL, int ARITH, bool STR1, int KG>
+static int launch_one_kg(const ConvArgs& a, hipStream_t st) {
+    auto* k = conv_igemm_split_kernel<2, 2, 2, 2, DGRAD, NPL, KG, ARITH, STR1, true>;
     static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSkLds);
     (void)attr;
     const dim3 grid((unsigned)(a.mtiles * a.ntiles), 1u, (unsigned)a.splits);
-    hipLaunchKernelGGL(k, grid, dim3(512), kSkLds, st, a);
-    return launch_status("conv_igemm_split_kernel<128x128, 2 K groups, cooperative split-K>");
+    // one K group: the LDS of the ordinary 128x128 launch (two stages of 256 rows x NPL planes x 64 B, or the tile parked for the fast BatchNorm-sum epilogue)
+    const size_t lds = KG > 1 ? kSkLds : std::max((size_t)2 * (128 + 128) * NPL * 64, a.bn_fast ? (size_t)128 * 128 * 4 : (size_t)0);
+    hipLaunchKernelGGL(k, grid, dim3(256 * KG), lds, st, a);
+    return launch_status("conv_igemm_split_kernel<128x128, cooperative split-K>");
+}
+// one K group (DSRL_SK_COOP1, round 5): the planner's ordinary 128x128 / split-K plan with the reduction moved into the launch - no slabs + reduce launch
+template <bool DGRAD, int NPL, int ARITH, bool STR1>
+static int launch_one(const ConvArgs& a, hipStream_t st) {
+    return a.kg > 1 ? launch_one_kg<DGRAD, NPL, ARITH, STR1, 2>(a, st) : launch_one_kg<DGRAD, NPL, ARITH, STR1, 1>(a, st);
 }
 
 int launch_sk_igemm(const ConvArgs& a, bool dgrad, bool str1, int npl, hipStream_t st) {

@@ -464,14 +464,15 @@ void conv_igemm_split_kernel(const ConvArgs a) {
             }
             __syncthreads();
             if (!coop_last) return;
-            // the partials of the other blocks, four at a time in flight (every load unconditional: an absent or own partial reads through an out-of-range offset)
+            // the partials of the other blocks, ZB at a time in flight (every load unconditional: an absent or own partial reads through an out-of-range offset)
             float tot[NSH];
 #pragma unroll
             for (int f = 0; f < NSH; ++f) tot[f] = 0.f;
-            for (int z0 = 0; z0 < a.splits; z0 += 4) {
-                u32x4 in[4][NV4];
+            constexpr int ZB = NV4 > 8 ? 1 : 4;          // partials in flight: 4 x 8 or 1 x 16 float4 per thread (one K group: acc + running sum + one partial = 192 registers)
+            for (int z0 = 0; z0 < a.splits; z0 += ZB) {
+                u32x4 in[ZB][NV4];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
+                for (int d = 0; d < ZB; ++d) {
                     const int zz = z0 + d;
                     const unsigned zoff = (zz < a.splits && zz != z) ? (unsigned)zz * zstride : kOOB;
 #pragma unroll
@@ -479,7 +480,7 @@ void conv_igemm_split_kernel(const ConvArgs a) {
                         in[d][v] = __builtin_amdgcn_raw_buffer_load_b128(sr, (int)__builtin_elementwise_add_sat(zoff, toff + (unsigned)v * (unsigned)(NTH * 16)), 0, kSC1);
                 }
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
+                for (int d = 0; d < ZB; ++d) {
                     const int zz = z0 + d;
                     if (zz < a.splits) {
 #pragma unroll

@@ -271,14 +271,17 @@ def test_planes_kernel_bit_identical_to_register_staged(shape, cfg, kg, monkeypa
 @pytest.mark.parametrize('shape,splits', [((8, 256, 16, 32, 256, 3, 1, 1, 1), 4), ((8, 1024, 16, 32, 256, 1, 1, 0, 1), 4), ((4, 512, 16, 32, 512, 3, 1, 2, 2), 2),
                                           ((3, 200, 9, 20, 136, 3, 1, 1, 1), 3), ((8, 256, 16, 32, 256, 3, 1, 1, 1), 1)])
 @pytest.mark.parametrize('mode', ['f16x3', 'f16x1'])
-def test_cooperative_splitk_matches_slabs_and_oracle(shape, splits, mode, monkeypatch):
+@pytest.mark.parametrize('kg', [2, 1])
+def test_cooperative_splitk_matches_slabs_and_oracle(shape, splits, mode, kg, monkeypatch):
     """conv_sk.hip (round 5): 128x128 tiles, two K groups, split-K across workgroups with the reduction INSIDE the launch (arrival tickets in the spare
     words of the activation's amax record, last arriver sums in the order z = 0 .. splits-1) against the same plan with slabs + splitk_reduce_kernel:
     forward and data gradient (plain and accumulating) are BIT-identical; both match the fp64 oracle; the BatchNorm partials of the forward epilogue
     and the BatchNorm-backward sums of the dgrad epilogue - which only the cooperative launch can produce under split-K - reproduce the statistics of
     the tensors the launch wrote; the tickets are left zero (two launches in a row through the same record).  Ragged case: M, N and C off the tile sizes."""
     N, C, H, W, K, R, stride, pad, dil = shape
-    monkeypatch.setenv('DSRL_FORCE_CFG', '0'); monkeypatch.setenv('DSRL_FORCE_KG', '2'); monkeypatch.setenv('DSRL_FORCE_SPLITS', str(splits))
+    # kg = 1 (DSRL_SK_COOP1): the planner's ordinary one-group 128x128 plan with only the reduction moved into the launch
+    monkeypatch.setenv('DSRL_FORCE_CFG', '0'); monkeypatch.setenv('DSRL_FORCE_KG', str(kg)); monkeypatch.setenv('DSRL_FORCE_SPLITS', str(splits))
+    monkeypatch.setenv('DSRL_SK_COOP1', '1')
     rs = np.random.RandomState(sum(shape) + splits)
     x = dev(np.maximum(rs.standard_normal((N, C, H, W)), 0).astype(np.float32))
     w = dev((rs.standard_normal((K, C, R, R)) / np.sqrt(C * R * R)).astype(np.float32))
