@@ -1447,7 +1447,7 @@ static FwdPlan plan_fwd(int N, int Hin, int Win, int Cin, int Kout, int R, int S
     // (one arrival ticket per tile in the activation's amax record), partial tiles within one buffer descriptor
     cfg_dims(p.cfg, bm, bn);
     const long long t2 = ceil_div(p.M, bm) * ceil_div(Kout, bn);
-    p.coop = p.splits > 1 && (p.kg == 2 || (p.kg == 1 && env_int("DSRL_SK_COOP1", 1))) && p.cfg == T128x128 && conv_precision_mode() >= 4 && t2 <= kCoopMaxTiles &&
+    p.coop = p.splits > 1 && (p.kg == 2 || (p.kg == 1 && env_int("DSRL_SK_COOP1", 0))) && p.cfg == T128x128 && conv_precision_mode() >= 4 && t2 <= kCoopMaxTiles &&
              (long long)p.splits * t2 * bm * bn * 4 < (1ll << 31) && env_int("DSRL_SK_COOP", 1);
     p.ws = p.splits > 1 ? (p.coop ? (size_t)p.splits * t2 * bm * bn * sizeof(float) : (size_t)p.splits * p.M * Kout * sizeof(float)) : 0;
     return p;
