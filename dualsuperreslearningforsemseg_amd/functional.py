@@ -1224,7 +1224,7 @@ class LogitsGrad:
         if not (convt_ce_enabled and self.y is not None and logits.data_ptr() == self.y.data_ptr() and tuple(logits.shape) == tuple(self.y.shape)):
             return False
         N, Ci, H, W = self.xshape
-        return bool(cquery('dsrl_convt2x2_bwd_ce_supported', self.x_ptr, logits.data_ptr(), target.data_ptr(), N, H, W, Ci, logits.shape[1]))
+        return bool(query('dsrl_convt2x2_bwd_ce_supported', self.x_ptr, logits.data_ptr(), target.data_ptr(), N, H, W, Ci, logits.shape[1]))
 
 
 
@@ -1269,7 +1269,7 @@ class _ConvT2x2(torch.autograd.Function):
         y = new_cl((N, Co, 2 * H, 2 * W), x)
         lt = _logits_target if holder is not None else None
         if (lt is not None and tuple(lt[0].shape) == (N, 2 * H, 2 * W) and lt[0].device == x.device
-                and cquery('dsrl_convt2x2_fwd_ce_supported', x.data_ptr(), y.data_ptr(), N, H, W, Ci, Co)):
+                and query('dsrl_convt2x2_fwd_ce_supported', x.data_ptr(), y.data_ptr(), N, H, W, Ci, Co)):       # (pointer arguments: not memoised)
             tgt, ign, flag = lt
             holder.value = torch.empty(8, device=x.device, dtype=torch.float32)
             holder.value_key = (tgt.data_ptr(), ign, flag.data_ptr())
