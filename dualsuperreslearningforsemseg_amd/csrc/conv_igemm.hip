@@ -1447,9 +1447,15 @@ static FwdPlan plan_fwd(int N, int Hin, int Win, int Cin, int Kout, int R, int S
     // (one arrival ticket per tile in the activation's amax record), partial tiles within one buffer descriptor
     cfg_dims(p.cfg, bm, bn);
     const long long t2 = ceil_div(p.M, bm) * ceil_div(Kout, bn);
-    p.coop = p.splits > 1 && (p.kg == 2 || (p.kg == 1 && env_int("DSRL_SK_COOP1", 0))) && p.cfg == T128x128 && conv_precision_mode() >= 4 && t2 <= kCoopMaxTiles &&
+    p.coop = p.splits > 1 && (p.kg == 2 || (p.kg == 1 && env_int("DSRL_SK_COOP1", 1))) && p.cfg == T128x128 && conv_precision_mode() >= 4 && t2 <= kCoopMaxTiles &&
              (long long)p.splits * t2 * bm * bn * 4 < (1ll << 31) && env_int("DSRL_SK_COOP", 1);
     p.ws = p.splits > 1 ? (p.coop ? (size_t)p.splits * t2 * bm * bn * sizeof(float) : (size_t)p.splits * p.M * Kout * sizeof(float)) : 0;
+    return p;
+}
+// the data gradient's plan: a strided one cannot reduce its split-K inside the launch (parity-ordered rows), so it keeps slabs + reduce
+static FwdPlan plan_dgrad(int N, int Ho, int Wo, int Kp, int C, int R, int S, int H, int W, int npl, int stride) {
+    FwdPlan p = plan_fwd(N, Ho, Wo, Kp, C, R, S, H, W, npl, true);
+    if (stride != 1 && p.coop) { p.coop = false; p.ws = p.splits > 1 ? (size_t)p.splits * p.M * C * sizeof(float) : 0; }
     return p;
 }
 // workspace queries do not know which arithmetic the launch will run in: the larger of the two plans
@@ -1533,8 +1539,12 @@ static int fwd_impl(const float* x, int ldx, const float* w, const float* bias, 
         // both operands as fp16 planes carrying the scales of THESE records (dsrl_split_planes / dsrl_conv2d_filter_planes_batched): same tile plan,
         // same summation order, staged by LDS-DMA
         // (round 5) f16x1 takes ONE plane per operand - the operand of a half-precision STORAGE format: fp16 activations at their tensor's scale
+        // A plan that reduces its split-K inside the launch (p.coop) has no planes build: it keeps the register-staged kernel whether or not planes are
+        // on offer, so that the launch, its BatchNorm partials (dsrl_conv2d_fwd_stats_parts) and the bits of its result do not depend on which step first
+        // had the planes (round 5: with the planes taking precedence the step-1 and step-2 plans differed, and the slab reduce wrote ceil(M/64) rows of
+        // partials into a buffer sized for the cooperative launch's M/128).
         if (x_planes != nullptr && w_planes != nullptr && x_amax != nullptr && w_amax != nullptr && planes_usable(C, ldx, x_planes, w_planes) &&
-            planes_cfg_supported((int)p.cfg, p.kg)) {
+            planes_cfg_supported((int)p.cfg, p.kg) && !(p.coop && p.splits > 1)) {
             const long long pe = (long long)N * H * W * ldx, we = (long long)K * R * S * C;
             a.planes = conv_planes(PASS_FWD); a.w_split = 0;
             a.x = (const float*)x_planes; a.w = (const float*)w_planes;
@@ -1558,6 +1568,7 @@ static int fwd_impl(const float* x, int ldx, const float* w, const float* bias, 
         return launch_igemm<false>(a, p.cfg, st);
     }
     if (p.splits > 1) {
+        DSRL_REQUIRE(!(p.coop && stats != nullptr), DSRL_E_UNSUPPORTED, "conv2d_fwd_stats: the cooperative split-K plan of this shape could not be launched (no operand magnitudes)");
         a.y = (float*)ws; a.ldy = K; a.bias = nullptr;
         if (int e = launch_igemm<false>(a, p.cfg, st)) return e;
         const long long total = (long long)p.M * K;
@@ -1658,13 +1669,13 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
     hipStream_t st = (hipStream_t)stream;
     if (int e = bind_stream_device(st)) return e;
     const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
-    const FwdPlan p = plan_fwd(N, Ho, Wo, Kp, C, R, S, H, W, conv_planes(PASS_DGRAD), true);
+    const FwdPlan p = plan_dgrad(N, Ho, Wo, Kp, C, R, S, H, W, conv_planes(PASS_DGRAD), stride);
     const size_t wtb = dgrad_wt_bytes(C, K, R, S);
     DSRL_REQUIRE(ws && ws_bytes >= wtb + p.ws, DSRL_E_WORKSPACE, "conv2d_dgrad: workspace %zu < %zu", ws_bytes, wtb + p.ws);
     const float* wt = wt_in;
     float* slabs = (float*)((char*)ws + wtb);
     const bool use_planes = conv_f16() && dy_planes != nullptr && wt_planes != nullptr && dy_amax != nullptr && w_amax != nullptr && stride == 1 && K % 8 == 0 &&
-                            planes_usable(K, lddy, dy_planes, wt_planes) && planes_cfg_supported((int)p.cfg, p.kg);
+                            planes_usable(K, lddy, dy_planes, wt_planes) && planes_cfg_supported((int)p.cfg, p.kg) && !(p.coop && p.splits > 1);    // see fwd_impl
     const bool use_split = conv_f16() && wt_split != nullptr && w_amax != nullptr && env_int("DSRL_PRESPLIT", 1);
     if (wt == nullptr && use_planes) wt = (const float*)wt_planes;       // replaced below; no fp32 transpose is built for it
     if (wt == nullptr && use_split) wt = (const float*)wt_split;         // replaced below; no fp32 transpose is built for it
@@ -1701,6 +1712,7 @@ static int dgrad_impl(const float* dy, int lddy, const float* w, const float* wt
     ProfScope prof(prof_family(PASS_DGRAD), 2.0 * (double)dsrl_conv2d_inbounds_macs(N, H, W, C, K, R, S, stride, pad, dil), 4.0 * ((double)N * H * W * C + (double)K * R * S * C + (double)N * out_size(H, R, stride, pad, dil) * out_size(W, S, stride, pad, dil) * K), st);
     prof.shape("dgrad", N, H, W, C, K, R, stride, pad, dil);
     if (p.splits > 1 && !(p.coop && a.amax_a != nullptr && !a.planes && stride == 1)) {
+        DSRL_REQUIRE(bn == nullptr, DSRL_E_UNSUPPORTED, "conv2d_dgrad: BatchNorm sums asked from a split-K launch that reduces through slabs");
         a.y = slabs; a.ldy = C; a.bias = nullptr;
         if (int e = launch_igemm<true>(a, p.cfg, st)) return e;
         const long long total = (long long)p.M * C;
@@ -1738,7 +1750,7 @@ extern "C" int dsrl_conv2d_dgrad_stats_parts(int N, int H, int W, int C, int K, 
     const int Ho = out_size(H, R, stride, pad, dil), Wo = out_size(W, S, stride, pad, dil);
     if (Ho <= 0 || Wo <= 0) return 0;
     const int npl = conv_planes(PASS_DGRAD);
-    return fwd_stats_parts(plan_fwd(N, Ho, Wo, pad4(K), C, R, S, H, W, npl, true), npl, true);
+    return fwd_stats_parts(plan_dgrad(N, Ho, Wo, pad4(K), C, R, S, H, W, npl, stride), npl, true);
 }
 extern "C" int dsrl_conv2d_dgrad_bnstats(const float* dy, int lddy, const float* w, const float* wt_in, float* dx, int lddx,
                                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
