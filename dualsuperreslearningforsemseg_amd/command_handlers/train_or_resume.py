@@ -175,6 +175,7 @@ class TrainStep:
     def _finish(self, hp, in_graph):
         """Gradient exchange (when it did not run between the phases) and the optimiser step."""
         flat = self.flat
+        flat.settle_grads()                       # every gradient kernel of the pass has been enqueued or recorded: the arena fill could be skipped again
         hyper = self.hyper if self.rng is not None else None
         if flat.world > 1 and flat.defer_collectives:
             HF.flush_wgrad_queue()

@@ -90,6 +90,12 @@ class FlatParams:
         # gradient sink: kernels may write a parameter's gradient straight into its arena slot (functional._sink)
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._claimed = set()
+        # Round 5: zero_grad() skips the fill of the gradient arena (239.5 MB, 31 us) when every parameter's gradient kernel OVERWROTE its slot in the
+        # previous pass (claim: all 354 parameters of the stage-3 step do) - the same kernels will overwrite them again.  settle_grads() checks the
+        # assumption behind the skipped fill after the backward pass and refuses to go on if it did not hold (DSRL_LAZY_ZERO_GRAD=0: always fill).
+        self.lazy_zero = os.environ.get('DSRL_LAZY_ZERO_GRAD', '1') != '0'
+        self._all_claimed_last = False
+        self._fill_skipped = False
         for p in self.params:
             p._dsrl_arena = self
         self._build_transposed_filters()
@@ -325,7 +331,9 @@ class FlatParams:
             self.wt_valid, self.wt_fp32_valid, self.split_valid, self.planes_valid = True, not presplit, presplit, planes
 
     def zero_grad(self):
-        self.g_flat.zero_()
+        self._fill_skipped = self.lazy_zero and self._all_claimed_last
+        if not self._fill_skipped:
+            self.g_flat.zero_()
         self._claimed.clear()
         self._pending = [c[2] for c in self.chunks]
         self._works = []
@@ -341,6 +349,17 @@ class FlatParams:
                 HF.wgrad_queue = None
             if HF.f16_mode():
                 HF.amax_begin_step(self.device)     # operand-magnitude slots of this step (functional.amax_slot)
+
+    def settle_grads(self):
+        """After the backward pass (every gradient kernel enqueued or recorded): was it right not to zero the arena?  Remembers whether the next
+        zero_grad() may skip the fill."""
+        complete = len(self._claimed) == len(self.params)
+        if self._fill_skipped and not complete:
+            missing = [i for i in range(len(self.params)) if i not in self._claimed]
+            raise HF.DsrlHipError(f'{len(missing)} parameter gradients were not written by their kernels in this pass (first: parameter #{missing[0]}) although the '
+                                  'previous pass wrote all of them, and the gradient arena was not zeroed: the graph of the step changed - set DSRL_LAZY_ZERO_GRAD=0')
+        self._all_claimed_last = complete
+        self._fill_skipped = False
 
     def finish_reduction(self):
         """Waits (stream-wise) for the chunk all-reduces launched during backward; chunks whose hooks did not all fire

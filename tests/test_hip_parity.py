@@ -1463,6 +1463,48 @@ def test_train_steps_golden(golden):
                 check(host(v), g[f'step{step}.{k}'], 2e-4, f'step{step} {k}')
 
 
+@pytest.mark.parametrize('graph', [False, True])
+def test_gradient_arena_fill_skipped_only_because_every_slot_is_overwritten(graph, monkeypatch):
+    """ddp.FlatParams.zero_grad() skips the 240 MB fill once a whole pass has written every parameter's gradient through the sink protocol (round 5).
+    That is only sound if the kernels OVERWRITE their slots: poison the arena with NaN in front of a step and compare with a step that did zero it -
+    every gradient finite and bit-identical; and the guard: a pass that leaves a parameter unwritten after a skipped fill is refused."""
+    from dualsuperreslearningforsemseg_amd.command_handlers.train_or_resume import SyntheticCityscapes, TrainStep
+    from dualsuperreslearningforsemseg_amd.datasets.Cityscapes import settings as cs
+    from dualsuperreslearningforsemseg_amd.ddp import FlatParams
+    (img, org), (tgt, _) = next(iter(SyntheticCityscapes(2, (64, 128), torch.device(DEV), length=1)))
+    res = {}
+    for lazy in (True, False):
+        torch.manual_seed(77)
+        model = D.DSRL(3, cs).to(DEV).to(memory_format=torch.channels_last).train()
+        flat = FlatParams(model)
+        flat.lazy_zero = lazy
+        HF.set_dropout_seed(1234)
+        step = TrainStep(model, flat, 3, 0.1, 1.0, cs.IGNORE_CLASS_LABEL, graph=graph)
+
+        def poison(flat=flat):                  # every parameter's slot (the alignment padding between slots is written by nobody and stays zero)
+            for p_ in flat.params:
+                p_.grad.fill_(float('nan'))
+        for it in range(step.GRAPH_WARMUP + 3 if graph else 3):
+            if lazy and not graph and it >= 1:
+                assert flat._all_claimed_last                      # the previous pass wrote all of them: this step will not fill
+                poison()                                          # ... so whatever is in the slots must not matter
+            losses, _ = step(img, org, tgt, 0.0, 0.9, 0.0, True)            # lr 0: the parameters stay put
+        if graph:
+            if lazy:
+                poison()                                          # the captured step carries no fill either
+            losses, _ = step(img, org, tgt, 0.0, 0.9, 0.0, True)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(flat.g_flat).all()), 'a gradient slot kept what was in the arena'
+        res[lazy] = (flat.g_flat.clone(), losses)
+        if lazy and not graph:
+            flat.zero_grad()
+            assert flat._fill_skipped
+            with pytest.raises(HF.DsrlHipError, match='not written by their kernels'):
+                flat.settle_grads()                                # no backward pass in between: nothing was written
+        step.release()
+    assert torch.equal(res[True][0], res[False][0]) and res[True][1] == res[False][1]
+
+
 def test_full_model_train_steps_run():
     """Whole DSRL (ResNet-101 on the same kernels: 7x7 s2 stem, strided/dilated bottlenecks, max-pool, residual BN) takes
     three SGD steps on a 64x128 batch through TrainStep: finite losses, every parameter receives a gradient."""
