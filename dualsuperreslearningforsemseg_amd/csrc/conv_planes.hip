@@ -585,6 +585,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 // lies dsrl_planes_lo_offset(elements) bytes behind it.  K % 8 == 0 and C % 8 == 0 (host-checked).
 constexpr int kWtRowP = 10, kWtTilesPerBlockP = 4;
 __global__ __launch_bounds__(256) void filter_planes_batched_kernel(const long long* __restrict__ table, int n, long long total_tiles) {
+    // software-pipelined like weight_split_batched_kernel (round 5): the next tile's loads are in flight while this one is split and written
     __shared__ float tile[32][33];
     const long long b0 = (long long)blockIdx.x * kWtTilesPerBlockP;
     int lo_ = 0, hi_ = n - 1;
@@ -594,28 +595,46 @@ __global__ __launch_bounds__(256) void filter_planes_batched_kernel(const long l
     }
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int row = threadIdx.x >> 2, g8 = (threadIdx.x & 3) * 8;       // 128 threads write 32 rows x 4 units of 8 elements
-    for (int u = 0; u < kWtTilesPerBlockP; ++u) {
-        const long long b = b0 + u;
-        if (b >= total_tiles) break;
+    struct Tile { const long long* e; int tap, k0, c0; };
+    auto decode = [&](long long b) -> Tile {
         while (lo_ + 1 < n && table[(lo_ + 1) * kWtRowP + 6] <= b) ++lo_;
         const long long* e = table + lo_ * kWtRowP;
-        const float* w = reinterpret_cast<const float*>(e[0]);
-        char* wtp = reinterpret_cast<char*>(e[1]);
-        char* wp = reinterpret_cast<char*>(e[9]);
-        const int K = (int)e[2], RS = (int)e[4], C = (int)e[5], ct = (int)e[7];
-        const int kt = (K + 31) / 32;
+        const int K = (int)e[2], ct = (int)e[7], kt = (K + 31) / 32;
         int t = (int)(b - e[6]);
         const int tap = t / (ct * kt); t -= tap * ct * kt;
-        const int k0 = (t / ct) * 32, c0 = (t % ct) * 32;
-        const int sh = amax_shift(reinterpret_cast<const unsigned*>(e[8]));
-        const long long elems = (long long)K * RS * C, lo_off = planes_lo_offset(elems);
+        return Tile{e, tap, (t / ct) * 32, (t % ct) * 32};
+    };
+    auto fetch = [&](const Tile& T, float (&v)[4]) {
+        const float* w = reinterpret_cast<const float*>(T.e[0]);
+        const int K = (int)T.e[2], RS = (int)T.e[4], C = (int)T.e[5];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = T.k0 + ty + 8 * i, c = T.c0 + tx;
+            v[i] = (k < K && c < C) ? w[((long long)k * RS + T.tap) * C + c] : 0.f;
+        }
+    };
+    Tile cur = decode(b0);
+    float v[4];
+    fetch(cur, v);
+    unsigned am = amax_fetch(reinterpret_cast<const unsigned*>(cur.e[8]));
+    const long long* am_of = cur.e;
+    for (int u = 0; u < kWtTilesPerBlockP; ++u) {
+        if (b0 + u >= total_tiles) break;
         __syncthreads();
 #pragma unroll
-        for (int r = ty; r < 32; r += 8) {
-            const int k = k0 + r, c = c0 + tx;
-            tile[r][tx] = (k < K && c < C) ? w[((long long)k * RS + tap) * C + c] : 0.f;
-        }
+        for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = v[i];
+        const int sh = amax_shift_of(am);
         __syncthreads();
+        const Tile me = cur;
+        if (u + 1 < kWtTilesPerBlockP && b0 + u + 1 < total_tiles) {
+            cur = decode(b0 + u + 1);
+            fetch(cur, v);
+            if (cur.e != am_of) { am = amax_fetch(reinterpret_cast<const unsigned*>(cur.e[8])); am_of = cur.e; }
+        }
+        char* wtp = reinterpret_cast<char*>(me.e[1]);
+        char* wp = reinterpret_cast<char*>(me.e[9]);
+        const int K = (int)me.e[2], RS = (int)me.e[4], C = (int)me.e[5], tap = me.tap, k0 = me.k0, c0 = me.c0;
+        const long long elems = (long long)K * RS * C, lo_off = planes_lo_offset(elems);
         if (threadIdx.x < 128) {
             float r0[4], r1[4];
             {   // forward layout: row = out channel, 8 consecutive input channels
