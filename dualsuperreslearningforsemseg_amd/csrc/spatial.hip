@@ -959,8 +959,12 @@ __global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float* __restr
 // C = c*r*r floats on one side, r row segments of 32*r*c floats on the other - and the permutation happens in LDS ([pixel][channel][r*r + 1]:
 // the odd channel stride keeps the c planes of a pixel on different banks). Same values as the gather kernel above, only the traffic differs.
 constexpr int kPsTile = 32;
-__global__ __launch_bounds__(256) void pixel_shuffle_tiled_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H, int W, int c, int r, int inverse) {
+// CT, RT: the channel count / factor as compile-time constants (3, 8: the SISR decoder's PixelShuffle, DSRL.py:84) - the index arithmetic below is
+// divisions and remainders by them, per element; 0, 0: any shape, taken from the arguments
+template <int CT, int RT>
+__global__ __launch_bounds__(256) void pixel_shuffle_tiled_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H, int W, int c_, int r_, int inverse) {
     extern __shared__ float tile[];                               // [kPsTile][c][r*r + 1]
+    const int c = CT ? CT : c_, r = RT ? RT : r_;
     const int rr = r * r, C = c * rr, cs = rr + 1, ps = c * cs;
     const int tiles_w = (W + kPsTile - 1) / kPsTile;
     const int tw = blockIdx.x % tiles_w, row = blockIdx.x / tiles_w;          // row = n*H + h
@@ -1257,7 +1261,8 @@ static bool pixel_shuffle_tiled_ok(int N, int H, int W, int c, int r) {
 extern "C" int dsrl_pixel_shuffle_fwd(const float* x, float* y, int N, int H, int W, int c, int r, dsrl_stream_t stream) {
     DSRL_PROLOGUE(x && y && N > 0 && H > 0 && W > 0 && c > 0 && r > 0, "pixel_shuffle_fwd")
     if (pixel_shuffle_tiled_ok(N, H, W, c, r)) {
-        hipLaunchKernelGGL(pixel_shuffle_tiled_kernel, dim3((unsigned)((long long)N * H * ceil_div(W, kPsTile))), dim3(256), pixel_shuffle_tile_bytes(c, r), st, x, y, N, H, W, c, r, 0);
+        if (c == 3 && r == 8) hipLaunchKernelGGL((pixel_shuffle_tiled_kernel<3, 8>), dim3((unsigned)((long long)N * H * ceil_div(W, kPsTile))), dim3(256), pixel_shuffle_tile_bytes(c, r), st, x, y, N, H, W, c, r, 0);
+        else hipLaunchKernelGGL((pixel_shuffle_tiled_kernel<0, 0>), dim3((unsigned)((long long)N * H * ceil_div(W, kPsTile))), dim3(256), pixel_shuffle_tile_bytes(c, r), st, x, y, N, H, W, c, r, 0);
         return launch_status("pixel_shuffle_tiled_kernel");
     }
     hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(flat_grid((long long)N * H * W * c * r * r)), dim3(256), 0, st, x, y, N, H, W, c, r, 0);
@@ -1266,7 +1271,8 @@ extern "C" int dsrl_pixel_shuffle_fwd(const float* x, float* y, int N, int H, in
 extern "C" int dsrl_pixel_shuffle_bwd(const float* dy, float* dx, int N, int H, int W, int c, int r, dsrl_stream_t stream) {
     DSRL_PROLOGUE(dy && dx && N > 0 && H > 0 && W > 0 && c > 0 && r > 0, "pixel_shuffle_bwd")
     if (pixel_shuffle_tiled_ok(N, H, W, c, r)) {
-        hipLaunchKernelGGL(pixel_shuffle_tiled_kernel, dim3((unsigned)((long long)N * H * ceil_div(W, kPsTile))), dim3(256), pixel_shuffle_tile_bytes(c, r), st, dy, dx, N, H, W, c, r, 1);
+        if (c == 3 && r == 8) hipLaunchKernelGGL((pixel_shuffle_tiled_kernel<3, 8>), dim3((unsigned)((long long)N * H * ceil_div(W, kPsTile))), dim3(256), pixel_shuffle_tile_bytes(c, r), st, dy, dx, N, H, W, c, r, 1);
+        else hipLaunchKernelGGL((pixel_shuffle_tiled_kernel<0, 0>), dim3((unsigned)((long long)N * H * ceil_div(W, kPsTile))), dim3(256), pixel_shuffle_tile_bytes(c, r), st, dy, dx, N, H, W, c, r, 1);
         return launch_status("pixel_shuffle_tiled_kernel");
     }
     hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(flat_grid((long long)N * H * W * c * r * r)), dim3(256), 0, st, dy, dx, N, H, W, c, r, 1);
