@@ -764,22 +764,36 @@ __global__ __launch_bounds__(kFusedThreads) void bn_fused_bwd_kernel(const float
 
 
 // ---------------------------------------------------------------------------------------------- BN forward from conv-epilogue partials
+constexpr int kMergeRows = 4;      // partial rows a thread requests at once in the merges below
 // The producing conv already wrote (n, mean, M2) per (row block, channel) of its output (conv_igemm_split_kernel epilogue), so the
 // statistics pass and the device-wide barrier of bn_fused_fwd_kernel disappear: a block = (32-channel group) x (row slab) merges
 // the <= 256 partials of its own 32 channels (fp64, fixed order: every block of a group gets bit-identical statistics) and streams
 // x -> y once.  Any number of blocks; slab-0 blocks publish mean / invstd and update the running statistics.
-__global__ __launch_bounds__(256) void bn_stats_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int P, int C,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void bn_stats_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int P, int C,
                                                               int groups, int rows_per_slab, float eps, float momentum,
                                                               float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ rm, float* __restrict__ rv,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ res, int ldr, int relu, float drop_p, SeedArg seed_arg, unsigned rng_stream,
                                                               const float* __restrict__ part, int nparts, unsigned* __restrict__ y_amax) {
     const unsigned long long seed = seed_arg.dev ? *seed_arg.dev : seed_arg.value;     // device-resident key: replayable from a graph
-    __shared__ double shm[8][3][32];
+    constexpr int KG = THREADS / 32, RP = THREADS / 8;      // row groups of the merge, tensor rows per pass
+    __shared__ double shm[KG][3][32];
     __shared__ float fin[2][32];
     const int grp = blockIdx.x % groups, slab = blockIdx.x / groups;
     const int tid = threadIdx.x, l8 = tid & 7, rr = tid >> 3;
     const int q = grp * 8 + l8;
+    // The first row of the slab and the affine parameters are requested before the merge of the partials: a P = 4096 tensor gives a thread
+    // one row, and its load would otherwise start only behind the merge's two barriers.
+    const int row0 = slab * rows_per_slab, row1 = min(P, row0 + rows_per_slab), p0 = row0 + rr;
+    float4 xv0 = make_float4(0.f, 0.f, 0.f, 0.f), rv0 = xv0;
+    if (p0 < row1) {
+        xv0 = LD4(x, p0, ldx, q);
+        if (res) rv0 = LD4(res, p0, ldr, q);
+    }
+    float gmv[4], btv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gmv[j] = gamma[4 * q + j]; btv[j] = beta[4 * q + j]; }
     {
         const int ch = tid & 31, k = tid >> 5;
         const float* pn = part + grp * 32 + ch;
@@ -787,17 +801,31 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(const float* __rest
         const float* pq = pn + 2ll * nparts * C;
         const float mref = pm_[0];
         double N = 0, S = 0, T = 0;
-        for (int base = k; base < nparts; base += 32) {
-            float vn[4], vm[4], vq[4];
+        // rows k, k + KG, k + 2 KG, ... in that order; the next batch of rows is requested before this one is summed
+        struct Batch { float n[kMergeRows], m[kMergeRows], q[kMergeRows]; };
+        auto fetch = [&](int base, Batch& b) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int sl = min(base + 8 * u, nparts - 1);
-                vn[u] = pn[(long long)sl * C]; vm[u] = pm_[(long long)sl * C]; vq[u] = pq[(long long)sl * C];
+            for (int u = 0; u < kMergeRows; ++u) {
+                const int sl = min(base + KG * u, nparts - 1);
+                b.n[u] = pn[(long long)sl * C]; b.m[u] = pm_[(long long)sl * C]; b.q[u] = pq[(long long)sl * C];
             }
+        };
+        auto sum = [&](int base, const Batch& b) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double nb = base + 8 * u < nparts ? (double)vn[u] : 0.0, d = (double)vm[u] - (double)mref;
-                N += nb; S += nb * d; T += (base + 8 * u < nparts ? (double)vq[u] : 0.0) + nb * d * d;
+            for (int u = 0; u < kMergeRows; ++u) {
+                const double nb = base + KG * u < nparts ? (double)b.n[u] : 0.0, d = (double)b.m[u] - (double)mref;
+                N += nb; S += nb * d; T += (base + KG * u < nparts ? (double)b.q[u] : 0.0) + nb * d * d;
+            }
+        };
+        Batch b0, b1;
+        fetch(k, b0);
+        for (int base = k; base < nparts; base += 2 * KG * kMergeRows) {
+            const int mid = base + KG * kMergeRows;
+            if (mid < nparts) fetch(mid, b1);
+            sum(base, b0);
+            if (mid < nparts) {
+                if (mid + KG * kMergeRows < nparts) fetch(mid + KG * kMergeRows, b0);
+                sum(mid, b1);
             }
         }
         shm[k][0][ch] = N; shm[k][1][ch] = S; shm[k][2][ch] = T;
@@ -807,7 +835,7 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(const float* __rest
     if (tid < 32) {
         double N = 0, S = 0, T = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { N += shm[k][0][tid]; S += shm[k][1][tid]; T += shm[k][2][tid]; }
+        for (int k = 0; k < KG; ++k) { N += shm[k][0][tid]; S += shm[k][1][tid]; T += shm[k][2][tid]; }
         const double mu = N > 0 ? (double)fin[0][tid] + S / N : 0.0;
         const double Q = N > 0 ? fmax(T - S * S / N, 0.0) : 0.0;
         const double var = N > 0 ? Q / N : 0.0;
@@ -823,28 +851,33 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(const float* __rest
     __syncthreads();
     float sc[4], sf[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int c = 4 * q + j; sc[j] = gamma[c] * fin[1][4 * l8 + j]; sf[j] = beta[c] - fin[0][4 * l8 + j] * sc[j]; }
+    for (int j = 0; j < 4; ++j) { sc[j] = gmv[j] * fin[1][4 * l8 + j]; sf[j] = btv[j] - fin[0][4 * l8 + j] * sc[j]; }
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    const int row0 = slab * rows_per_slab, row1 = min(P, row0 + rows_per_slab);
     unsigned am = 0u;
-#pragma unroll 4
-    for (int p = row0 + rr; p < row1; p += 32) {
-        const float4 xv = LD4(x, p, ldx, q);
+    auto row = [&](int p, const float4 xv, const float4 r) {
         float v[4] = {fmaf(xv.x, sc[0], sf[0]), fmaf(xv.y, sc[1], sf[1]), fmaf(xv.z, sc[2], sf[2]), fmaf(xv.w, sc[3], sf[3])};
-        if (res) { const float4 r = LD4(res, p, ldr, q); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        if (res) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
         if (relu) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         if (drop_p > 0.f) {
             const unsigned long long e = (unsigned long long)p * C + 4ull * q;
-            unsigned r[4];
-            philox4x32_10((unsigned)(e >> 2), (unsigned)(e >> 34), rng_stream, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
+            unsigned r4[4];
+            philox4x32_10((unsigned)(e >> 2), (unsigned)(e >> 34), rng_stream, 0u, (unsigned)seed, (unsigned)(seed >> 32), r4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = ((float)(r[j] >> 8) * 5.9604644775390625e-08f >= drop_p) ? v[j] * ks : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = ((float)(r4[j] >> 8) * 5.9604644775390625e-08f >= drop_p) ? v[j] * ks : 0.f;
         }
         ST4(y, p, ldy, q) = make_float4(v[0], v[1], v[2], v[3]);
         am = abs_bits4(am, v[0], v[1], v[2], v[3]);
+    };
+    if (p0 < row1) row(p0, xv0, rv0);
+#pragma unroll 4
+    for (int p = p0 + RP; p < row1; p += RP) {
+        const float4 xv = LD4(x, p, ldx, q);
+        float4 r = xv;
+        if (res) r = LD4(res, p, ldr, q);
+        row(p, xv, r);
     }
     amax_publish(am, y_amax);
 }
@@ -865,9 +898,19 @@ __global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __res
     const float* pq = pn + 2ll * nparts * C;
     const float mref = p0 < p1 ? pm_[(long long)p0 * C] : 0.f;
     double N = 0, S = 0, T = 0;
-    for (int sl = p0 + k; sl < p1; sl += 8) {
-        const double nb = (double)pn[(long long)sl * C], d = (double)pm_[(long long)sl * C] - (double)mref;
-        N += nb; S += nb * d; T += (double)pq[(long long)sl * C] + nb * d * d;
+    for (int base = p0 + k; base < p1; base += 32) {        // rows p0 + k, + 8, ... in order, four requested at once
+        float vn[4], vm[4], vq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int sl = min(base + 8 * u, p1 - 1);
+            vn[u] = pn[(long long)sl * C]; vm[u] = pm_[(long long)sl * C]; vq[u] = pq[(long long)sl * C];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (base + 8 * u < p1) {
+                const double nb = (double)vn[u], d = (double)vm[u] - (double)mref;
+                N += nb; S += nb * d; T += (double)vq[u] + nb * d * d;
+            }
     }
     shm[k][0][ch] = N; shm[k][1][ch] = S; shm[k][2][ch] = T;
     if (k == 0) ref[ch] = mref;
@@ -889,7 +932,17 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_reduce_kernel(const float* _
     const float* pa = part + grp * 32 + ch;
     const float* pb = pa + (long long)nparts * C;
     double a = 0, b = 0;
-    for (int sl = p0 + k; sl < p1; sl += 8) { a += (double)pa[(long long)sl * C]; b += (double)pb[(long long)sl * C]; }
+    for (int base = p0 + k; base < p1; base += 32) {
+        float va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int sl = min(base + 8 * u, p1 - 1);
+            va[u] = pa[(long long)sl * C]; vb[u] = pb[(long long)sl * C];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (base + 8 * u < p1) { a += (double)va[u]; b += (double)vb[u]; }
+    }
     shm[k][0][ch] = a; shm[k][1][ch] = b;
     __syncthreads();
     if (tid < 32) {
@@ -904,32 +957,57 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_reduce_kernel(const float* _
 // BN backward from dgrad-epilogue partials: the conv whose data gradient IS this BatchNorm's output gradient already left
 // sum(g) and sum(g * xhat) per (row block, channel) (conv_igemm_split_kernel, DGRAD epilogue); merge them for the block's 32
 // channels (fp64, fixed order) and stream x, y, dy -> dx once.  No reduction pass, no device-wide barrier.
-__global__ __launch_bounds__(256) void bn_bwd_stats_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void bn_bwd_stats_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
                                                                   const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
                                                                   float* __restrict__ dres, int lddr, int P, int C, int groups, int rows_per_slab,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int relu, int training,
                                                                   const float* __restrict__ part, int nparts, unsigned* __restrict__ dx_amax, float ks) {
-    __shared__ double shm[8][2][32];
+    constexpr int KG = THREADS / 32, RP = THREADS / 8;
+    __shared__ double shm[KG][2][32];
     __shared__ float fin[2][32];
     const int grp = blockIdx.x % groups, slab = blockIdx.x / groups;
     const int tid = threadIdx.x, l8 = tid & 7, rr = tid >> 3;
     const int q = grp * 8 + l8;
+    // first row and per-channel constants requested before the merge (see bn_stats_apply_kernel)
+    const int row0 = slab * rows_per_slab, row1 = min(P, row0 + rows_per_slab), p0 = row0 + rr;
+    float4 dv0 = make_float4(0.f, 0.f, 0.f, 0.f), xv0 = dv0, yv0 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (p0 < row1) {
+        dv0 = LD4(dy, p0, lddy, q); xv0 = LD4(x, p0, ldx, q);
+        if (relu) yv0 = LD4(y, p0, ldy, q);
+    }
+    float mu[4], is[4], gi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = mean[4 * q + j]; is[j] = invstd[4 * q + j]; gi[j] = gamma[4 * q + j]; }
     {
         const int ch = tid & 31, k = tid >> 5;
         const float* pa = part + grp * 32 + ch;
         const float* pb = pa + (long long)nparts * C;
         double a = 0, b = 0;
-        for (int base = k; base < nparts; base += 32) {
-            float va[4], vb[4];
+        struct Batch { float a[kMergeRows], b[kMergeRows]; };      // same schedule as the forward merge: rows k, k + KG, ... in order
+        auto fetch = [&](int base, Batch& t) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int sl = min(base + 8 * u, nparts - 1);
-                va[u] = pa[(long long)sl * C]; vb[u] = pb[(long long)sl * C];
+            for (int u = 0; u < kMergeRows; ++u) {
+                const int sl = min(base + KG * u, nparts - 1);
+                t.a[u] = pa[(long long)sl * C]; t.b[u] = pb[(long long)sl * C];
             }
+        };
+        auto sum = [&](int base, const Batch& t) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (base + 8 * u < nparts) { a += va[u]; b += vb[u]; }
+            for (int u = 0; u < kMergeRows; ++u)
+                if (base + KG * u < nparts) { a += t.a[u]; b += t.b[u]; }
+        };
+        Batch b0, b1;
+        fetch(k, b0);
+        for (int base = k; base < nparts; base += 2 * KG * kMergeRows) {
+            const int mid = base + KG * kMergeRows;
+            if (mid < nparts) fetch(mid, b1);
+            sum(base, b0);
+            if (mid < nparts) {
+                if (mid + KG * kMergeRows < nparts) fetch(mid + KG * kMergeRows, b0);
+                sum(mid, b1);
+            }
         }
         shm[k][0][ch] = a; shm[k][1][ch] = b;
     }
@@ -937,7 +1015,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_apply_kernel(const float* __
     if (tid < 32) {
         double a = 0, b = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { a += shm[k][0][tid]; b += shm[k][1][tid]; }
+        for (int k = 0; k < KG; ++k) { a += shm[k][0][tid]; b += shm[k][1][tid]; }
         const float inv_n = 1.f / (float)P;
         fin[0][tid] = training ? (float)a * inv_n : 0.f; fin[1][tid] = training ? (float)b * inv_n : 0.f;
         if (slab == 0) {
@@ -947,19 +1025,11 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_apply_kernel(const float* __
         }
     }
     __syncthreads();
-    float mu[4], is[4], gi[4], mb[4], mg[4];
+    float mb[4], mg[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = 4 * q + j;
-        mu[j] = mean[c]; is[j] = invstd[c]; gi[j] = gamma[c] * is[j]; mb[j] = fin[0][4 * l8 + j]; mg[j] = fin[1][4 * l8 + j];
-    }
-    const int row0 = slab * rows_per_slab, row1 = min(P, row0 + rows_per_slab);
+    for (int j = 0; j < 4; ++j) { gi[j] *= is[j]; mb[j] = fin[0][4 * l8 + j]; mg[j] = fin[1][4 * l8 + j]; }
     unsigned am = 0u;
-#pragma unroll 2
-    for (int p = row0 + rr; p < row1; p += 32) {
-        const float4 dv = LD4(dy, p, lddy, q), xv = LD4(x, p, ldx, q);
-        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (relu) yv = LD4(y, p, ldy, q);
+    auto row = [&](int p, const float4 dv, const float4 xv, const float4 yv) {
         // ks: 1 / (1 - p) of a Dropout behind the ReLU (the combined mask is y > 0), else 1 (exact)
         const float g0 = masked_grad(dv.x, yv.x, relu, 0.f, ks), g1 = masked_grad(dv.y, yv.y, relu, 0.f, ks);
         const float g2 = masked_grad(dv.z, yv.z, relu, 0.f, ks), g3 = masked_grad(dv.w, yv.w, relu, 0.f, ks);
@@ -968,6 +1038,14 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_apply_kernel(const float* __
         ST4(dx, p, lddx, q) = d;
         am = abs_bits4(am, d.x, d.y, d.z, d.w);
         if (dres) ST4(dres, p, lddr, q) = make_float4(g0, g1, g2, g3);
+    };
+    if (p0 < row1) row(p0, dv0, xv0, yv0);
+#pragma unroll 2
+    for (int p = p0 + RP; p < row1; p += RP) {
+        const float4 dv = LD4(dy, p, lddy, q), xv = LD4(x, p, ldx, q);
+        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (relu) yv = LD4(y, p, ldy, q);
+        row(p, dv, xv, yv);
     }
     amax_publish(am, dx_amax);
 }
@@ -1184,6 +1262,20 @@ static SeedArg seed_arg(uint64_t seed) {
     return SeedArg{(unsigned long long)seed, g_rng_dev_key[dev].load()};
 }
 static int env_int_bn(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+// The from-statistics kernels: every block merges the partials of its channel group again, and what that costs is the bytes a CU pulls through its L1
+// (128 partials x 4 blocks of 256 threads per CU: 3.4 us on a 3.7 us launch; 2 blocks of 512: 1.8 us; 1 block of 1024: 0.9 us - but the streaming part
+// of a 1024-thread block is 0.3 us slower on a 4 MB tensor and 1.5 us on a 16 MB one, profiles/round5_bn_prologue_probe.txt).  So: 512 threads, and
+// 1024 where there are many partials over a small tensor.  DSRL_BN_APPLY_THREADS = 256 | 512 | 1024 forces one size.
+static int stats_apply_threads(int64_t P, int C, int nparts) {
+    static const int forced = [] { const int v = env_int_bn("DSRL_BN_APPLY_THREADS", 0); return v == 256 || v == 512 || v == 1024 ? v : 0; }();
+    if (forced) return forced;
+    return nparts >= 128 && P * C <= (2ll << 20) ? 1024 : 512;
+}
+static int stats_apply_rows(int64_t P, int groups, int threads) {        // rows per slab: ~(4 * 256 * 256 / threads) blocks, at least one pass of rows each
+    const int rp = threads / 8;
+    const int64_t slabs = std::max<int64_t>(1, std::min<int64_t>(ceil_div(P, rp), ceil_div((int64_t)4 * 256 * 256 / threads, groups)));
+    return (int)ceil_div(P, slabs);
+}
 static std::atomic<int> g_fused_max_blocks{-1};      // dsrl_bn_fused_max_blocks(); -1 = DSRL_BN_FUSED / DSRL_BN_FUSED_BIG from the environment
 struct FusedPlan { bool ok; int blocks, groups, slabs, rows_per_slab; };
 // eligible: C a power-of-two multiple of 32 and the tensor fits the registers of 128 (P*C <= 4.2 M elements) or 256 blocks (8.4 M)
@@ -1343,11 +1435,12 @@ extern "C" int dsrl_bn_train_fwd_from_stats(const float* x, int ldx, float* y, i
         if (int e = launch_status("bn_stats_reduce_kernel")) return e;
         stats = red; stats_parts = kStatsReduced;
     }
-    int slabs = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(P, 32), ceil_div(4 * 256, groups)));     // ~4 blocks per CU, >= 32 rows each
-    const int rows_per_slab = (int)ceil_div(P, (int64_t)slabs);
-    slabs = (int)ceil_div(P, (int64_t)rows_per_slab);
-    hipLaunchKernelGGL(bn_stats_apply_kernel, dim3((unsigned)(groups * slabs)), dim3(256), 0, st, x, ldx, y, ldy, (int)P, C, groups, rows_per_slab, eps, momentum,
-                       mean, invstd, running_mean, running_var, gamma, beta, residual, ldr, relu, drop_p, seed_arg(seed), (unsigned)rng_stream, stats, stats_parts, y_amax);
+    const int T = stats_apply_threads(P, C, stats_parts), rows_per_slab = stats_apply_rows(P, groups, T), slabs = (int)ceil_div(P, (int64_t)rows_per_slab);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)(groups * slabs)), dim3(T), 0, st, x, ldx, y, ldy, (int)P, C, groups, rows_per_slab, eps, momentum,
+                           mean, invstd, running_mean, running_var, gamma, beta, residual, ldr, relu, drop_p, seed_arg(seed), (unsigned)rng_stream, stats, stats_parts, y_amax);
+    };
+    if (T == 1024) go(bn_stats_apply_kernel<1024>); else if (T == 512) go(bn_stats_apply_kernel<512>); else go(bn_stats_apply_kernel<256>);
     return launch_status("bn_stats_apply_kernel");
 }
 
@@ -1418,11 +1511,12 @@ extern "C" int dsrl_bn_bwd_from_stats_drop(const float* x, int ldx, const float*
         if (int e = launch_status("bn_bwd_stats_reduce_kernel")) return e;
         stats = red; stats_parts = kStatsReduced;
     }
-    int slabs = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(P, 32), ceil_div(4 * 256, groups)));
-    const int rows_per_slab = (int)ceil_div(P, (int64_t)slabs);
-    slabs = (int)ceil_div(P, (int64_t)rows_per_slab);
-    hipLaunchKernelGGL(bn_bwd_stats_apply_kernel, dim3((unsigned)(groups * slabs)), dim3(256), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (int)P, C,
-                       groups, rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, training, stats, stats_parts, dx_amax, ks);
+    const int T = stats_apply_threads(P, C, stats_parts), rows_per_slab = stats_apply_rows(P, groups, T), slabs = (int)ceil_div(P, (int64_t)rows_per_slab);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)(groups * slabs)), dim3(T), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (int)P, C,
+                           groups, rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, training, stats, stats_parts, dx_amax, ks);
+    };
+    if (T == 1024) go(bn_bwd_stats_apply_kernel<1024>); else if (T == 512) go(bn_bwd_stats_apply_kernel<512>); else go(bn_bwd_stats_apply_kernel<256>);
     return launch_status("bn_bwd_stats_apply_kernel");
 }
 
