@@ -87,17 +87,17 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     sh[0][sl][cl] = na; sh[1][sl][cl] = ma; sh[2][sl][cl] = qa;
     __syncthreads();
     if (sl != 0 || c >= C) return;
-    double n2 = 0, m2 = 0, q2 = 0;
+    // the 32 slices relative to slice 0's mean (it always holds row block 0): N = sum n, S = sum n d, T = sum (M2 + n d^2), d = mean_s - mref - the
+    // merge of the from-statistics kernels.  (Until round 5 this was Chan's pairwise update, 32 steps with two dependent fp64 divisions each: ~10 us
+    // for a launch with nothing else in it.)
+    const double mref = sh[1][0][cl];
+    double n2 = 0, S = 0, T = 0;
+#pragma unroll 8
     for (int s2 = 0; s2 < 32; ++s2) {
-        const double nb = sh[0][s2][cl];
-        if (nb > 0) {
-            const double mb = sh[1][s2][cl], qb = sh[2][s2][cl];
-            const double nt = n2 + nb, d = mb - m2;
-            m2 += d * (nb / nt);
-            q2 += qb + d * d * (n2 * nb / nt);
-            n2 = nt;
-        }
+        const double nb = sh[0][s2][cl], d = (double)sh[1][s2][cl] - mref;
+        n2 += nb; S += nb * d; T += (double)sh[2][s2][cl] + nb * d * d;
     }
+    const double m2 = n2 > 0 ? mref + S / n2 : 0.0, q2 = n2 > 0 ? fmax(T - S * S / n2, 0.0) : 0.0;
     const double var = n2 > 0 ? q2 / n2 : 0.0;
     mean[c] = (float)m2;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
