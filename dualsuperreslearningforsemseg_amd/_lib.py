@@ -108,6 +108,8 @@ PROTOTYPES = {
     'dsrl_pointwise_strided_bwd_workspace_bytes': (sz, [i32] * 5),
     'dsrl_pointwise_strided_bwd': (i32, [fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, fp, sz, stream_t]),
     'dsrl_copy2d': (i32, [fp, i32, fp, i32, i64, i32, stream_t]),
+    'dsrl_cat_channels_supported': (i32, [fp, fp, fp, i32, fp, i32, i64]),          # srcs / lds / cs: host arrays (ctypes)
+    'dsrl_cat_channels': (i32, [fp, fp, fp, i32, fp, i32, i64, fp, stream_t]),
     'dsrl_nchw_to_nhwc': (i32, [fp, fp, i32, i32, i32, i32, i32, stream_t]),
     'dsrl_ce_workspace_bytes': (sz, [i64]),
     'dsrl_ce_fwd': (i32, [fp, i32, fp, i64, i32, i32, fp, fp, sz, stream_t]),

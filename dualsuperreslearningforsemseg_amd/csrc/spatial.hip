@@ -1322,6 +1322,61 @@ extern "C" int dsrl_copy2d(const float* src, int ld_src, float* dst, int ld_dst,
     return DSRL_OK;
 }
 
+// ---- channel concatenation as ONE launch (ASPP.py:44: five 256-channel branches; DSRL.py:165: 256 + 48 channels).  Until round 5 every source was a
+// hipMemcpy2DAsync (a rect-copy node per source in the step's graph) and the consumers' operand magnitude a dsrl_amax pass over the finished buffer
+// (80 MB read again for the decoder's concat).  Here one kernel writes all sources into their channel ranges and leaves max |value| in the record.
+constexpr int kCatMaxSources = 8;
+struct CatArgs { const float* src[kCatMaxSources]; int ld4[kCatMaxSources]; int end4[kCatMaxSources]; int n; };      // float4 units; end4 = prefix sums of the widths
+__global__ __launch_bounds__(256) void cat_channels_kernel(const CatArgs a, float4* __restrict__ dst, int ld_dst4, unsigned total, unsigned ctot4, unsigned* __restrict__ amax) {
+    // 32-bit index arithmetic (host: fewer than 2^31 float4 per tensor span) and ONE division per thread: (pixel, column) advance by the grid stride with a
+    // carry.  (A 64-bit division per element made the first version of this kernel slower than the copies it replaces.)  Four elements in flight.
+    const unsigned stride = gridDim.x * 256u, dp = stride / ctot4, dq = stride - dp * ctot4;
+    unsigned e = blockIdx.x * 256u + threadIdx.x;
+    unsigned p = e / ctot4, q = e - p * ctot4;
+    unsigned am = 0u;
+    auto locate = [&](unsigned pp, unsigned qq, const float4*& sp, float4*& dp_) {
+        unsigned s = 0, q0 = 0;
+#pragma unroll
+        for (int i = 0; i < kCatMaxSources - 1; ++i)
+            if (i < a.n - 1 && qq >= (unsigned)a.end4[i]) { s = i + 1; q0 = (unsigned)a.end4[i]; }
+        sp = reinterpret_cast<const float4*>(a.src[s]) + (pp * (unsigned)a.ld4[s] + (qq - q0));
+        dp_ = dst + (pp * (unsigned)ld_dst4 + qq);
+    };
+    auto step = [&]() { e += stride; p += dp; q += dq; if (q >= ctot4) { q -= ctot4; ++p; } };
+    while (e < total) {
+        const float4* sp[4]; float4* dq4[4]; float4 v[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ok[u] = e < total;
+            if (ok[u]) { locate(p, q, sp[u], dq4[u]); v[u] = *sp[u]; }
+            step();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ok[u]) { *dq4[u] = v[u]; am = abs_bits4(am, v[u].x, v[u].y, v[u].z, v[u].w); }
+    }
+    amax_publish(am, amax);
+}
+
+extern "C" int dsrl_cat_channels_supported(const float* const* srcs, const int* lds, const int* cs, int n, const float* dst, int ld_dst, int64_t P) {
+    if (!srcs || !lds || !cs || n < 1 || n > kCatMaxSources || !dst || ld_dst % 4 || ((uintptr_t)dst % 16) || P <= 0 || P * (ld_dst / 4) >= (1ll << 31)) return 0;
+    for (int i = 0; i < n; ++i)
+        if (!srcs[i] || cs[i] <= 0 || cs[i] % 4 || lds[i] % 4 || lds[i] < cs[i] || ((uintptr_t)srcs[i] % 16) || P * (lds[i] / 4) >= (1ll << 31)) return 0;
+    return 1;      // the kernel indexes float4 with 32 bits
+}
+
+extern "C" int dsrl_cat_channels(const float* const* srcs, const int* lds, const int* cs, int n, float* dst, int ld_dst, int64_t P, uint32_t* amax, dsrl_stream_t stream) {
+    DSRL_PROLOGUE(dsrl_cat_channels_supported(srcs, lds, cs, n, dst, ld_dst, P), "cat_channels: 1..8 sources, widths and strides multiples of 4, 16-byte aligned, spans below 2^31 float4")
+    CatArgs a{};
+    int tot = 0;
+    for (int i = 0; i < n; ++i) { a.src[i] = srcs[i]; a.ld4[i] = lds[i] / 4; tot += cs[i] / 4; a.end4[i] = tot; }
+    a.n = n;
+    DSRL_REQUIRE(4 * tot <= ld_dst, DSRL_E_BADARG, "cat_channels: %d channels do not fit the destination stride %d", 4 * tot, ld_dst);
+    hipLaunchKernelGGL(cat_channels_kernel, dim3(flat_grid(P * tot, 256, 4096)), dim3(256), 0, st, a, reinterpret_cast<float4*>(dst), ld_dst / 4, (unsigned)(P * tot), (unsigned)tot,
+                       (unsigned*)amax);
+    return launch_status("cat_channels_kernel");
+}
+
 extern "C" int dsrl_pad_image_nhwc(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* y,
                                    int N, int C, int H, int W, int Cp, int top, int left, int Hp, int Wp, dsrl_stream_t stream) {
     DSRL_PROLOGUE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C && top >= 0 && left >= 0 && Hp >= H + top && Wp >= W + left, "pad_image_nhwc")

@@ -4,6 +4,7 @@ Tensors keep the reference's logical NCHW shapes; physically they are torch.chan
 [P][ld] for the kernels), which the wrappers enforce with at most one strided copy at the boundary.  Every op
 raises if its tensors are not on a HIP device: there is no CPU / stock-ATen fallback in this package.
 """
+import ctypes
 import os
 import weakref
 
@@ -1174,6 +1175,9 @@ def max_pool3x3s2(x):
     return _MaxPool3x3s2.apply(x)
 
 
+cat_one_launch = os.environ.get('DSRL_CAT_ONE_LAUNCH', '1') != '0'        # 0: a strided copy per source + a magnitude pass by the consumer (until round 5)
+
+
 class _Cat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *xs):
@@ -1183,9 +1187,20 @@ class _Cat(torch.autograd.Function):
         y = new_cl((N, ctot, H, W), xs[0][0])
         off = 0
         st = _stream()
-        for x, ld in xs:
-            call('dsrl_copy2d', x.data_ptr(), ld, y.data_ptr() + 4 * off, ctot, N * H * W, x.shape[1], st)
-            off += x.shape[1]
+        n = len(xs)
+        srcs = (ctypes.c_void_p * n)(*[x.data_ptr() for x, _ in xs])
+        lds = (ctypes.c_int32 * n)(*[ld for _, ld in xs])
+        cs = (ctypes.c_int32 * n)(*[x.shape[1] for x, _ in xs])
+        if cat_one_launch and n <= 8 and query('dsrl_cat_channels_supported', srcs, lds, cs, n, y.data_ptr(), ctot, N * H * W):
+            # one kernel for all sources, and it leaves the magnitude the consuming convs scale their operand by (no dsrl_amax pass over the buffer)
+            ya = amax_slot(y.device) if f16_mode() else None
+            call('dsrl_cat_channels', srcs, lds, cs, n, y.data_ptr(), ctot, N * H * W, None if ya is None else ya.data_ptr(), st)
+            if ya is not None:
+                set_amax(y, ya)
+        else:
+            for x, ld in xs:
+                call('dsrl_copy2d', x.data_ptr(), ld, y.data_ptr() + 4 * off, ctot, N * H * W, x.shape[1], st)
+                off += x.shape[1]
         ctx.sizes = [x.shape[1] for x, _ in xs]
         return y
 

@@ -358,6 +358,13 @@ int dsrl_pointwise_strided_bwd(const float* x, const float* w, const float* dy, 
 
 /* channel concatenation (ASPP.py:44, DSRL.py:165): dst[p*ld_dst + c] = src[p*ld_src + c], c < C (strided 2-D copy) */
 int dsrl_copy2d(const float* src, int ld_src, float* dst, int ld_dst, int64_t P, int C, dsrl_stream_t stream);
+/* the whole concatenation as one launch (round 5): sources srcs[i] (HOST array of n <= 8 device pointers; pixel strides lds[i], widths cs[i], all multiples of
+ * 4, 16-byte aligned) written side by side into dst (pixel stride ld_dst), and max |value| of everything written left in the amax record `amax`
+ * (nullable) - the consumers of a concatenated buffer (ASPP.py:44 -> the 1280 -> 256 projection; DSRL.py:165 -> cat_conv.0 and the SISR conv) need that
+ * magnitude for their operand scale and used to measure it with a pass of its own.  dsrl_cat_channels_supported: 1 when the arguments qualify (the
+ * kernel indexes float4 with 32 bits: P * stride / 4 < 2^31 for every tensor). */
+int dsrl_cat_channels_supported(const float* const* srcs, const int* lds, const int* cs, int n, const float* dst, int ld_dst, int64_t P);
+int dsrl_cat_channels(const float* const* srcs, const int* lds, const int* cs, int n, float* dst, int ld_dst, int64_t P, uint32_t* amax, dsrl_stream_t stream);
 
 /* layout converters at the boundary (NCHW image in, ResNet101.py:92): y has Cpad >= C channels, extra = 0 */
 int dsrl_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, dsrl_stream_t stream);

@@ -1323,6 +1323,46 @@ def test_train_step_stage1_stage2_b8_256x512(stage):
     assert all(v == 0.0 for v in fa) and (all(v == 0.0 for v in ms) if stage == 1 else all(v > 0.0 for v in ms))
 
 
+@pytest.mark.parametrize('widths,strided', [((256, 48), False), ((256, 256, 256, 256, 256), False), ((64, 32), True), ((19, 48), False)])
+def test_channel_concatenation_in_one_launch_with_its_magnitude(widths, strided, monkeypatch):
+    """torch.cat(dim=1) of ASPP.py:44 / DSRL.py:165 as ONE kernel (dsrl_cat_channels) that also leaves max |value| in the amax record the consuming convs
+    scale their operand by: bit-identical to the per-source strided copies (DSRL_CAT_ONE_LAUNCH=0) and to numpy; the record equals the measured maximum;
+    the gradient is the channel slices.  The last case (19 channels) does not qualify and takes the copies."""
+    rs = np.random.RandomState(len(widths))
+    N, H, W = 2, 16, 32
+    xs = [rs.standard_normal((N, c, H, W)).astype(np.float32) * (i + 1) for i, c in enumerate(widths)]
+    def make():
+        ts = []
+        for x in xs:
+            t = dev(x)
+            if strided:             # a channel slice of a wider pixel-major buffer (pixel stride 2c)
+                t = torch.cat([t, t], 1).contiguous(memory_format=torch.channels_last)[:, :x.shape[1]]
+            ts.append(t.requires_grad_(True))
+        return ts
+    got = {}
+    dyh = rs.standard_normal((N, sum(widths), H, W)).astype(np.float32)
+    for mode in (True, False):
+        monkeypatch.setattr(HF, 'cat_one_launch', mode)
+        ts = make()
+        y = HF.cat_channels(ts)
+        rec = HF.carried_amax(y)
+        y.backward(dev(dyh))
+        torch.cuda.synchronize()
+        got[mode] = (host(y), [host(t.grad) for t in ts], rec)
+    ref = np.concatenate(xs, 1)
+    assert np.array_equal(got[True][0], ref) and np.array_equal(got[False][0], ref)
+    off = 0
+    for a, b, c in zip(got[True][1], got[False][1], widths):
+        assert np.array_equal(a, b) and np.array_equal(a, dyh[:, off:off + c])
+        off += c
+    if all(c % 4 == 0 for c in widths) and HF.f16_mode():
+        rec = got[True][2]
+        assert rec is not None and got[False][2] is None
+        assert float(rec.view(torch.float32).max()) == float(np.abs(ref).max())       # abs bits of non-negative floats order like the floats
+    else:
+        assert got[True][2] is None
+
+
 def test_amax_record_goes_stale_with_the_tensor():
     """A magnitude record cached on a tensor (functional.amax_for) must not outlive what it describes: the step arena is rewound and zeroed by the
     next step (a zero record would scale by 2^140: Inf / NaN), and an in-place write changes the values under the record.  The
