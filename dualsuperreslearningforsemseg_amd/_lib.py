@@ -85,6 +85,8 @@ PROTOTYPES = {
     'dsrl_bn_bwd': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, f32, i32, fp, sz, fp, stream_t]),
     'dsrl_bn_bwd_from_stats': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, i32, fp, i32, fp, stream_t]),
     'dsrl_bn_bwd_from_stats_drop': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, f32, i32, fp, i32, fp, stream_t]),
+    'dsrl_bn_bwd_from_stats_res_parts': (i32, [i64, i32, i32]),
+    'dsrl_bn_bwd_from_stats_res': (i32, [fp, i32, fp, i32, fp, i32, fp, i32, fp, i32, i64, i32, fp, fp, fp, fp, fp, i32, f32, i32, fp, i32, fp, fp, i32, fp, fp, fp, i32, stream_t]),
     'dsrl_dropout_fwd': (i32, [fp, i32, fp, i32, i64, i32, f32, u64, u32, stream_t]),
     'dsrl_dropout_bwd': (i32, [fp, i32, fp, i32, i64, i32, f32, u64, u32, stream_t]),
     'dsrl_bilinear_ac_fwd': (i32, [fp, i32, fp, i32, i32, i32, i32, i32, i32, i32, stream_t]),

@@ -957,13 +957,18 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_reduce_kernel(const float* _
 // BN backward from dgrad-epilogue partials: the conv whose data gradient IS this BatchNorm's output gradient already left
 // sum(g) and sum(g * xhat) per (row block, channel) (conv_igemm_split_kernel, DGRAD epilogue); merge them for the block's 32
 // channels (fp64, fixed order) and stream x, y, dy -> dx once.  No reduction pass, no device-wide barrier.
-template <int THREADS>
+// RES2 (round 5): the residual of this BatchNorm is the output of ANOTHER BatchNorm without ReLU (the downsample branch of a layer's first bottleneck:
+// out = relu(bn3(.) + bn_ds(conv_ds(x)))), whose output gradient is the masked gradient g this kernel writes to dres.  With that BatchNorm's input x2 and
+// statistics the block also leaves ITS backward partial sums - sum g, sum g * xhat2 per (slab, channel) in part2 [2][slabs][C] - so that its backward is one
+// from-statistics launch instead of the three-kernel / barrier path (a read of x2 here against a pass over x2, dres there).
+struct BnRes2 { const float* x; int ldx; const float* mean; const float* invstd; float* part; int nslabs; };
+template <int THREADS, bool RES2 = false>
 __global__ __launch_bounds__(THREADS) void bn_bwd_stats_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
                                                                   const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
                                                                   float* __restrict__ dres, int lddr, int P, int C, int groups, int rows_per_slab,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int relu, int training,
-                                                                  const float* __restrict__ part, int nparts, unsigned* __restrict__ dx_amax, float ks) {
+                                                                  const float* __restrict__ part, int nparts, unsigned* __restrict__ dx_amax, float ks, const BnRes2 r2) {
     constexpr int KG = THREADS / 32, RP = THREADS / 8;
     __shared__ double shm[KG][2][32];
     __shared__ float fin[2][32];
@@ -972,10 +977,16 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_stats_apply_kernel(const float
     const int q = grp * 8 + l8;
     // first row and per-channel constants requested before the merge (see bn_stats_apply_kernel)
     const int row0 = slab * rows_per_slab, row1 = min(P, row0 + rows_per_slab), p0 = row0 + rr;
-    float4 dv0 = make_float4(0.f, 0.f, 0.f, 0.f), xv0 = dv0, yv0 = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 dv0 = make_float4(0.f, 0.f, 0.f, 0.f), xv0 = dv0, yv0 = make_float4(1.f, 1.f, 1.f, 1.f), x2v0 = dv0;
     if (p0 < row1) {
         dv0 = LD4(dy, p0, lddy, q); xv0 = LD4(x, p0, ldx, q);
         if (relu) yv0 = LD4(y, p0, ldy, q);
+        if constexpr (RES2) x2v0 = LD4(r2.x, p0, r2.ldx, q);
+    }
+    float mu2[4] = {0.f, 0.f, 0.f, 0.f}, is2[4] = {0.f, 0.f, 0.f, 0.f}, sg2[4] = {0.f, 0.f, 0.f, 0.f}, sgx2[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (RES2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mu2[j] = r2.mean[4 * q + j]; is2[j] = r2.invstd[4 * q + j]; }
     }
     float mu[4], is[4], gi[4];
 #pragma unroll
@@ -1029,7 +1040,7 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_stats_apply_kernel(const float
 #pragma unroll
     for (int j = 0; j < 4; ++j) { gi[j] *= is[j]; mb[j] = fin[0][4 * l8 + j]; mg[j] = fin[1][4 * l8 + j]; }
     unsigned am = 0u;
-    auto row = [&](int p, const float4 dv, const float4 xv, const float4 yv) {
+    auto row = [&](int p, const float4 dv, const float4 xv, const float4 yv, const float4 x2v) {
         // ks: 1 / (1 - p) of a Dropout behind the ReLU (the combined mask is y > 0), else 1 (exact)
         const float g0 = masked_grad(dv.x, yv.x, relu, 0.f, ks), g1 = masked_grad(dv.y, yv.y, relu, 0.f, ks);
         const float g2 = masked_grad(dv.z, yv.z, relu, 0.f, ks), g3 = masked_grad(dv.w, yv.w, relu, 0.f, ks);
@@ -1038,14 +1049,42 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_stats_apply_kernel(const float
         ST4(dx, p, lddx, q) = d;
         am = abs_bits4(am, d.x, d.y, d.z, d.w);
         if (dres) ST4(dres, p, lddr, q) = make_float4(g0, g1, g2, g3);
+        if constexpr (RES2) {
+            sg2[0] += g0; sgx2[0] += g0 * ((x2v.x - mu2[0]) * is2[0]);
+            sg2[1] += g1; sgx2[1] += g1 * ((x2v.y - mu2[1]) * is2[1]);
+            sg2[2] += g2; sgx2[2] += g2 * ((x2v.z - mu2[2]) * is2[2]);
+            sg2[3] += g3; sgx2[3] += g3 * ((x2v.w - mu2[3]) * is2[3]);
+        }
     };
-    if (p0 < row1) row(p0, dv0, xv0, yv0);
+    if (p0 < row1) row(p0, dv0, xv0, yv0, x2v0);
 #pragma unroll 2
     for (int p = p0 + RP; p < row1; p += RP) {
         const float4 dv = LD4(dy, p, lddy, q), xv = LD4(x, p, ldx, q);
         float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
         if (relu) yv = LD4(y, p, ldy, q);
-        row(p, dv, xv, yv);
+        float4 x2v = xv;
+        if constexpr (RES2) x2v = LD4(r2.x, p, r2.ldx, q);
+        row(p, dv, xv, yv, x2v);
+    }
+    if constexpr (RES2) {
+        // the block's sums per channel: lanes that share l8 (same four channels) within a wave, then the waves through LDS in the order 0 .. THREADS/64 - 1
+        __shared__ float r2s[THREADS / 64][2][32];
+#pragma unroll
+        for (int sft = 8; sft < 64; sft <<= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sg2[j] += __shfl_xor(sg2[j], sft); sgx2[j] += __shfl_xor(sgx2[j], sft); }
+        if ((tid & 63) < 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { r2s[tid >> 6][0][4 * l8 + j] = sg2[j]; r2s[tid >> 6][1][4 * l8 + j] = sgx2[j]; }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int v = tid >> 5, c = tid & 31;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < THREADS / 64; ++w) t += r2s[w][v][c];
+            r2.part[((long long)v * r2.nslabs + slab) * C + grp * 32 + c] = t;
+        }
     }
     amax_publish(am, dx_amax);
 }
@@ -1491,10 +1530,43 @@ extern "C" int dsrl_bn_bwd_from_stats(const float* x, int ldx, const float* y, i
     return dsrl_bn_bwd_from_stats_drop(x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, P, C, mean, invstd, gamma, dgamma, dbeta, relu, 0.f, training, stats, stats_parts,
                                        dx_amax, stream);
 }
+// slabs (= row blocks of the residual branch's partial sums) the from-statistics backward of a [P][C] tensor launches when handed stats_parts partials
+static int bwd_from_stats_slabs(int64_t P, int C, int stats_parts) {
+    const int parts = stats_parts > 256 ? kStatsReduced : stats_parts, groups = C / 32, T = stats_apply_threads(P, C, parts);
+    return (int)ceil_div(P, (int64_t)stats_apply_rows(P, groups, T));
+}
+extern "C" int dsrl_bn_bwd_from_stats_res_parts(int64_t P, int C, int stats_parts) {
+    return (P > 0 && P < (1ll << 31) && C > 0 && C % 32 == 0 && stats_parts > 0 && stats_parts <= 4096) ? bwd_from_stats_slabs(P, C, stats_parts) : 0;
+}
+static int bn_bwd_from_stats_impl(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
+                                  float* dresidual, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
+                                  float* dgamma, float* dbeta, int relu, float drop_p, int training, float* stats, int stats_parts, uint32_t* dx_amax,
+                                  dsrl_stream_t stream, const BnRes2* res2);
 extern "C" int dsrl_bn_bwd_from_stats_drop(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
                                            float* dresidual, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
                                            float* dgamma, float* dbeta, int relu, float drop_p, int training, float* stats, int stats_parts, uint32_t* dx_amax,
                                            dsrl_stream_t stream) {
+    return bn_bwd_from_stats_impl(x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, P, C, mean, invstd, gamma, dgamma, dbeta, relu, drop_p, training, stats, stats_parts,
+                                  dx_amax, stream, nullptr);
+}
+extern "C" int dsrl_bn_bwd_from_stats_res(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
+                                          float* dresidual, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
+                                          float* dgamma, float* dbeta, int relu, float drop_p, int training, float* stats, int stats_parts, uint32_t* dx_amax,
+                                          const float* res_x, int res_ldx, const float* res_mean, const float* res_invstd, float* res_stats, int res_parts,
+                                          dsrl_stream_t stream) {
+    DSRL_REQUIRE(dresidual && res_x && res_mean && res_invstd && res_stats && res_ldx >= C && res_ldx % 4 == 0 && ((uintptr_t)res_x % 16) == 0, DSRL_E_BADARG,
+                 "bn_bwd_from_stats_res: the residual branch's input / statistics / partials buffer are required (stride a multiple of 4, 16-byte aligned)");
+    DSRL_REQUIRE(res_parts > 0 && res_parts == dsrl_bn_bwd_from_stats_res_parts(P, C, stats_parts), DSRL_E_BADARG,
+                 "bn_bwd_from_stats_res: this launch writes %d row blocks of sums, the caller expects %d (dsrl_bn_bwd_from_stats_res_parts)",
+                 dsrl_bn_bwd_from_stats_res_parts(P, C, stats_parts), res_parts);
+    const BnRes2 r2{res_x, res_ldx, res_mean, res_invstd, res_stats, res_parts};
+    return bn_bwd_from_stats_impl(x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, P, C, mean, invstd, gamma, dgamma, dbeta, relu, drop_p, training, stats, stats_parts,
+                                  dx_amax, stream, &r2);
+}
+static int bn_bwd_from_stats_impl(const float* x, int ldx, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
+                                  float* dresidual, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
+                                  float* dgamma, float* dbeta, int relu, float drop_p, int training, float* stats, int stats_parts, uint32_t* dx_amax,
+                                  dsrl_stream_t stream, const BnRes2* res2) {
     DSRL_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || relu), DSRL_E_BADARG, "bn_bwd_from_stats_drop: dropout p=%f needs the ReLU mask (y > 0)", drop_p);
     const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     DSRL_REQUIRE(x && dy && dx && mean && invstd && gamma && stats && P > 0 && P < (1ll << 31) && C > 0, DSRL_E_BADARG, "bn_bwd_from_stats: bad arguments");
@@ -1512,11 +1584,14 @@ extern "C" int dsrl_bn_bwd_from_stats_drop(const float* x, int ldx, const float*
         stats = red; stats_parts = kStatsReduced;
     }
     const int T = stats_apply_threads(P, C, stats_parts), rows_per_slab = stats_apply_rows(P, groups, T), slabs = (int)ceil_div(P, (int64_t)rows_per_slab);
+    BnRes2 r2{};
+    if (res2) { r2 = *res2; DSRL_REQUIRE(r2.nslabs == slabs, DSRL_E_BADARG, "bn_bwd_from_stats_res: %d slabs launched, %d expected", slabs, r2.nslabs); }
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3((unsigned)(groups * slabs)), dim3(T), 0, st, x, ldx, y, ldy, dy, lddy, dx, lddx, dresidual, lddr, (int)P, C,
-                           groups, rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, training, stats, stats_parts, dx_amax, ks);
+                           groups, rows_per_slab, mean, invstd, gamma, dgamma, dbeta, relu, training, stats, stats_parts, dx_amax, ks, r2);
     };
-    if (T == 1024) go(bn_bwd_stats_apply_kernel<1024>); else if (T == 512) go(bn_bwd_stats_apply_kernel<512>); else go(bn_bwd_stats_apply_kernel<256>);
+    if (res2) { if (T == 1024) go(bn_bwd_stats_apply_kernel<1024, true>); else if (T == 512) go(bn_bwd_stats_apply_kernel<512, true>); else go(bn_bwd_stats_apply_kernel<256, true>); }
+    else if (T == 1024) go(bn_bwd_stats_apply_kernel<1024>); else if (T == 512) go(bn_bwd_stats_apply_kernel<512>); else go(bn_bwd_stats_apply_kernel<256>);
     return launch_status("bn_bwd_stats_apply_kernel");
 }
 

@@ -942,9 +942,12 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, grad_slot=None
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, drop_p, seed, rng_stream, residual, rslot=None,
-                stats=None, stats_parts=0, out_link=None):
+                stats=None, stats_parts=0, out_link=None, res_link=None):
         ctx.rslot = rslot
         ctx.out_link = out_link
+        # the residual is the output of a BatchNorm without ReLU (downsample branch) that feeds only this add: our backward leaves that BatchNorm's sums
+        ctx.res_link = res_link if (res_link is not None and res_link.valid and not res_link.relu and residual is not None
+                                    and res_link.y_ptr == residual.data_ptr() and res_link.y_shape == tuple(x.shape)) else None
         x, ldx = pm(x)
         _need_gpu(gamma, beta, running_mean, running_var)
         N, Cc, H, W = x.shape
@@ -1011,9 +1014,20 @@ class _BNAct(torch.autograd.Function):
         link = ctx.out_link
         if link is not None and link.stats is not None and link.dx_ptr == dy.data_ptr() and lddy == Cc and (drop_p == 0.0 or relu):
             # the gradient we received is the buffer the consuming conv's dgrad wrote, and it left our two per-channel sums with it
-            call('dsrl_bn_bwd_from_stats_drop', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,
-                 None if dres is None else dres.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                 dgamma.data_ptr(), dbeta.data_ptr(), int(relu), float(drop_p), int(training), link.stats.data_ptr(), int(link.parts), dxa_ptr, _stream())
+            rl = ctx.res_link
+            rparts = int(query('dsrl_bn_bwd_from_stats_res_parts', P, Cc, int(link.parts))) if (rl is not None and dres is not None and bn_res_stats_enabled) else 0
+            if rparts > 0:
+                # ... and the masked gradient we write to dres is the output gradient of the downsample branch's BatchNorm: leave its sums as well
+                rstats = torch.empty(cquery('dsrl_bn_stats_floats', 2, rparts, Cc), device=x.device, dtype=torch.float32)
+                _, rld = pm(rl.x)
+                call('dsrl_bn_bwd_from_stats_res', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc, dres.data_ptr(), Cc, P, Cc,
+                     mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), int(relu), float(drop_p), int(training),
+                     link.stats.data_ptr(), int(link.parts), dxa_ptr, rl.x.data_ptr(), rld, rl.mean.data_ptr(), rl.invstd.data_ptr(), rstats.data_ptr(), rparts, _stream())
+                rl.stats, rl.parts, rl.dx_ptr = rstats, rparts, dres.data_ptr()
+            else:
+                call('dsrl_bn_bwd_from_stats_drop', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,
+                     None if dres is None else dres.data_ptr(), Cc, P, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                     dgamma.data_ptr(), dbeta.data_ptr(), int(relu), float(drop_p), int(training), link.stats.data_ptr(), int(link.parts), dxa_ptr, _stream())
         else:
             ws = _ws(cquery('dsrl_bn_workspace_bytes', P, Cc), x)
             call('dsrl_bn_bwd', x.data_ptr(), ldx, y.data_ptr(), Cc, dy.data_ptr(), lddy, dx.data_ptr(), Cc,
@@ -1030,10 +1044,13 @@ class _BNAct(torch.autograd.Function):
                 ctx.rslot.buf = dres            # published: a later dgrad of the same input accumulates into it (GradSlot)
             else:
                 ctx.rslot.closed = True
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, dres, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, dres, None, None, None, None, None
 
 
-def batch_norm_act(x, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual=None, residual_grad_slot=None, stats=None, out_link=None):
+bn_res_stats_enabled = os.environ.get('DSRL_BN_RES_STATS', '1') != '0'       # 0: the downsample BatchNorm reduces its own backward sums (until round 5)
+
+
+def batch_norm_act(x, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual=None, residual_grad_slot=None, stats=None, out_link=None, res_link=None):
     """BatchNorm2d `bn` (an nn.BatchNorm2d holding the parameters/buffers) + optional residual add, ReLU, Dropout."""
     training = bn.training or bn.running_mean is None
     if training and bn.running_mean is not None:
@@ -1042,7 +1059,7 @@ def batch_norm_act(x, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual
     return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, relu,
                         drop_p if training or drop_p == 0.0 else 0.0, seed, rng_stream, residual, residual_grad_slot if residual is not None else None,
                         stats[0] if (stats is not None and training) else None, stats[1] if (stats is not None and training) else 0,
-                        out_link if bn_bwd_stats_enabled else None)
+                        out_link if bn_bwd_stats_enabled else None, res_link if (bn_bwd_stats_enabled and residual is not None) else None)
 
 
 # BatchNorm statistics from the conv epilogue: the conv that feeds a training-mode BN leaves (n, mean, M2) partials of its output, and
@@ -1051,7 +1068,7 @@ conv_bn_stats_enabled = os.environ.get('DSRL_CONV_BN_STATS', '1') != '0'
 
 
 def conv2d_bn_act(x, weight, bias, stride, padding, dilation, bn, relu=False, drop_p=0.0, seed=0, rng_stream=0, residual=None,
-                  grad_slot=None, residual_grad_slot=None, in_link=None, out_link=None):
+                  grad_slot=None, residual_grad_slot=None, in_link=None, out_link=None, res_link=None):
     """batch_norm_act(conv2d(x, ...), bn, ...) with the BN batch statistics taken from the conv epilogue when the launch can provide
     them (split-precision kernels, no split-K, <= 256 row blocks, out channels a multiple of 32)."""
     training = bn.training or bn.running_mean is None
@@ -1062,11 +1079,11 @@ def conv2d_bn_act(x, weight, bias, stride, padding, dilation, bn, relu=False, dr
         if parts > 0:
             y, stats = _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation), grad_slot, parts, in_link)
             return batch_norm_act(y, bn, relu=relu, drop_p=drop_p, seed=seed, rng_stream=rng_stream, residual=residual,
-                                  residual_grad_slot=residual_grad_slot, stats=(stats, parts), out_link=out_link)
+                                  residual_grad_slot=residual_grad_slot, stats=(stats, parts), out_link=out_link, res_link=res_link)
     y = (_Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation), grad_slot, 0, in_link)
          if (in_link is not None and x.is_cuda and C % 4 == 0) else conv2d(x, weight, bias, stride, padding, dilation, grad_slot=grad_slot))
     return batch_norm_act(y, bn, relu=relu, drop_p=drop_p, seed=seed, rng_stream=rng_stream, residual=residual,
-                          residual_grad_slot=residual_grad_slot, out_link=out_link)
+                          residual_grad_slot=residual_grad_slot, out_link=out_link, res_link=res_link)
 
 
 class _Dropout(torch.autograd.Function):

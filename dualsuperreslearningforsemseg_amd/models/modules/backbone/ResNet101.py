@@ -45,11 +45,14 @@ class Bottleneck(t.nn.Module):
             lin = None
         elif lin is not None:
             slot.link = lin
+        lds = None
         if self.downsample is None:
             identity = x
         elif len(self.downsample) == 2 and isinstance(self.downsample[0], HipConv2d) and self.downsample[0].bias is None:
             ds = self.downsample[0]
-            identity = HF.conv2d_bn_act(x, ds.weight, None, ds.stride[0], ds.padding[0], ds.dilation[0], self.downsample[1], grad_slot=slot, in_link=lin)
+            # the downsample BatchNorm's output feeds only bn3's residual add: bn3's backward writes its output gradient and leaves its sums (HF.BNLink)
+            lds = HF.BNLink() if (HF.bn_bwd_stats_enabled and HF.bn_res_stats_enabled and t.is_grad_enabled()) else None
+            identity = HF.conv2d_bn_act(x, ds.weight, None, ds.stride[0], ds.padding[0], ds.dilation[0], self.downsample[1], grad_slot=slot, in_link=lin, out_link=lds)
         else:
             if slot is not None:
                 slot.closed = True
@@ -62,7 +65,7 @@ class Bottleneck(t.nn.Module):
         out = HF.conv2d_bn_act(x, c1.weight, None, c1.stride[0], c1.padding[0], c1.dilation[0], self.bn1, relu=True, grad_slot=slot, out_link=l1, in_link=lin)
         out = HF.conv2d_bn_act(out, c2.weight, None, c2.stride[0], c2.padding[0], c2.dilation[0], self.bn2, relu=True, in_link=l1, out_link=l2)
         out = HF.conv2d_bn_act(out, c3.weight, None, c3.stride[0], c3.padding[0], c3.dilation[0], self.bn3, relu=True, residual=identity,   # bn3 + identity, ReLU
-                               residual_grad_slot=slot if self.downsample is None else None, in_link=l2, out_link=l3)
+                               residual_grad_slot=slot if self.downsample is None else None, in_link=l2, out_link=l3, res_link=lds)
         if l3 is not None and l3.valid and HF.bn_bwd_stats_shared:
             out._dsrl_bnlink = l3       # picked up by the next block, whose conv1 / downsample conv complete this tensor's gradient
         return out

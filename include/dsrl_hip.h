@@ -289,6 +289,18 @@ int dsrl_bn_bwd_from_stats_drop(const float* x, int ldx, const float* y /*nullab
                            float* dresidual /*nullable*/, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
                            float* dgamma /*nullable*/, float* dbeta /*nullable*/, int relu, float drop_p, int training, float* stats, int stats_parts,
                            uint32_t* dx_amax /*nullable*/, dsrl_stream_t stream);
+/* ... when the residual added before the ReLU is itself the output of a BatchNorm without ReLU - the downsample branch of a layer's first bottleneck,
+ * out = relu(bn3(.) + bn_ds(conv_ds(x))), models/modules/backbone/ResNet101.py:67-89 (torchvision Bottleneck.forward) - its output gradient is the masked
+ * gradient this launch writes to dresidual (required).  Given that BatchNorm's input res_x (pixel stride res_ldx) and batch statistics, the launch also
+ * leaves ITS two backward sums per (row block, channel) in res_stats [2][res_parts][C] (room per dsrl_bn_stats_floats(2, res_parts, C)), res_parts =
+ * dsrl_bn_bwd_from_stats_res_parts(P, C, stats_parts): the downsample BatchNorm's backward then is dsrl_bn_bwd_from_stats on dresidual - one streaming
+ * launch instead of a reduction pass + apply pass (or the device-wide-barrier kernel) over the same tensors. */
+int dsrl_bn_bwd_from_stats_res_parts(int64_t P, int C, int stats_parts);
+int dsrl_bn_bwd_from_stats_res(const float* x, int ldx, const float* y /*nullable*/, int ldy, const float* dy, int lddy, float* dx, int lddx,
+                           float* dresidual, int lddr, int64_t P, int C, const float* mean, const float* invstd, const float* gamma,
+                           float* dgamma /*nullable*/, float* dbeta /*nullable*/, int relu, float drop_p, int training, float* stats, int stats_parts,
+                           uint32_t* dx_amax /*nullable*/, const float* res_x, int res_ldx, const float* res_mean, const float* res_invstd,
+                           float* res_stats, int res_parts, dsrl_stream_t stream);
 
 /* Device-resident dropout key. By default every dropout-bearing launch (dsrl_bn_apply, dsrl_bn_train_fwd*, dsrl_dropout_*) bakes its
  * `seed` argument into the launch. After dsrl_rng_bind_device_key(ptr) the kernels of the CURRENT device ignore that argument and read

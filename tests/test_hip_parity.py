@@ -1696,6 +1696,53 @@ def test_grad_slots_match_autograd_accumulation():
         assert np.array_equal(grads[0][k], grads[1][k]), k          # downstream of every shared buffer: untouched
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 16, 32), (1, 256, 50, 100), (8, 128, 32, 64)])
+def test_bn_backward_leaves_the_sums_of_the_residual_branch_batchnorm(shape):
+    """out = relu(bn3(a) + bn_ds(b)) (first bottleneck of a layer, ResNet101.py:67-89): the backward of bn3 from given sums (dsrl_bn_bwd_from_stats_res)
+    writes the masked gradient g = dy * [out > 0] to dresidual - the output gradient of bn_ds - and leaves bn_ds's two backward sums per (row block,
+    channel).  dx / dresidual bit-identical to dsrl_bn_bwd_from_stats; the sums against numpy; bn_ds's backward from those sums against the fp64 oracle."""
+    N, C, H, W = shape
+    P = N * H * W
+    rs = np.random.RandomState(sum(shape))
+    a, b = rs.standard_normal((N, C, H, W)).astype(np.float32), rs.standard_normal((N, C, H, W)).astype(np.float32) * 2 + 0.5
+    out = np.maximum(rs.standard_normal((N, C, H, W)), 0).astype(np.float32)
+    dy = rs.standard_normal((N, C, H, W)).astype(np.float32)
+    mean, invstd, gamma = rs.standard_normal(C).astype(np.float32), rs.uniform(0.5, 2, C).astype(np.float32), rs.standard_normal(C).astype(np.float32)
+    mean2 = b.mean((0, 2, 3)).astype(np.float32); invstd2 = (1 / np.sqrt(b.astype(np.float64).var((0, 2, 3)) + 1e-5)).astype(np.float32)
+    gamma2 = rs.standard_normal(C).astype(np.float32)
+    g = dy * (out > 0)
+    xh = (a.astype(np.float64) - mean[None, :, None, None]) * invstd[None, :, None, None]
+    stats = np.stack([g.astype(np.float64).sum((0, 2, 3)), (g * xh).sum((0, 2, 3))]).astype(np.float32)       # one row block of partials
+    at, bt, ot, dyt = dev(a), dev(b), dev(out), dev(dy)
+    mt, it, gt, m2t, i2t, g2t, stt = dev(mean), dev(invstd), dev(gamma), dev(mean2), dev(invstd2), dev(gamma2), dev(stats.reshape(-1))
+    st = torch.cuda.current_stream().cuda_stream
+    rparts = int(HF.query('dsrl_bn_bwd_from_stats_res_parts', P, C, 1))
+    assert rparts > 0
+    res = {}
+    for name in ('dsrl_bn_bwd_from_stats_res', 'dsrl_bn_bwd_from_stats_drop'):
+        dx, dres = torch.empty_like(at), torch.empty_like(at)
+        dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        rst = torch.full((int(HF.query('dsrl_bn_stats_floats', 2, rparts, C)),), float('nan'), device=DEV)
+        extra = (bt.data_ptr(), C, m2t.data_ptr(), i2t.data_ptr(), rst.data_ptr(), rparts) if name.endswith('_res') else ()
+        HF.call(name, at.data_ptr(), C, ot.data_ptr(), C, dyt.data_ptr(), C, dx.data_ptr(), C, dres.data_ptr(), C, P, C, mt.data_ptr(), it.data_ptr(), gt.data_ptr(),
+                dg.data_ptr(), db.data_ptr(), 1, 0.0, 1, stt.data_ptr(), 1, None, *extra, st)
+        torch.cuda.synchronize()
+        res[name] = (host(dx), host(dres), rst, dres)
+    r, d = res['dsrl_bn_bwd_from_stats_res'], res['dsrl_bn_bwd_from_stats_drop']
+    assert np.array_equal(r[0], d[0]) and np.array_equal(r[1], d[1]) and np.array_equal(r[1], g)
+    sums = r[2][:2 * rparts * C].view(2, rparts, C).double().sum(1).cpu().numpy()
+    xh2 = (b.astype(np.float64) - mean2[None, :, None, None]) * invstd2[None, :, None, None]
+    check(sums[0], g.astype(np.float64).sum((0, 2, 3)), 1e-5, 'sum g'); check(sums[1], (g * xh2).sum((0, 2, 3)), 1e-5, 'sum g xhat2')
+    # the downsample BatchNorm's backward from those sums (no ReLU, no residual of its own)
+    dx2 = torch.empty_like(at)
+    dg2, db2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    HF.call('dsrl_bn_bwd_from_stats', bt.data_ptr(), C, None, C, r[3].data_ptr(), C, dx2.data_ptr(), C, None, C, P, C, m2t.data_ptr(), i2t.data_ptr(), g2t.data_ptr(),
+            dg2.data_ptr(), db2.data_ptr(), 0, 1, r[2].data_ptr(), rparts, None, st)
+    torch.cuda.synchronize()
+    dxo, dgo, dbo = O.batchnorm_train_bwd(b.astype(np.float64), gamma2.astype(np.float64), mean2.astype(np.float64), invstd2.astype(np.float64), g.astype(np.float64))
+    check(host(dx2), dxo, 1e-5, 'dx of the downsample BatchNorm'); check(host(dg2), dgo, 1e-5, 'dgamma'); check(host(db2), dbo, 1e-5, 'dbeta')
+
+
 @pytest.mark.parametrize('shared', [False, True])
 def test_bn_backward_statistics_from_dgrad_epilogue(shared):
     """functional.BNLink: bn1 / bn2 of every bottleneck take their two backward sums from the partials the consuming conv's dgrad left
@@ -1712,8 +1759,10 @@ def test_bn_backward_statistics_from_dgrad_epilogue(shared):
 
     def counting(name, *a):
         key = 'dsrl_conv2d_dgrad_bnstats' if (name == 'dsrl_conv2d_dgrad_planes_drop' and a[31] is not None) else name       # a[31]: the bstats argument
-        key = 'dsrl_bn_bwd_from_stats' if name == 'dsrl_bn_bwd_from_stats_drop' else key
+        key = 'dsrl_bn_bwd_from_stats' if name in ('dsrl_bn_bwd_from_stats_drop', 'dsrl_bn_bwd_from_stats_res') else key
         counts[-1][key] = counts[-1].get(key, 0) + 1
+        if name == 'dsrl_bn_bwd_from_stats_res':
+            counts[-1]['res'] = counts[-1].get('res', 0) + 1
         return orig_call(name, *a)
 
     try:
@@ -1739,8 +1788,12 @@ def test_bn_backward_statistics_from_dgrad_epilogue(shared):
     # bn1, bn2 of 33 bottlenecks + bn3 of the blocks whose output feeds only the next block (completed by its accumulating dgrad)
     # (a BN whose output has a further consumer - layer1's output also feeds the decoder - receives a summed gradient and rightly ignores them)
     # (round 5: + the two decoder BatchNorms of cat_conv, whose outputs feed conv4 / cls_conv only)
+    # (round 5: + the downsample BatchNorm of each layer's first bottleneck, whose sums bn3's backward leaves while it writes the residual gradient:
+    #  dsrl_bn_bwd_from_stats_res - needs bn3 itself on the from-statistics path, i.e. `shared`)
     lo, hi = (92, 101) if shared else (68, 68)
-    assert lo <= counts[1].get('dsrl_bn_bwd_from_stats', 0) <= counts[1].get('dsrl_conv2d_dgrad_bnstats', 0) <= hi
+    res = counts[1].get('res', 0)
+    assert res == (4 if (shared and HF.bn_res_stats_enabled) else 0), counts[1]
+    assert lo <= counts[1].get('dsrl_bn_bwd_from_stats', 0) - res <= counts[1].get('dsrl_conv2d_dgrad_bnstats', 0) <= hi
     bad = {k: rel_err(grads[1][k], grads[0][k]) for k in grads[0] if rel_err(grads[1][k], grads[0][k]) > 5e-4}
     assert not bad, bad
 
