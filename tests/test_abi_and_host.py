@@ -152,6 +152,31 @@ def test_bn_fused_block_budget_roundtrip():
     assert HF.set_bn_fused_max_blocks(first if first >= 0 else None) == -1
 
 
+def test_concat_and_residual_sum_queries_host_side():
+    """Host-only halves of two round-5 entry points (no GPU needed): dsrl_cat_channels_supported checks source count, widths / strides (multiples of 4),
+    alignment and the 32-bit float4 index range; dsrl_bn_bwd_from_stats_res_parts reports the row blocks of residual-branch sums the backward launch of a
+    [P][C] tensor writes (0 for shapes that launch cannot take) and never more than the partials buffer is sized for."""
+    import ctypes
+    from dualsuperreslearningforsemseg_amd import functional as HF
+
+    def ok(ptrs, lds, cs, dst, ld_dst, P):
+        n = len(ptrs)
+        return HF.query('dsrl_cat_channels_supported', (ctypes.c_void_p * n)(*ptrs), (ctypes.c_int32 * n)(*lds), (ctypes.c_int32 * n)(*cs), n, dst, ld_dst, P)
+
+    base = 1 << 20
+    assert ok([base, base + 4096], [256, 48], [256, 48], base + 8192, 304, 65536) == 1            # DSRL.py:165
+    assert ok([base + 1024 * i for i in range(5)], [256] * 5, [256] * 5, base, 1280, 4096) == 1    # ASPP.py:44
+    assert ok([base, base + 4096], [19, 48], [19, 48], base + 8192, 67, 65536) == 0               # widths not multiples of 4: per-source copies
+    assert ok([base + 4, base + 4096], [256, 48], [256, 48], base + 8192, 304, 65536) == 0        # unaligned source
+    assert ok([base] * 9, [4] * 9, [4] * 9, base, 36, 16) == 0                                    # more than eight sources
+    assert ok([base, base + 4096], [256, 48], [256, 48], base + 8192, 304, 1 << 26) == 0          # 2^26 pixels x 76 float4: beyond the 32-bit index
+    for P, C, parts in ((65536, 256, 32), (16384, 512, 128), (4096, 1024, 64), (4096, 2048, 32), (1000, 64, 1), (65536, 64, 1024)):
+        n = HF.query('dsrl_bn_bwd_from_stats_res_parts', P, C, parts)
+        assert 0 < n <= 1024 and HF.query('dsrl_bn_stats_floats', 2, n, C) >= 2 * n * C, (P, C, parts, n)
+    assert HF.query('dsrl_bn_bwd_from_stats_res_parts', 4096, 48, 32) == 0                         # C % 32 != 0: no from-statistics launch
+    assert HF.query('dsrl_bn_bwd_from_stats_res_parts', 4096, 256, 0) == 0
+
+
 @pytest.mark.parametrize('unit,least', [('conv_planes', 100), ('convt_dma', 10)])
 def test_lds_dma_inline_asm_is_the_only_m0_user(tmp_path, unit, least):
     """lds_dma.h sets M0 inside inline asm without declaring it (hipcc refuses "m0" as a clobber: reserved register).  That is sound only while
