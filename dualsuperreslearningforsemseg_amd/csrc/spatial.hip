@@ -39,26 +39,44 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
     }
 }
 
-// four channels per thread (C, the pixel strides % 4 == 0, 16-byte aligned bases): the index arithmetic is paid once per float4 and in 32 bits;
-// the arithmetic per element is the scalar kernel's, so the results are bit-identical
+// four channels per thread: the index arithmetic (and, in the backward passes, the tap weights) is paid once per group of four and in 32 bits; the arithmetic
+// per element is the scalar kernel's, so the results are bit-identical.  VEC: C, the pixel strides % 4 == 0, 16-byte aligned bases - one 16-byte access per
+// tensor and tap.  !VEC (round 5): any width (the 19-channel upsample of DSRL.py:54) - the last group is short and the accesses are 4-byte ones.
+template <bool VEC> __device__ __forceinline__ float4 ldg4(const float* p, int nv) {
+    if constexpr (VEC) return *reinterpret_cast<const float4*>(p);
+    float4 v = make_float4(p[0], 0.f, 0.f, 0.f);
+    if (nv > 1) v.y = p[1];
+    if (nv > 2) v.z = p[2];
+    if (nv > 3) v.w = p[3];
+    return v;
+}
+template <bool VEC> __device__ __forceinline__ void stg4(float* p, const float4 v, int nv) {
+    if constexpr (VEC) { *reinterpret_cast<float4*>(p) = v; return; }
+    p[0] = v.x;
+    if (nv > 1) p[1] = v.y;
+    if (nv > 2) p[2] = v.z;
+    if (nv > 3) p[3] = v.w;
+}
+template <bool VEC>
 __global__ __launch_bounds__(256) void bilinear_fwd4_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
-                                                             int N, int H, int W, int C4, int Ho, int Wo, float sh, float sw) {
+                                                             int N, int H, int W, int C, int C4, int Ho, int Wo, float sh, float sw) {
     const unsigned total = (unsigned)N * Ho * Wo * C4;
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const unsigned q = e % C4; unsigned pix = e / C4;
         const int wo = (int)(pix % Wo); pix /= Wo;
         const int ho = (int)(pix % Ho), n = (int)(pix / Ho);
+        const int nv = min(4, C - 4 * (int)q);
         int h0, hp, w0, wp; float lh, lw;
         ac_src(ho, sh, H, h0, hp, lh); ac_src(wo, sw, W, w0, wp, lw);
         const float* b = x + ((long long)(n * H + h0) * W + w0) * ldx + 4 * q;
-        const float4 x00 = *reinterpret_cast<const float4*>(b), x01 = *reinterpret_cast<const float4*>(b + (long long)wp * ldx);
-        const float4 x10 = *reinterpret_cast<const float4*>(b + (long long)hp * W * ldx), x11 = *reinterpret_cast<const float4*>(b + ((long long)hp * W + wp) * ldx);
+        const float4 x00 = ldg4<VEC>(b, nv), x01 = ldg4<VEC>(b + (long long)wp * ldx, nv);
+        const float4 x10 = ldg4<VEC>(b + (long long)hp * W * ldx, nv), x11 = ldg4<VEC>(b + ((long long)hp * W + wp) * ldx, nv);
         float4 v;
         v.x = (1.f - lh) * ((1.f - lw) * x00.x + lw * x01.x) + lh * ((1.f - lw) * x10.x + lw * x11.x);
         v.y = (1.f - lh) * ((1.f - lw) * x00.y + lw * x01.y) + lh * ((1.f - lw) * x10.y + lw * x11.y);
         v.z = (1.f - lh) * ((1.f - lw) * x00.z + lw * x01.z) + lh * ((1.f - lw) * x10.z + lw * x11.z);
         v.w = (1.f - lh) * ((1.f - lw) * x00.w + lw * x01.w) + lh * ((1.f - lw) * x10.w + lw * x11.w);
-        *reinterpret_cast<float4*>(y + ((long long)(n * Ho + ho) * Wo + wo) * ldy + 4 * q) = v;
+        stg4<VEC>(y + ((long long)(n * Ho + ho) * Wo + wo) * ldy + 4 * q, v, nv);
     }
 }
 
@@ -116,12 +134,15 @@ __global__ __launch_bounds__(256) void bilinear_bwd_h_kernel(const float* __rest
     }
 }
 
+// tmp is (N, Ho, W, C) dense
+template <bool VEC>
 __global__ __launch_bounds__(256) void bilinear_bwd_w4_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ tmp,
-                                                               int N, int W, int C4, int Ho, int Wo, float sw) {
+                                                               int N, int W, int C, int C4, int Ho, int Wo, float sw) {
     const unsigned total = (unsigned)N * Ho * W * C4;
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const unsigned q = e % C4, pix = e / C4;
         const int w = (int)(pix % W); const unsigned row = pix / W;          // row = n*Ho + ho
+        const int nv = min(4, C - 4 * (int)q);
         int wlo, whi;
         ac_range(w, sw, Wo, wlo, whi);
         const float* r = dy + (long long)row * Wo * lddy + 4 * q;
@@ -129,31 +150,33 @@ __global__ __launch_bounds__(256) void bilinear_bwd_w4_kernel(const float* __res
         for (int wo = wlo; wo <= whi; ++wo) {
             const float ww = ac_weight(wo, sw, W, w);
             if (ww != 0.f) {
-                const float4 v = *reinterpret_cast<const float4*>(r + (long long)wo * lddy);
+                const float4 v = ldg4<VEC>(r + (long long)wo * lddy, nv);
                 acc.x += ww * v.x; acc.y += ww * v.y; acc.z += ww * v.z; acc.w += ww * v.w;
             }
         }
-        *reinterpret_cast<float4*>(tmp + 4ll * e) = acc;
+        stg4<VEC>(tmp + (long long)pix * C + 4 * q, acc, nv);
     }
 }
+template <bool VEC>
 __global__ __launch_bounds__(256) void bilinear_bwd_h4_kernel(const float* __restrict__ tmp, float* __restrict__ dx, int lddx,
-                                                               int N, int H, int W, int C4, int Ho, float sh) {
+                                                               int N, int H, int W, int C, int C4, int Ho, float sh) {
     const unsigned total = (unsigned)N * H * W * C4;
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const unsigned q = e % C4; unsigned pix = e / C4;
         const int w = (int)(pix % W); pix /= W;
         const int h = (int)(pix % H), n = (int)(pix / H);
+        const int nv = min(4, C - 4 * (int)q);
         int hlo, hhi;
         ac_range(h, sh, Ho, hlo, hhi);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int ho = hlo; ho <= hhi; ++ho) {
             const float wh = ac_weight(ho, sh, H, h);
             if (wh != 0.f) {
-                const float4 v = *reinterpret_cast<const float4*>(tmp + ((((long long)n * Ho + ho) * W + w) * C4 + q) * 4);
+                const float4 v = ldg4<VEC>(tmp + (((long long)n * Ho + ho) * W + w) * C + 4 * q, nv);
                 acc.x += wh * v.x; acc.y += wh * v.y; acc.z += wh * v.z; acc.w += wh * v.w;
             }
         }
-        *reinterpret_cast<float4*>(dx + ((long long)(n * H + h) * W + w) * lddx + 4 * q) = acc;
+        stg4<VEC>(dx + ((long long)(n * H + h) * W + w) * lddx + 4 * q, acc, nv);
     }
 }
 
@@ -1103,13 +1126,19 @@ using namespace dsrl;
     hipStream_t st = (hipStream_t)stream;                                           \
     if (int e_ = bind_stream_device(st)) return e_;
 
+static int env_int_sp(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static float ac_scale(int n_in, int n_out) { return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f; }
 
 extern "C" int dsrl_bilinear_ac_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int Ho, int Wo, dsrl_stream_t stream) {
     DSRL_PROLOGUE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && ldx >= C && ldy >= C, "bilinear_ac_fwd")
     if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (long long)N * Ho * Wo * C < (1ll << 32)) {
-        hipLaunchKernelGGL(bilinear_fwd4_kernel, dim3(flat_grid((long long)N * Ho * Wo * (C / 4))), dim3(256), 0, st, x, ldx, y, ldy, N, H, W, C / 4, Ho, Wo, ac_scale(H, Ho), ac_scale(W, Wo));
+        hipLaunchKernelGGL(bilinear_fwd4_kernel<true>, dim3(flat_grid((long long)N * Ho * Wo * (C / 4))), dim3(256), 0, st, x, ldx, y, ldy, N, H, W, C, C / 4, Ho, Wo, ac_scale(H, Ho), ac_scale(W, Wo));
         return launch_status("bilinear_fwd4_kernel");
+    }
+    const int Cg = (C + 3) / 4;           // any width: groups of four channels with 4-byte accesses
+    if ((long long)N * Ho * Wo * C < (1ll << 31) && env_int_sp("DSRL_BILINEAR_G4", 1)) {
+        hipLaunchKernelGGL(bilinear_fwd4_kernel<false>, dim3(flat_grid((long long)N * Ho * Wo * Cg)), dim3(256), 0, st, x, ldx, y, ldy, N, H, W, C, Cg, Ho, Wo, ac_scale(H, Ho), ac_scale(W, Wo));
+        return launch_status("bilinear_fwd4_kernel<any width>");
     }
     if ((long long)N * Ho * Wo * C < (1ll << 31))
         hipLaunchKernelGGL(bilinear_fwd_kernel<unsigned>, dim3(flat_grid((long long)N * Ho * Wo * C)), dim3(256), 0, st, x, ldx, y, ldy, N, H, W, C, Ho, Wo, ac_scale(H, Ho), ac_scale(W, Wo));
@@ -1124,10 +1153,17 @@ extern "C" int dsrl_bilinear_ac_bwd(const float* dy, int lddy, float* dx, int ld
     DSRL_REQUIRE(ws_bytes >= dsrl_bilinear_ac_bwd_workspace_bytes(N, H, W, C, Ho, Wo), DSRL_E_WORKSPACE, "bilinear_ac_bwd: workspace too small");
     if (C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)ws % 16) == 0 &&
         (long long)N * Ho * std::max(W, Wo) * C < (1ll << 32)) {
-        hipLaunchKernelGGL(bilinear_bwd_w4_kernel, dim3(flat_grid((long long)N * Ho * W * (C / 4))), dim3(256), 0, st, dy, lddy, (float*)ws, N, W, C / 4, Ho, Wo, ac_scale(W, Wo));
+        hipLaunchKernelGGL(bilinear_bwd_w4_kernel<true>, dim3(flat_grid((long long)N * Ho * W * (C / 4))), dim3(256), 0, st, dy, lddy, (float*)ws, N, W, C, C / 4, Ho, Wo, ac_scale(W, Wo));
         if (int e = launch_status("bilinear_bwd_w4_kernel")) return e;
-        hipLaunchKernelGGL(bilinear_bwd_h4_kernel, dim3(flat_grid((long long)N * H * W * (C / 4))), dim3(256), 0, st, (const float*)ws, dx, lddx, N, H, W, C / 4, Ho, ac_scale(H, Ho));
+        hipLaunchKernelGGL(bilinear_bwd_h4_kernel<true>, dim3(flat_grid((long long)N * H * W * (C / 4))), dim3(256), 0, st, (const float*)ws, dx, lddx, N, H, W, C, C / 4, Ho, ac_scale(H, Ho));
         return launch_status("bilinear_bwd_h4_kernel");
+    }
+    if ((long long)N * std::max(H, Ho) * std::max(W, Wo) * C < (1ll << 31) && env_int_sp("DSRL_BILINEAR_G4", 1)) {
+        const int Cg = (C + 3) / 4;
+        hipLaunchKernelGGL(bilinear_bwd_w4_kernel<false>, dim3(flat_grid((long long)N * Ho * W * Cg)), dim3(256), 0, st, dy, lddy, (float*)ws, N, W, C, Cg, Ho, Wo, ac_scale(W, Wo));
+        if (int e = launch_status("bilinear_bwd_w4_kernel<any width>")) return e;
+        hipLaunchKernelGGL(bilinear_bwd_h4_kernel<false>, dim3(flat_grid((long long)N * H * W * Cg)), dim3(256), 0, st, (const float*)ws, dx, lddx, N, H, W, C, Cg, Ho, ac_scale(H, Ho));
+        return launch_status("bilinear_bwd_h4_kernel<any width>");
     }
     const bool small = (long long)N * std::max(H, Ho) * std::max(W, Wo) * C < (1ll << 31);
     if (small) hipLaunchKernelGGL(bilinear_bwd_w_kernel<unsigned>, dim3(flat_grid((long long)N * Ho * W * C)), dim3(256), 0, st, dy, lddy, (float*)ws, N, W, C, Ho, Wo, ac_scale(W, Wo));

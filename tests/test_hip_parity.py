@@ -1323,6 +1323,29 @@ def test_train_step_stage1_stage2_b8_256x512(stage):
     assert all(v == 0.0 for v in fa) and (all(v == 0.0 for v in ms) if stage == 1 else all(v > 0.0 for v in ms))
 
 
+@pytest.mark.parametrize('C', [19, 3, 5, 1])
+def test_bilinear_any_width_groups_of_four_bit_identical_to_the_scalar_kernels(C, monkeypatch):
+    """align_corners=True resize of a tensor whose width is no multiple of 4 (the 19-channel logits upsample, DSRL.py:54): groups of four channels per thread
+    (index arithmetic and tap weights once per group, 4-byte accesses, a short last group) against the one-element-per-thread kernels (DSRL_BILINEAR_G4=0):
+    forward and backward bit-identical, and against torch's own CPU interpolate."""
+    rs = np.random.RandomState(C)
+    x = rs.standard_normal((2, C, 9, 13)).astype(np.float32)
+    dy = rs.standard_normal((2, C, 18, 26)).astype(np.float32)
+    got = {}
+    for g4 in ('1', '0'):
+        monkeypatch.setenv('DSRL_BILINEAR_G4', g4)
+        xt = dev(x).requires_grad_(True)
+        y = HF.upsample_bilinear_ac(xt, (18, 26))
+        y.backward(dev(dy))
+        torch.cuda.synchronize()
+        got[g4] = (host(y), host(xt.grad))
+    assert np.array_equal(got['1'][0], got['0'][0]) and np.array_equal(got['1'][1], got['0'][1])
+    xr = torch.from_numpy(x).requires_grad_(True)
+    yr = torch.nn.functional.interpolate(xr, size=(18, 26), mode='bilinear', align_corners=True)
+    yr.backward(torch.from_numpy(dy))
+    check(got['1'][0], yr.detach().numpy(), 1e-6, 'y'); check(got['1'][1], xr.grad.numpy(), 1e-5, 'dx')
+
+
 @pytest.mark.parametrize('widths,strided', [((256, 48), False), ((256, 256, 256, 256, 256), False), ((64, 32), True), ((19, 48), False)])
 def test_channel_concatenation_in_one_launch_with_its_magnitude(widths, strided, monkeypatch):
     """torch.cat(dim=1) of ASPP.py:44 / DSRL.py:165 as ONE kernel (dsrl_cat_channels) that also leaves max |value| in the amax record the consuming convs
