@@ -205,11 +205,12 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
 }
 
 // four channels per lane (C % 4 == 0, 16-byte aligned rows): one 16-byte store per lane instead of four 4-byte ones (21 -> 7 us on ASPP's 33 MB)
+template <typename I>      // unsigned when N * HW * C4 < 2^31 (host side): 32-bit divisions
 __global__ __launch_bounds__(256) void gap_bwd4_kernel(const float* __restrict__ dy, float* __restrict__ dx, int lddx, int N, int HW, int C4) {
-    const long long total = (long long)N * HW * C4;
+    const I total = (I)N * HW * C4;
     const float inv = 1.f / (float)HW;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C4); const long long p = e / C4; const int n = (int)(p / HW);
+    for (I e = (I)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (I)gridDim.x * blockDim.x) {
+        const int c = (int)(e % (I)C4); const long long p = (long long)(e / (I)C4); const int n = (int)((I)p / (I)HW);
         const float4 g = reinterpret_cast<const float4*>(dy)[(long long)n * C4 + c];
         *reinterpret_cast<float4*>(dx + p * lddx + 4 * c) = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
     }
@@ -1107,14 +1108,15 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     }
 }
 
+template <typename I>
 __global__ __launch_bounds__(256) void pad_image_kernel(const float* __restrict__ x, long long sn, long long sc, long long sh, long long sw,
                                                          float* __restrict__ y, int N, int C, int H, int W, int Cp, int top, int left, int Hp, int Wp) {
-    const long long total = (long long)N * Hp * Wp;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int wp = (int)(e % Wp); const long long t = e / Wp; const int hp = (int)(t % Hp); const long long n = t / Hp;
+    const I total = (I)N * Hp * Wp;
+    for (I e = (I)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (I)gridDim.x * blockDim.x) {
+        const int wp = (int)(e % (I)Wp); const I t = e / (I)Wp; const int hp = (int)(t % (I)Hp); const long long n = (long long)(t / (I)Hp);
         const int h = hp - top, w = wp - left;
         const bool in = h >= 0 && h < H && w >= 0 && w < W;
-        for (int c = 0; c < Cp; ++c) y[e * Cp + c] = (in && c < C) ? x[n * sn + c * sc + h * sh + w * sw] : 0.f;
+        for (int c = 0; c < Cp; ++c) y[(long long)e * Cp + c] = (in && c < C) ? x[n * sn + c * sc + h * sh + w * sw] : 0.f;
     }
 }
 
@@ -1181,7 +1183,8 @@ extern "C" int dsrl_global_avgpool_fwd(const float* x, int ldx, float* y, int N,
 extern "C" int dsrl_global_avgpool_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, dsrl_stream_t stream) {
     DSRL_PROLOGUE(dy && dx && N > 0 && HW > 0 && C > 0 && lddx >= C, "global_avgpool_bwd")
     if (C % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0) {
-        hipLaunchKernelGGL(gap_bwd4_kernel, dim3(flat_grid((long long)N * HW * (C / 4))), dim3(256), 0, st, dy, dx, lddx, N, HW, C / 4);
+        if ((long long)N * HW * (C / 4) < (1ll << 31)) hipLaunchKernelGGL(gap_bwd4_kernel<unsigned>, dim3(flat_grid((long long)N * HW * (C / 4))), dim3(256), 0, st, dy, dx, lddx, N, HW, C / 4);
+        else hipLaunchKernelGGL(gap_bwd4_kernel<long long>, dim3(flat_grid((long long)N * HW * (C / 4))), dim3(256), 0, st, dy, dx, lddx, N, HW, C / 4);
         return launch_status("gap_bwd4_kernel");
     }
     hipLaunchKernelGGL(gap_bwd_kernel, dim3(flat_grid((long long)N * HW * C)), dim3(256), 0, st, dy, dx, lddx, N, HW, C);
@@ -1461,7 +1464,11 @@ extern "C" int dsrl_cat_channels(const float* const* srcs, const int* lds, const
 extern "C" int dsrl_pad_image_nhwc(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* y,
                                    int N, int C, int H, int W, int Cp, int top, int left, int Hp, int Wp, dsrl_stream_t stream) {
     DSRL_PROLOGUE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C && top >= 0 && left >= 0 && Hp >= H + top && Wp >= W + left, "pad_image_nhwc")
-    hipLaunchKernelGGL(pad_image_kernel, dim3(flat_grid((long long)N * Hp * Wp)), dim3(256), 0, st, x, (long long)sn, (long long)sc, (long long)sh, (long long)sw,
-                       y, N, C, H, W, Cp, top, left, Hp, Wp);
+    if ((long long)N * Hp * Wp < (1ll << 31))
+        hipLaunchKernelGGL(pad_image_kernel<unsigned>, dim3(flat_grid((long long)N * Hp * Wp)), dim3(256), 0, st, x, (long long)sn, (long long)sc, (long long)sh, (long long)sw,
+                           y, N, C, H, W, Cp, top, left, Hp, Wp);
+    else
+        hipLaunchKernelGGL(pad_image_kernel<long long>, dim3(flat_grid((long long)N * Hp * Wp)), dim3(256), 0, st, x, (long long)sn, (long long)sc, (long long)sh, (long long)sw,
+                           y, N, C, H, W, Cp, top, left, Hp, Wp);
     return launch_status("pad_image_kernel");
 }
